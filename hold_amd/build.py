@@ -1,0 +1,51 @@
+"""In-tree build of libholdhip.so with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import glob
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SRC_DIR = os.path.join(_HERE, "csrc")
+OUT = os.path.join(_HERE, "libholdhip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(SRC_DIR, "*.hip")))
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = sources() + glob.glob(os.path.join(SRC_DIR, "*.h")) + glob.glob(os.path.join(_HERE, "..", "include", "*.h"))
+    return any(os.path.getmtime(s) > t for s in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(_HERE, "build"), exist_ok=True)
+    for s in sources():
+        o = os.path.join(_HERE, "build", os.path.basename(s) + ".o")
+        objs.append(o)
+        procs.append((s, subprocess.Popen(["hipcc", *FLAGS, "-c", s, "-o", o], stdout=subprocess.PIPE,
+                                          stderr=subprocess.STDOUT)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {s}:\n{out.decode()}")
+        if verbose and out:
+            print(out.decode())
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout.decode())
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,73 @@
+"""Thin python wrappers over hold_gemm_nt / hold_wgrad (include/hold_hip.h)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_DBWD, EPI_MUL_DRELU, EPI_MUL_DSIG, EPI_MUL_DSP, EPI_NONE, EPI_RELU, EPI_SIGMOID,  # noqa: F401
+                   EPI_SOFTPLUS, GemmDesc, check, ptr, stream_ptr)
+
+
+def _ld(t):
+    assert t.stride(-1) == 1, "innermost dim must be contiguous"
+    return t.stride(0)
+
+
+def gemm_nt(A, W, out, *, bias=None, epi=EPI_NONE, alpha=1.0, N=None, K=None, n_split=None, out_raw=None,
+            aux1=None, aux2=None, out2=None, accumulate=False):
+    """out[:, :N] = epi(alpha * A[:, :K] @ W[:N, :K].T + bias).  All tensors are 2-D fp32 CUDA views with unit
+    inner stride; row strides (leading dimensions) are taken from the views, so callers can write
+    straight into column slices of wider buffers."""
+    P = A.shape[0]
+    N = W.shape[0] if N is None else N
+    K = W.shape[1] if K is None else K
+    assert A.shape[1] >= K and W.shape[1] >= K and K % 4 == 0, (A.shape, W.shape, K)
+    d = GemmDesc()
+    d.A, d.lda = ptr(A), _ld(A)
+    d.W, d.ldw = ptr(W), _ld(W)
+    d.bias = ptr(bias)
+    d.C, d.ldc = ptr(out), _ld(out)
+    d.P, d.N, d.K = P, N, K
+    d.alpha = float(alpha)
+    d.epilogue = int(epi)
+    d.n_split = N if n_split is None else int(n_split)
+    if out_raw is not None:
+        d.C2, d.ldc2 = ptr(out_raw), _ld(out_raw)
+    if aux1 is not None:
+        d.aux1, d.ldaux1 = ptr(aux1), _ld(aux1)
+    if aux2 is not None:
+        d.aux2, d.ldaux2 = ptr(aux2), _ld(aux2)
+    if out2 is not None:
+        d.out2, d.ldout2 = ptr(out2), _ld(out2)
+    d.accumulate = 1 if accumulate else 0
+    check(_lib.lib().hold_gemm_nt(C.byref(d), stream_ptr()), "hold_gemm_nt")
+    return out
+
+
+_ws_cache = {}
+
+
+def _workspace(nfloats, device):
+    key = (device.index,)
+    w = _ws_cache.get(key)
+    if w is None or w.numel() < nfloats:
+        w = torch.empty(int(nfloats), dtype=torch.float32, device=device)
+        _ws_cache[key] = w
+    return w
+
+
+def wgrad(R, X, dW, db=None, *, N=None, K=None, accumulate=False, splits=None):
+    """dW[:N,:K] (+)= R[:, :N].T @ X[:, :K]; db[:N] (+)= R[:, :N].sum(0)."""
+    P = R.shape[0]
+    N = dW.shape[0] if N is None else N
+    K = dW.shape[1] if K is None else K
+    if splits is None:
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
+        splits = max(1, min(1024 // tiles, (P + 255) // 256))
+    L = _lib.lib()
+    ws = _workspace(L.hold_wgrad_workspace_floats(N, K, splits), R.device)
+    check(L.hold_wgrad(ptr(R), _ld(R), ptr(X), _ld(X), P, N, K, ptr(dW), _ld(dW), ptr(db), 1 if accumulate else 0,
+                       splits, ptr(ws), stream_ptr()), "hold_wgrad")
+    return dW

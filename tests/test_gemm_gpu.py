@@ -1,0 +1,92 @@
+"""GPU parity of the MFMA GEMM kernels against a torch fp64 reference of the same op."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _softplus_ref(y):
+    return torch.nn.functional.softplus(y, beta=100)
+
+
+@pytest.mark.parametrize("P,N,K", [(1000, 256, 256), (777, 217, 256), (130, 257, 256), (4096, 3, 256), (513, 256, 40),
+                                    (300, 39, 256), (260, 256, 272), (64, 128, 316)])
+def test_gemm_nt_plain_and_softplus(P, N, K):
+    from hold_amd import gemm
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(P + N + K)
+    A = torch.randn(P, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev) * 0.1
+    ref = A.double() @ W.double().t() + b.double()
+    out = torch.full((P, N + 5), -7.0, device=dev)
+    gemm.gemm_nt(A, W, out[:, :N], bias=b, N=N)
+    assert torch.all(out[:, N:] == -7.0)
+    err = (out[:, :N].double() - ref).abs().max().item()
+    assert err < 2e-5, err
+    # asymmetric check on layout: columns and rows must not be swapped
+    out2 = torch.empty(P, N, device=dev)
+    gemm.gemm_nt(A, W, out2, bias=b, epi=gemm.EPI_SOFTPLUS)
+    ref2 = _softplus_ref(ref * 0.05) if False else _softplus_ref(ref)
+    assert (out2.double() - ref2).abs().max().item() < 2e-5
+
+
+def test_gemm_split_and_epilogues():
+    from hold_amd import gemm
+    dev = _dev()
+    torch.manual_seed(0)
+    P, N, K = 515, 256, 256
+    A = torch.randn(P, K, device=dev)
+    W = torch.randn(N, K, device=dev) / 16
+    H = torch.nn.functional.softplus(torch.randn(P, 217, device=dev) * 0.05, beta=100)
+    add = torch.randn(P, 217, device=dev)
+    y = (A.double() @ W.double().t()) * 0.7071
+    out = torch.empty(P, 217, device=dev)
+    raw = torch.empty(P, 39, device=dev)
+    gemm.gemm_nt(A, W, out, epi=gemm.EPI_MUL_DSP, alpha=0.7071, n_split=217, out_raw=raw, aux1=H, aux2=add)
+    s = -torch.expm1(-100 * H.double())
+    assert (out.double() - (y[:, :217] * s + add.double())).abs().max().item() < 3e-5
+    assert (raw.double() - y[:, 217:]).abs().max().item() < 3e-5
+    # DBWD
+    Hf = torch.nn.functional.softplus(torch.randn(P, N, device=dev) * 0.05, beta=100)
+    T = torch.randn(P, N, device=dev)
+    o1 = torch.empty(P, N, device=dev)
+    o2 = torch.empty(P, N, device=dev)
+    gemm.gemm_nt(A, W, o1, epi=gemm.EPI_DBWD, aux1=Hf, aux2=T, out2=o2)
+    y = A.double() @ W.double().t()
+    s = -torch.expm1(-100 * Hf.double())
+    assert (o1.double() - y * s).abs().max().item() < 3e-5
+    ref2 = 100 * y * T.double() * (1 - s)
+    assert ((o2.double() - ref2).abs().max() / ref2.abs().max()).item() < 1e-5
+    # relu mask / sigmoid / accumulate
+    o3 = torch.empty(P, N, device=dev)
+    gemm.gemm_nt(A, W, o3, epi=gemm.EPI_MUL_DRELU, aux1=T)
+    assert (o3.double() - y * (T > 0)).abs().max().item() < 3e-5
+    o4 = torch.ones(P, N, device=dev)
+    gemm.gemm_nt(A, W, o4, accumulate=True)
+    assert (o4.double() - (y + 1)).abs().max().item() < 3e-5
+    o5 = torch.empty(P, N, device=dev)
+    gemm.gemm_nt(A, W, o5, epi=gemm.EPI_SIGMOID)
+    assert (o5.double() - torch.sigmoid(y)).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("P,N,K", [(5000, 256, 256), (1234, 217, 256), (999, 257, 256), (4100, 3, 256), (700, 256, 40),
+                                    (70, 256, 304)])
+def test_wgrad(P, N, K):
+    from hold_amd import gemm
+    dev = _dev()
+    torch.manual_seed(P)
+    R = torch.randn(P, N, device=dev)
+    X = torch.randn(P, K, device=dev)
+    dW = torch.ones(N, K, device=dev)
+    db = torch.ones(N, device=dev)
+    gemm.wgrad(R, X, dW, db, accumulate=True)
+    ref = R.double().t() @ X.double() + 1
+    refb = R.double().sum(0) + 1
+    assert ((dW.double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
+    assert ((db.double() - refb).abs().max() / refb.abs().max()).item() < 1e-5
