@@ -50,23 +50,67 @@ def lib():
     return _lib
 
 
+class CompositeDesc(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_int32), ("S", C.c_int32), ("n_rays", C.c_int64),
+        ("z", C.c_void_p * 3), ("sdf", C.c_void_p * 3), ("color", C.c_void_p * 3), ("normal", C.c_void_p * 3),
+        ("ldc", C.c_int32 * 3), ("ldn", C.c_int32 * 3), ("class_id", C.c_int32 * 3),
+        ("beta", C.c_float * 3),
+        ("out_node", C.c_void_p * 3), ("out_comp", C.c_void_p), ("out_sem", C.c_void_p), ("out_w", C.c_void_p),
+        ("out_zmerge", C.c_void_p),
+        ("d_node", C.c_void_p * 3), ("d_comp", C.c_void_p), ("d_sem", C.c_void_p),
+        ("d_sdf", C.c_void_p * 3), ("d_color", C.c_void_p * 3), ("d_normal", C.c_void_p * 3), ("d_beta", C.c_void_p),
+    ]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+# every exported symbol of include/hold_hip.h with its argument types (stream is always last)
+SIGNATURES = {
+    "hold_gemm_nt": [C.POINTER(GemmDesc), _P],
+    "hold_wgrad": [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _P],
+    "hold_ray_points": [_P, _P, _P, _I, _I, _L, _P, _I, _P],
+    "hold_embed_fwd": [_P, _I, _I, _I, _P, _L, _P, _I, _P, _I, _P, _I, _L, _P],
+    "hold_embed_bwd": [_P, _I, _I, _P, _L, _P, _I, _P, _I, _I, _P],
+    "hold_embed_bwd2": [_P, _I, _I, _P, _L, _P, _I, _P, _I, _P, _I, _P, _I, _P],
+    "hold_knn_invlbs_fwd": [_P, _I, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _P],
+    "hold_invskin_fwd": [_P, _I, _L, _L, _P, _P, _I, _P, _I, _P],
+    "hold_invskin_bwd": [_P, _I, _P, _P, _I, _L, _L, _P, _I, _P, _P],
+    "hold_normal_fwd": [_P, _I, _P, _P, _I, _L, _L, _P, _I, _P],
+    "hold_normal_bwd": [_P, _I, _P, _P, _I, _L, _L, _P, _I, _P, _I, _P, _P],
+    "hold_frame_colsum": [_P, _I, _I, _I, _L, _L, _P, _P],
+    "hold_frame_bcast": [_P, _I, _L, _L, _P, _I, _I, _P],
+    "hold_copy_cols": [_P, _I, _P, _I, _I, _L, _I, _P],
+    "hold_bg_points": [_P, _P, _P, _I, _L, _F, _P, _I, _P],
+    "hold_rowdot": [_P, _I, _P, _I, _F, _L, _P, _I, _P],
+    "hold_seed_dsp": [_P, _I, _P, _I, _L, _P, _I, _P],
+    "hold_colsum": [_P, _I, _I, _L, _P, _P],
+    "hold_sampler_init": [_P, _P, _L, _F, _F, _I, _F, _P, _P, _I, _P, _P, _P, _P],
+    "hold_sampler_beta": [_P, _P, _I, _I, _L, _P, _P, _I, _P, _F, _F, _I, _P, _P],
+    "hold_sampler_sample": [_P, _P, _I, _I, _L, _P, _I, _F, _P, _L, _I, _P, _P, _P],
+    "hold_sampler_final": [_P, _I, _P, _I, _P, _I, _P, _F, _L, _P, _I, _P],
+    "hold_composite_fwd": [C.POINTER(CompositeDesc), _P],
+    "hold_composite_bwd": [C.POINTER(CompositeDesc), _P],
+    "hold_bg_composite_fwd": [_P, _P, _P, _I, _I, _L, _P, _P, _P],
+    "hold_bg_composite_bwd": [_P, _P, _P, _I, _I, _L, _P, _P, _P, _P],
+}
+
+
 def _declare(L):
     L.hold_abi_version.restype = C.c_int
-    L.hold_gemm_nt.argtypes = [C.POINTER(GemmDesc), C.c_void_p]
-    L.hold_gemm_nt.restype = C.c_int
     L.hold_wgrad_workspace_floats.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     L.hold_wgrad_workspace_floats.restype = C.c_int64
-    L.hold_wgrad.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                             C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
-    L.hold_wgrad.restype = C.c_int
-    for name, args in _EXTRA.items():
-        fn = getattr(L, name)
+    for name, args in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError here = symbol missing from the shared object
         fn.argtypes = args
         fn.restype = C.c_int
 
 
-# filled by the op modules below this one (name -> argtypes) before first lib() call
-_EXTRA: dict = {}
+def call(name, *args):
+    """invoke an exported entry point on the current torch stream; raise on a non-zero code."""
+    L = lib()
+    code = getattr(L, name)(*args, stream_ptr())
+    if code != 0:
+        raise RuntimeError(f"libholdhip: {name} failed with code {code}")
 
 
 def stream_ptr():

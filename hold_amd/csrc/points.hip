@@ -1,0 +1,711 @@
+// Per-point kernels of the HOLD hot path (gfx950): ray points, Fourier embedding (+ its first and
+// second derivative products), KNN skinning-weight lookup fused with inverse LBS, canonical normals,
+// and their backward passes.  All are HBM/VALU bound (no matrix work).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hold_hip.h"
+
+namespace {
+
+constexpr int MAXV = 800;   // MANO has 778 vertices
+constexpr int NB = 16;      // MANO bones
+constexpr int KNN = 15;
+
+// ---------------------------------------------------------------------------------------------
+// points = cam_loc + z * dir                                  (mano_node.py:111, ray_sampler.py:162)
+// ---------------------------------------------------------------------------------------------
+__global__ void ray_points_kernel(const float* __restrict__ cam, const float* __restrict__ dirs,
+                                  const float* __restrict__ z, int ldz, int S, long P, float* __restrict__ out,
+                                  int ldo) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const long r = p / S;
+  const int s = (int)(p % S);
+  const float zz = z[r * ldz + s];
+  float* o = out + p * ldo;
+  o[0] = cam[r * 3 + 0] + zz * dirs[r * 3 + 0];
+  o[1] = cam[r * 3 + 1] + zz * dirs[r * 3 + 1];
+  o[2] = cam[r * 3 + 2] + zz * dirs[r * 3 + 2];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fourier embedding, one thread per (point, output column)             (embedders.py:18-50,92-122)
+// column layout: [x (d), sin(2^0 x) (d), cos(2^0 x) (d), sin(2^1 x) (d), ...], then cond[frame][:]
+// ---------------------------------------------------------------------------------------------
+__global__ void embed_fwd_kernel(const float* __restrict__ x, int ldx, int d, int L, const float* __restrict__ bw,
+                                 long P, float* __restrict__ out, int ldo, float* __restrict__ out2, int ldo2,
+                                 const float* __restrict__ cond, int cdim, long ppf) {
+  const int E = d + 2 * L * d;
+  const int W = E + cdim;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P * W) return;
+  const long p = i / W;
+  const int j = (int)(i % W);
+  if (j >= E) {
+    out[p * ldo + j] = cond[(p / ppf) * cdim + (j - E)];
+    return;
+  }
+  float v;
+  if (j < d) {
+    v = x[p * ldx + j];
+  } else {
+    const int q = (j - d) / d, dim = (j - d) % d;
+    const int k = q >> 1;
+    const float a = x[p * ldx + dim] * (float)(1 << k);
+    v = (q & 1) ? cosf(a) : sinf(a);
+  }
+  if (bw) v *= bw[j];
+  out[p * ldo + j] = v;
+  if (out2) out2[p * ldo2 + j] = v;
+}
+
+// gx[p][dim] (+)= sum_j dE_j/dx_dim * ge[p][j]      (chain rule through the embedding, d = 3)
+__global__ void embed_bwd_kernel(const float* __restrict__ x, int ldx, int L, const float* __restrict__ bw, long P,
+                                 const float* __restrict__ ge, int ldge, float* __restrict__ gx, int ldgx,
+                                 int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P * 3) return;
+  const long p = i / 3;
+  const int dim = (int)(i % 3);
+  const float xv = x[p * ldx + dim];
+  const float* g = ge + p * ldge;
+  float acc = g[dim] * (bw ? bw[dim] : 1.f);
+  for (int k = 0; k < L; ++k) {
+    const float f = (float)(1 << k);
+    float s, c;
+    sincosf(xv * f, &s, &c);
+    const int js = 3 + 6 * k + dim, jc = js + 3;
+    const float ws = bw ? bw[js] : 1.f, wc = bw ? bw[jc] : 1.f;
+    acc += f * (c * ws * g[js] - s * wc * g[jc]);
+  }
+  float* o = gx + p * ldgx + dim;
+  *o = accumulate ? *o + acc : acc;
+}
+
+// double backward of g = E^T ge:  gebar[p][j] = dE_j/dx_dim(j) * gbar[p][dim(j)];
+//                                 xbar[p][dim] += gbar[p][dim] * sum_j d2E_j/dx_dim^2 * ge[p][j]
+__global__ void embed_bwd2_kernel(const float* __restrict__ x, int ldx, int L, const float* __restrict__ bw, long P,
+                                  const float* __restrict__ ge, int ldge, const float* __restrict__ gbar, int ldgb,
+                                  float* __restrict__ gebar, int ldgeb, float* __restrict__ xbar, int ldxb) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P * 3) return;
+  const long p = i / 3;
+  const int dim = (int)(i % 3);
+  const float xv = x[p * ldx + dim];
+  const float gb = gbar[p * ldgb + dim];
+  const float* g = ge + p * ldge;
+  float* o = gebar + p * ldgeb;
+  o[dim] = gb * (bw ? bw[dim] : 1.f);
+  float acc = 0.f;
+  for (int k = 0; k < L; ++k) {
+    const float f = (float)(1 << k);
+    float s, c;
+    sincosf(xv * f, &s, &c);
+    const int js = 3 + 6 * k + dim, jc = js + 3;
+    const float ws = bw ? bw[js] : 1.f, wc = bw ? bw[jc] : 1.f;
+    o[js] = gb * f * c * ws;
+    o[jc] = -gb * f * s * wc;
+    acc += -f * f * (s * ws * g[js] + c * wc * g[jc]);
+  }
+  if (xbar) xbar[p * ldxb + dim] += gb * acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// KNN(K=15) skinning weights (+ fused inverse LBS)      (mano/deformer.py:84-105, 145-170)
+// one thread per query point; the frame's 778 vertices (SoA) and the 778x16 skinning table sit in LDS.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void inv3(const float* A, float* Ai) {
+  const float c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+  const float det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+  const float id = 1.0f / det;
+  Ai[0] = c00 * id;
+  Ai[1] = (A[2] * A[7] - A[1] * A[8]) * id;
+  Ai[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+  Ai[3] = c01 * id;
+  Ai[4] = (A[0] * A[8] - A[2] * A[6]) * id;
+  Ai[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+  Ai[6] = c02 * id;
+  Ai[7] = (A[1] * A[6] - A[0] * A[7]) * id;
+  Ai[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+}
+
+// blended transform: M[0..11] = sum_j w_j T_j[:3,:4], s = sum_j w_j T_j[3][3]
+__device__ __forceinline__ void blend_tf(const float* w, const float* T /*[nb][16]*/, int nb, float* M, float& s) {
+#pragma unroll
+  for (int e = 0; e < 12; ++e) M[e] = 0.f;
+  s = 0.f;
+  for (int j = 0; j < nb; ++j) {
+    const float wj = w[j];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) M[e] += wj * T[j * 16 + e];
+    s += wj * T[j * 16 + 15];
+  }
+}
+
+__global__ __launch_bounds__(256) void knn_invlbs_kernel(const float* __restrict__ x, int ldx, long P, long ppf,
+                                                        const float* __restrict__ verts, long vstride, int nv,
+                                                        const float* __restrict__ skin, const float* __restrict__ tfs,
+                                                        float* __restrict__ w_out, float* __restrict__ xc_out,
+                                                        int ldxc) {
+  __shared__ float sv[3][MAXV];
+  __shared__ __attribute__((aligned(16))) float sw[MAXV * NB];
+  __shared__ float st[NB * 16];
+  const long blocks_per_frame = (ppf + 255) / 256;
+  const long frame = blockIdx.x / blocks_per_frame;
+  const long off = (blockIdx.x % blocks_per_frame) * 256 + threadIdx.x;
+  const float* v = verts + frame * vstride;
+  for (int i = threadIdx.x; i < nv; i += 256) {
+    sv[0][i] = v[i * 3 + 0];
+    sv[1][i] = v[i * 3 + 1];
+    sv[2][i] = v[i * 3 + 2];
+  }
+  for (int i = threadIdx.x; i < nv * NB; i += 256) sw[i] = skin[i];
+  if (tfs && threadIdx.x < NB * 16) st[threadIdx.x] = tfs[frame * NB * 16 + threadIdx.x];
+  __syncthreads();
+  if (off >= ppf) return;
+  const long p = frame * ppf + off;
+  if (p >= P) return;
+  const float px = x[p * ldx + 0], py = x[p * ldx + 1], pz = x[p * ldx + 2];
+
+  float bd[KNN];
+  int bi[KNN];
+#pragma unroll
+  for (int k = 0; k < KNN; ++k) {
+    bd[k] = 3.0e38f;
+    bi[k] = 0;
+  }
+  for (int i = 0; i < nv; ++i) {
+    const float dx = px - sv[0][i], dy = py - sv[1][i], dz = pz - sv[2][i];
+    const float dist = dx * dx + dy * dy + dz * dz;
+    if (dist < bd[KNN - 1]) {
+      bd[KNN - 1] = dist;
+      bi[KNN - 1] = i;
+#pragma unroll
+      for (int k = KNN - 1; k > 0; --k) {
+        const bool sw_ = bd[k] < bd[k - 1];
+        const float d0 = bd[k - 1], d1 = bd[k];
+        const int i0 = bi[k - 1], i1 = bi[k];
+        bd[k - 1] = sw_ ? d1 : d0;
+        bd[k] = sw_ ? d0 : d1;
+        bi[k - 1] = sw_ ? i1 : i0;
+        bi[k] = sw_ ? i0 : i1;
+      }
+    }
+  }
+  // conf = exp(-min(d,4)) normalised; w = sum_k conf_k * skin[idx_k]
+  float conf[KNN], csum = 0.f;
+#pragma unroll
+  for (int k = 0; k < KNN; ++k) {
+    conf[k] = expf(-fminf(bd[k], 4.0f));
+    csum += conf[k];
+  }
+  float w[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) w[j] = 0.f;
+#pragma unroll
+  for (int k = 0; k < KNN; ++k) {
+    const float c = conf[k] / csum;
+    const float4* row = reinterpret_cast<const float4*>(sw + bi[k] * NB);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 r = row[q];
+      w[4 * q + 0] += r.x * c;
+      w[4 * q + 1] += r.y * c;
+      w[4 * q + 2] += r.z * c;
+      w[4 * q + 3] += r.w * c;
+    }
+  }
+  if (w_out) {
+    float4* wo = reinterpret_cast<float4*>(w_out + p * NB);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wo[q] = make_float4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+  }
+  if (xc_out) {
+    float M[12], s;
+    blend_tf(w, st, NB, M, s);
+    const float A[9] = {M[0], M[1], M[2], M[4], M[5], M[6], M[8], M[9], M[10]};
+    float Ai[9];
+    inv3(A, Ai);
+    const float is = 1.0f / s;
+    const float bx = px - M[3] * is, by = py - M[7] * is, bz = pz - M[11] * is;
+    float* o = xc_out + p * ldxc;
+    o[0] = Ai[0] * bx + Ai[1] * by + Ai[2] * bz;
+    o[1] = Ai[3] * bx + Ai[4] * by + Ai[5] * bz;
+    o[2] = Ai[6] * bx + Ai[7] * by + Ai[8] * bz;
+  }
+}
+
+// rigid / pre-blended variants: weights given (w != null, nb = 16) or single transform (w == null, nb = 1)
+__global__ void invskin_kernel(const float* __restrict__ x, int ldx, long P, long ppf, const float* __restrict__ w,
+                               const float* __restrict__ tfs, int nb, float* __restrict__ xc, int ldxc) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const long frame = p / ppf;
+  const float* T = tfs + frame * nb * 16;
+  float wl[NB];
+  if (w) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) wl[j] = w[p * NB + j];
+  } else {
+    wl[0] = 1.f;
+  }
+  float M[12], s;
+  blend_tf(wl, T, nb, M, s);
+  const float A[9] = {M[0], M[1], M[2], M[4], M[5], M[6], M[8], M[9], M[10]};
+  float Ai[9];
+  inv3(A, Ai);
+  const float is = 1.0f / s;
+  const float bx = x[p * ldx] - M[3] * is, by = x[p * ldx + 1] - M[7] * is, bz = x[p * ldx + 2] - M[11] * is;
+  float* o = xc + p * ldxc;
+  o[0] = Ai[0] * bx + Ai[1] * by + Ai[2] * bz;
+  o[1] = Ai[3] * bx + Ai[4] * by + Ai[5] * bz;
+  o[2] = Ai[6] * bx + Ai[7] * by + Ai[8] * bz;
+}
+
+// ---------------------------------------------------------------------------------------------
+// canonical normal: n = normalize(g . J^-1), J = sum_j w_j T_j[:3,:3]   (volsdf_utils.py:68-81,100-102)
+// ---------------------------------------------------------------------------------------------
+__global__ void normal_fwd_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ w,
+                                  const float* __restrict__ tfs, int nb, long P, long ppf, float* __restrict__ n_out,
+                                  int ldn) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const float* T = tfs + (p / ppf) * nb * 16;
+  float wl[NB];
+  if (w) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) wl[j] = w[p * NB + j];
+  } else {
+    wl[0] = 1.f;
+  }
+  float M[12], s;
+  blend_tf(wl, T, nb, M, s);
+  const float A[9] = {M[0], M[1], M[2], M[4], M[5], M[6], M[8], M[9], M[10]};
+  float Ai[9];
+  inv3(A, Ai);
+  const float g0 = g[p * ldg], g1 = g[p * ldg + 1], g2 = g[p * ldg + 2];
+  const float r0 = g0 * Ai[0] + g1 * Ai[3] + g2 * Ai[6];
+  const float r1 = g0 * Ai[1] + g1 * Ai[4] + g2 * Ai[7];
+  const float r2 = g0 * Ai[2] + g1 * Ai[5] + g2 * Ai[8];
+  const float nrm = fmaxf(sqrtf(r0 * r0 + r1 * r1 + r2 * r2), 1e-6f);
+  float* o = n_out + p * ldn;
+  o[0] = r0 / nrm;
+  o[1] = r1 / nrm;
+  o[2] = r2 / nrm;
+}
+
+// Block-level reduction of per-point contributions to d tfs: every thread deposits up to 12 values
+// and its weights in LDS; thread (j,e) then sums w_j * val_e over the block and does one atomicAdd.
+__device__ __forceinline__ void reduce_dtfs(float* sval /*[256][13]*/, float* swt /*[256][17]*/, const float* val12,
+                                            const float* wl, int nb, bool valid, float* __restrict__ dT /*frame*/) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int e = 0; e < 12; ++e) sval[t * 13 + e] = valid ? val12[e] : 0.f;
+  for (int j = 0; j < nb; ++j) swt[t * 17 + j] = valid ? wl[j] : 0.f;
+  __syncthreads();
+  if (t < nb * 12) {
+    const int j = t / 12, e = t % 12;
+    float acc = 0.f;
+    for (int q = 0; q < 256; ++q) acc += swt[q * 17 + j] * sval[q * 13 + e];
+    // e -> (row a = e/4, col b = e%4) of the 4x4
+    atomicAdd(dT + j * 16 + e, acc);
+  }
+  __syncthreads();
+}
+
+// backward of the canonical normal w.r.t. g and tfs
+__global__ __launch_bounds__(256) void normal_bwd_kernel(const float* __restrict__ g, int ldg,
+                                                        const float* __restrict__ w, const float* __restrict__ tfs,
+                                                        int nb, long P, long ppf, const float* __restrict__ nbar,
+                                                        int ldnb, float* __restrict__ gbar, int ldgb,
+                                                        float* __restrict__ dtfs) {
+  __shared__ float sval[256 * 13];
+  __shared__ float swt[256 * 17];
+  const long bpf = (ppf + 255) / 256;
+  const long frame = blockIdx.x / bpf;
+  const long off = (blockIdx.x % bpf) * 256 + threadIdx.x;
+  const bool valid = off < ppf && frame * ppf + off < P;
+  const long p = frame * ppf + (valid ? off : 0);
+  const float* T = tfs + frame * nb * 16;
+  float wl[NB];
+  if (w) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) wl[j] = w[p * NB + j];
+  } else {
+    wl[0] = 1.f;
+  }
+  float M[12], s;
+  blend_tf(wl, T, nb, M, s);
+  const float A[9] = {M[0], M[1], M[2], M[4], M[5], M[6], M[8], M[9], M[10]};
+  float Ai[9];
+  inv3(A, Ai);
+  const float g0 = g[p * ldg], g1 = g[p * ldg + 1], g2 = g[p * ldg + 2];
+  const float r[3] = {g0 * Ai[0] + g1 * Ai[3] + g2 * Ai[6], g0 * Ai[1] + g1 * Ai[4] + g2 * Ai[7],
+                      g0 * Ai[2] + g1 * Ai[5] + g2 * Ai[8]};
+  const float nr = sqrtf(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  const float nb0 = nbar[p * ldnb], nb1 = nbar[p * ldnb + 1], nb2 = nbar[p * ldnb + 2];
+  float rb[3];
+  if (nr > 1e-6f) {
+    const float inr = 1.0f / nr;
+    const float n0 = r[0] * inr, n1 = r[1] * inr, n2 = r[2] * inr;
+    const float dot = n0 * nb0 + n1 * nb1 + n2 * nb2;
+    rb[0] = (nb0 - n0 * dot) * inr;
+    rb[1] = (nb1 - n1 * dot) * inr;
+    rb[2] = (nb2 - n2 * dot) * inr;
+  } else {
+    rb[0] = nb0 * 1e6f;
+    rb[1] = nb1 * 1e6f;
+    rb[2] = nb2 * 1e6f;
+  }
+  // gbar_i = sum_j Ainv[i][j] rb_j
+  float gb[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) gb[i] = Ai[i * 3] * rb[0] + Ai[i * 3 + 1] * rb[1] + Ai[i * 3 + 2] * rb[2];
+  if (valid) {
+    gbar[p * ldgb] = gb[0];
+    gbar[p * ldgb + 1] = gb[1];
+    gbar[p * ldgb + 2] = gb[2];
+  }
+  // Jbar[a][b] = -r[a] * gb[b]
+  float val[12];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) val[a * 4 + b] = -r[a] * gb[b];
+    val[a * 4 + 3] = 0.f;
+  }
+  reduce_dtfs(sval, swt, val, wl, nb, valid, dtfs + frame * nb * 16);
+}
+
+// backward of x_c = A^-1 (x - t/s) w.r.t. tfs  (x itself carries no gradient: z_vals are detached)
+__global__ __launch_bounds__(256) void invskin_bwd_kernel(const float* __restrict__ xc, int ldxc,
+                                                         const float* __restrict__ w, const float* __restrict__ tfs,
+                                                         int nb, long P, long ppf, const float* __restrict__ xcbar,
+                                                         int ldxb, float* __restrict__ dtfs) {
+  __shared__ float sval[256 * 13];
+  __shared__ float swt[256 * 17];
+  const long bpf = (ppf + 255) / 256;
+  const long frame = blockIdx.x / bpf;
+  const long off = (blockIdx.x % bpf) * 256 + threadIdx.x;
+  const bool valid = off < ppf && frame * ppf + off < P;
+  const long p = frame * ppf + (valid ? off : 0);
+  const float* T = tfs + frame * nb * 16;
+  float wl[NB];
+  if (w) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) wl[j] = w[p * NB + j];
+  } else {
+    wl[0] = 1.f;
+  }
+  float M[12], s;
+  blend_tf(wl, T, nb, M, s);
+  const float A[9] = {M[0], M[1], M[2], M[4], M[5], M[6], M[8], M[9], M[10]};
+  float Ai[9];
+  inv3(A, Ai);
+  const float b0 = xcbar[p * ldxb], b1 = xcbar[p * ldxb + 1], b2 = xcbar[p * ldxb + 2];
+  // y = A^-T xcbar
+  const float y[3] = {Ai[0] * b0 + Ai[3] * b1 + Ai[6] * b2, Ai[1] * b0 + Ai[4] * b1 + Ai[7] * b2,
+                      Ai[2] * b0 + Ai[5] * b1 + Ai[8] * b2};
+  const float c[3] = {xc[p * ldxc], xc[p * ldxc + 1], xc[p * ldxc + 2]};
+  const float is = 1.0f / s;
+  float val[12];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) val[a * 4 + b] = -y[a] * c[b];
+    val[a * 4 + 3] = -y[a] * is;
+  }
+  reduce_dtfs(sval, swt, val, wl, nb, valid, dtfs + frame * nb * 16);
+}
+
+// out[frame][c] += sum over the frame's points of X[p][col0 + c]
+__global__ __launch_bounds__(256) void frame_colsum_kernel(const float* __restrict__ X, int ldx, int col0, int ncols,
+                                                          long P, long ppf, long rows_per_block,
+                                                          float* __restrict__ out) {
+  const long bpf = (ppf + rows_per_block - 1) / rows_per_block;
+  const long frame = blockIdx.x / bpf;
+  const long r0 = (blockIdx.x % bpf) * rows_per_block;
+  const long r1 = min(ppf, r0 + rows_per_block);
+  // thread t handles column t % ncols, row phase t / ncols
+  const int c = threadIdx.x % ncols, ph = threadIdx.x / ncols, nph = 256 / ncols;
+  if (ph >= nph) return;
+  float acc = 0.f;
+  for (long r = r0 + ph; r < r1; r += nph) {
+    const long p = frame * ppf + r;
+    if (p < P) acc += X[p * ldx + col0 + c];
+  }
+  atomicAdd(out + frame * ncols + c, acc);
+}
+
+// broadcast per-frame rows into columns of a per-point buffer: out[p][col0 + c] = src[frame][c]
+__global__ void frame_bcast_kernel(const float* __restrict__ src, int ncols, long P, long ppf, float* __restrict__ out,
+                                   int ldo, int col0) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P * ncols) return;
+  const long p = i / ncols;
+  const int c = (int)(i % ncols);
+  out[p * ldo + col0 + c] = src[(p / ppf) * ncols + c];
+}
+
+// strided 2-D copy: dst[p][c] = src[p][c] (c < ncols)
+__global__ void copy_cols_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst, int ldd, int ncols,
+                                 long P, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P * ncols) return;
+  const long p = i / ncols;
+  const int c = (int)(i % ncols);
+  float* o = dst + p * ldd + c;
+  const float v = src[p * lds_ + c];
+  *o = accumulate ? *o + v : v;
+}
+
+inline unsigned nblk(long n, int b = 256) { return (unsigned)((n + b - 1) / b); }
+inline int ok() { return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH; }
+
+}  // namespace
+
+extern "C" int hold_ray_points(const float* cam_loc, const float* ray_dirs, const float* z, int32_t ldz, int32_t S,
+                               int64_t n_rays, float* out, int32_t ldo, hold_stream_t st) {
+  if (!cam_loc || !ray_dirs || !z || !out || S <= 0) return HOLD_E_ARG;
+  const long P = n_rays * S;
+  if (P == 0) return HOLD_OK;
+  hipLaunchKernelGGL(ray_points_kernel, dim3(nblk(P)), dim3(256), 0, (hipStream_t)st, cam_loc, ray_dirs, z, ldz, S, P,
+                     out, ldo);
+  return ok();
+}
+
+extern "C" int hold_embed_fwd(const float* x, int32_t ldx, int32_t d_in, int32_t L, const float* barf_w, int64_t P,
+                              float* out, int32_t ldo, float* out2, int32_t ldo2, const float* cond, int32_t cond_dim,
+                              int64_t pts_per_frame, hold_stream_t st) {
+  if (!x || !out || d_in < 1 || d_in > 4 || L < 0 || L > 16 || (cond_dim > 0 && (!cond || pts_per_frame <= 0)))
+    return HOLD_E_ARG;
+  if (P == 0) return HOLD_OK;
+  const long W = d_in + 2 * L * d_in + cond_dim;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(nblk(P * W)), dim3(256), 0, (hipStream_t)st, x, ldx, d_in, L, barf_w,
+                     (long)P, out, ldo, out2, ldo2, cond, cond_dim, (long)(pts_per_frame > 0 ? pts_per_frame : 1));
+  return ok();
+}
+
+extern "C" int hold_embed_bwd(const float* x, int32_t ldx, int32_t L, const float* barf_w, int64_t P, const float* ge,
+                              int32_t ldge, float* gx, int32_t ldgx, int32_t accumulate, hold_stream_t st) {
+  if (!x || !ge || !gx) return HOLD_E_ARG;
+  if (P == 0) return HOLD_OK;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(nblk(P * 3)), dim3(256), 0, (hipStream_t)st, x, ldx, L, barf_w, (long)P, ge,
+                     ldge, gx, ldgx, accumulate);
+  return ok();
+}
+
+extern "C" int hold_embed_bwd2(const float* x, int32_t ldx, int32_t L, const float* barf_w, int64_t P, const float* ge,
+                               int32_t ldge, const float* gbar, int32_t ldgb, float* gebar, int32_t ldgeb, float* xbar,
+                               int32_t ldxb, hold_stream_t st) {
+  if (!x || !ge || !gbar || !gebar) return HOLD_E_ARG;
+  if (P == 0) return HOLD_OK;
+  hipLaunchKernelGGL(embed_bwd2_kernel, dim3(nblk(P * 3)), dim3(256), 0, (hipStream_t)st, x, ldx, L, barf_w, (long)P, ge,
+                     ldge, gbar, ldgb, gebar, ldgeb, xbar, ldxb);
+  return ok();
+}
+
+extern "C" int hold_knn_invlbs_fwd(const float* x, int32_t ldx, int64_t P, int64_t pts_per_frame, const float* verts,
+                                   int64_t verts_frame_stride, int32_t n_verts, const float* skin_w, const float* tfs,
+                                   float* w_out, float* xc_out, int32_t ldxc, hold_stream_t st) {
+  if (!x || !verts || !skin_w || n_verts < KNN || n_verts > MAXV || pts_per_frame <= 0) return HOLD_E_ARG;
+  if (xc_out && !tfs) return HOLD_E_ARG;
+  if (P == 0) return HOLD_OK;
+  const long frames = (P + pts_per_frame - 1) / pts_per_frame;
+  const long bpf = (pts_per_frame + 255) / 256;
+  hipLaunchKernelGGL(knn_invlbs_kernel, dim3((unsigned)(frames * bpf)), dim3(256), 0, (hipStream_t)st, x, ldx, (long)P,
+                     (long)pts_per_frame, verts, (long)verts_frame_stride, n_verts, skin_w, tfs, w_out, xc_out, ldxc);
+  return ok();
+}
+
+extern "C" int hold_invskin_fwd(const float* x, int32_t ldx, int64_t P, int64_t pts_per_frame, const float* w,
+                                const float* tfs, int32_t n_bones, float* xc, int32_t ldxc, hold_stream_t st) {
+  if (!x || !tfs || !xc || (n_bones != 1 && n_bones != NB) || (n_bones == NB && !w) || pts_per_frame <= 0)
+    return HOLD_E_ARG;
+  if (P == 0) return HOLD_OK;
+  hipLaunchKernelGGL(invskin_kernel, dim3(nblk(P)), dim3(256), 0, (hipStream_t)st, x, ldx, (long)P, (long)pts_per_frame,
+                     n_bones == 1 ? nullptr : w, tfs, n_bones, xc, ldxc);
+  return ok();
+}
+
+extern "C" int hold_normal_fwd(const float* g, int32_t ldg, const float* w, const float* tfs, int32_t n_bones,
+                               int64_t P, int64_t pts_per_frame, float* n_out, int32_t ldn, hold_stream_t st) {
+  if (!g || !tfs || !n_out || (n_bones != 1 && n_bones != NB) || (n_bones == NB && !w) || pts_per_frame <= 0)
+    return HOLD_E_ARG;
+  if (P == 0) return HOLD_OK;
+  hipLaunchKernelGGL(normal_fwd_kernel, dim3(nblk(P)), dim3(256), 0, (hipStream_t)st, g, ldg,
+                     n_bones == 1 ? nullptr : w, tfs, n_bones, (long)P, (long)pts_per_frame, n_out, ldn);
+  return ok();
+}
+
+extern "C" int hold_normal_bwd(const float* g, int32_t ldg, const float* w, const float* tfs, int32_t n_bones,
+                               int64_t P, int64_t pts_per_frame, const float* nbar, int32_t ldnb, float* gbar,
+                               int32_t ldgb, float* dtfs, hold_stream_t st) {
+  if (!g || !tfs || !nbar || !gbar || !dtfs || (n_bones != 1 && n_bones != NB) || (n_bones == NB && !w) ||
+      pts_per_frame <= 0)
+    return HOLD_E_ARG;
+  if (P == 0) return HOLD_OK;
+  const long frames = (P + pts_per_frame - 1) / pts_per_frame;
+  const long bpf = (pts_per_frame + 255) / 256;
+  hipLaunchKernelGGL(normal_bwd_kernel, dim3((unsigned)(frames * bpf)), dim3(256), 0, (hipStream_t)st, g, ldg,
+                     n_bones == 1 ? nullptr : w, tfs, n_bones, (long)P, (long)pts_per_frame, nbar, ldnb, gbar, ldgb,
+                     dtfs);
+  return ok();
+}
+
+extern "C" int hold_invskin_bwd(const float* xc, int32_t ldxc, const float* w, const float* tfs, int32_t n_bones,
+                                int64_t P, int64_t pts_per_frame, const float* xcbar, int32_t ldxb, float* dtfs,
+                                hold_stream_t st) {
+  if (!xc || !tfs || !xcbar || !dtfs || (n_bones != 1 && n_bones != NB) || (n_bones == NB && !w) ||
+      pts_per_frame <= 0)
+    return HOLD_E_ARG;
+  if (P == 0) return HOLD_OK;
+  const long frames = (P + pts_per_frame - 1) / pts_per_frame;
+  const long bpf = (pts_per_frame + 255) / 256;
+  hipLaunchKernelGGL(invskin_bwd_kernel, dim3((unsigned)(frames * bpf)), dim3(256), 0, (hipStream_t)st, xc, ldxc,
+                     n_bones == 1 ? nullptr : w, tfs, n_bones, (long)P, (long)pts_per_frame, xcbar, ldxb, dtfs);
+  return ok();
+}
+
+extern "C" int hold_frame_colsum(const float* X, int32_t ldx, int32_t col0, int32_t ncols, int64_t P,
+                                 int64_t pts_per_frame, float* out, hold_stream_t st) {
+  if (!X || !out || ncols <= 0 || ncols > 256 || pts_per_frame <= 0) return HOLD_E_ARG;
+  if (P == 0) return HOLD_OK;
+  const long frames = (P + pts_per_frame - 1) / pts_per_frame;
+  const long rpb = 4096;
+  const long bpf = (pts_per_frame + rpb - 1) / rpb;
+  hipLaunchKernelGGL(frame_colsum_kernel, dim3((unsigned)(frames * bpf)), dim3(256), 0, (hipStream_t)st, X, ldx, col0,
+                     ncols, (long)P, (long)pts_per_frame, rpb, out);
+  return ok();
+}
+
+extern "C" int hold_frame_bcast(const float* src, int32_t ncols, int64_t P, int64_t pts_per_frame, float* out,
+                                int32_t ldo, int32_t col0, hold_stream_t st) {
+  if (!src || !out || ncols <= 0 || pts_per_frame <= 0) return HOLD_E_ARG;
+  if (P == 0) return HOLD_OK;
+  hipLaunchKernelGGL(frame_bcast_kernel, dim3(nblk(P * ncols)), dim3(256), 0, (hipStream_t)st, src, ncols, (long)P,
+                     (long)pts_per_frame, out, ldo, col0);
+  return ok();
+}
+
+extern "C" int hold_copy_cols(const float* src, int32_t lds, float* dst, int32_t ldd, int32_t ncols, int64_t P,
+                              int32_t accumulate, hold_stream_t st) {
+  if (!src || !dst || ncols <= 0) return HOLD_E_ARG;
+  if (P == 0) return HOLD_OK;
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(nblk(P * ncols)), dim3(256), 0, (hipStream_t)st, src, lds, dst, ldd, ncols,
+                     (long)P, accumulate);
+  return ok();
+}
+
+// ---------------------------------------------------------------------------------------------
+// NeRF++ inverted-sphere background points (code/src/model/renderables/background.py:102-135)
+// and small dense helpers
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ void bg_points_kernel(const float* __restrict__ cam, const float* __restrict__ dirs,
+                                 const float* __restrict__ depth, int S, long P, float R, float* __restrict__ out,
+                                 int ldo) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const long r = p / S;
+  const float ox = cam[r * 3], oy = cam[r * 3 + 1], oz = cam[r * 3 + 2];
+  const float dx = dirs[r * 3], dy = dirs[r * 3 + 1], dz = dirs[r * 3 + 2];
+  const float dep = depth[p];
+  const float odd = dx * ox + dy * oy + dz * oz;
+  const float under = odd * odd - ((ox * ox + oy * oy + oz * oz) - R * R);
+  const float dsph = sqrtf(under) - odd;
+  const float sx = ox + dsph * dx, sy = oy + dsph * dy, sz = oz + dsph * dz;
+  const float mx = ox - odd * dx, my = oy - odd * dy, mz = oz - odd * dz;
+  const float mnorm = sqrtf(mx * mx + my * my + mz * mz);
+  float ax = oy * sz - oz * sy, ay = oz * sx - ox * sz, az = ox * sy - oy * sx;
+  const float an = sqrtf(ax * ax + ay * ay + az * az);
+  ax /= an; ay /= an; az /= an;
+  const float phi = asinf(mnorm / R), theta = asinf(mnorm * dep);
+  const float ra = phi - theta;
+  const float c = cosf(ra), s = sinf(ra);
+  const float cx = ay * sz - az * sy, cy = az * sx - ax * sz, cz = ax * sy - ay * sx;
+  const float dot = ax * sx + ay * sy + az * sz;
+  float nx = sx * c + cx * s + ax * dot * (1.0f - c);
+  float ny = sy * c + cy * s + ay * dot * (1.0f - c);
+  float nz = sz * c + cz * s + az * dot * (1.0f - c);
+  const float nn = sqrtf(nx * nx + ny * ny + nz * nz);
+  float* o = out + p * ldo;
+  o[0] = nx / nn; o[1] = ny / nn; o[2] = nz / nn; o[3] = dep;
+}
+
+// out[p] = sum_k A[p][k] * w[k] + b   (one wave per row, K <= 256*... any K multiple of 4)
+__global__ void rowdot_kernel(const float* __restrict__ A, int lda, const float* __restrict__ w, int K, float b,
+                              long P, float* __restrict__ out, int ldo) {
+  const int lane = threadIdx.x & 63;
+  const long p = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (p >= P) return;
+  float acc = 0.f;
+  for (int k = lane * 4; k < K; k += 256) {
+    const float4 a = *reinterpret_cast<const float4*>(A + p * lda + k);
+    const float4 ww = *reinterpret_cast<const float4*>(w + k);
+    acc += a.x * ww.x + a.y * ww.y + a.z * ww.z + a.w * ww.w;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+  if (lane == 0) out[p * ldo] = acc + b;
+}
+
+// t[p][n] = w[n] * softplus'(h[p][n])   (start of the reverse sweep: u_7 = W_8[sdf row])
+__global__ void seed_dsp_kernel(const float* __restrict__ h, int ldh, const float* __restrict__ w, int N, long P,
+                                float* __restrict__ t, int ldt) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P * N) return;
+  const long p = i / N;
+  const int n = (int)(i % N);
+  t[p * ldt + n] = w[n] * (-expm1f(-100.0f * h[p * ldh + n]));
+}
+
+// column sums: out[n] += sum_p X[p][n]   (n < N <= 512); blocks stride over rows
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int ldx, int N, long P,
+                                                    long rows_per_block, float* __restrict__ out) {
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(P, r0 + rows_per_block);
+  for (int n = threadIdx.x; n < N; n += 256) {
+    float acc = 0.f;
+    for (long r = r0; r < r1; ++r) acc += X[r * ldx + n];
+    atomicAdd(out + n, acc);
+  }
+}
+}  // namespace
+
+extern "C" int hold_bg_points(const float* cam_loc, const float* ray_dirs, const float* depth, int32_t S,
+                              int64_t n_rays, float R, float* out, int32_t ldo, hold_stream_t st) {
+  if (!cam_loc || !ray_dirs || !depth || !out || S <= 0) return HOLD_E_ARG;
+  const long P = n_rays * S;
+  if (P == 0) return HOLD_OK;
+  hipLaunchKernelGGL(bg_points_kernel, dim3(nblk(P)), dim3(256), 0, (hipStream_t)st, cam_loc, ray_dirs, depth, S, P, R,
+                     out, ldo);
+  return ok();
+}
+
+extern "C" int hold_rowdot(const float* A, int32_t lda, const float* w, int32_t K, float b, int64_t P, float* out,
+                           int32_t ldo, hold_stream_t st) {
+  if (!A || !w || !out || (K & 3) || (lda & 3)) return HOLD_E_ARG;
+  if (P == 0) return HOLD_OK;
+  hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, (hipStream_t)st, A, lda, w, K, b,
+                     (long)P, out, ldo);
+  return ok();
+}
+
+extern "C" int hold_seed_dsp(const float* h, int32_t ldh, const float* w, int32_t N, int64_t P, float* t, int32_t ldt,
+                             hold_stream_t st) {
+  if (!h || !w || !t || N <= 0) return HOLD_E_ARG;
+  if (P == 0) return HOLD_OK;
+  hipLaunchKernelGGL(seed_dsp_kernel, dim3(nblk((long)P * N)), dim3(256), 0, (hipStream_t)st, h, ldh, w, N, (long)P, t,
+                     ldt);
+  return ok();
+}
+
+extern "C" int hold_colsum(const float* X, int32_t ldx, int32_t N, int64_t P, float* out, hold_stream_t st) {
+  if (!X || !out || N <= 0) return HOLD_E_ARG;
+  if (P == 0) return HOLD_OK;
+  const long rpb = 2048;
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((P + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)st, X, ldx, N,
+                     (long)P, rpb, out);
+  return ok();
+}

@@ -1,0 +1,318 @@
+"""Canonical SDF / colour field of one foreground node on the HIP kernels.
+
+Host-side orchestration of ImplicitNet.forward (code/src/networks/shape_net.py:84-130), the
+canonical normal of extract_features (code/src/engine/volsdf_utils.py:51-105), RenderingNet.forward in
+mode 'pose' (code/src/networks/texture_net.py:46-101) and their hand-derived backward (including the
+second-order terms torch would get from ``create_graph=True``), as sequences of libholdhip launches.
+Nothing here computes on the CPU or with torch math beyond tiny per-layer weight re-layouts.
+
+Buffers (fp32, ray-major points p = ray*S + s):
+  x      [P,4]   query points in deformed space          xc   [P,4]  canonical points
+  in0    [P,K0]  embedding (+cond)                        h[l] [P,256] softplus outputs (h[3] = [h3|embed])
+  rin    [P,Kr]  render-net input [xc,n,pose8,feat256(,time32)]
+  t[l]   [P,256] reverse-sweep d sdf/d a_l               ge   [P,K0]  d sdf/d embed       g [P,4] d sdf/d xc
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import gemm as G
+from . import kernels as K
+
+FEAT = 256
+RIN_X, RIN_N, RIN_POSE, RIN_FEAT = 0, 3, 6, 14
+
+
+def pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class Pool:
+    """named scratch buffers, grown on demand, zero-initialised on (re)allocation."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs = {}
+
+    def get(self, name, rows, cols, dtype=torch.float32):
+        b = self.bufs.get(name)
+        if b is None or b.shape[0] < rows or b.shape[1] != cols or b.dtype != dtype:
+            b = torch.zeros(rows, cols, dtype=dtype, device=self.device)
+            self.bufs[name] = b
+        return b[:rows]
+
+    def nbytes(self):
+        return sum(b.numel() * b.element_size() for b in self.bufs.values())
+
+
+class FieldSpec:
+    """static shape description of a node's networks."""
+
+    def __init__(self, kind):
+        assert kind in ("hand", "object")
+        self.kind = kind
+        self.L = 6
+        self.E = 3 + 3 * 2 * self.L  # 39
+        self.K0 = pad4(self.E)  # 40
+        self.skip_out = 256 - self.E  # 217
+        self.skip_pad = pad4(self.skip_out)  # 220
+        self.time = 32 if kind == "object" else 0
+        self.rin_dim = 3 + 3 + 8 + FEAT + self.time  # 270 / 302
+        self.Kr = pad4(self.rin_dim)
+        self.n_bones = 1 if kind == "object" else 16
+
+
+def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
+    """iw/ib: 9 effective ImplicitNet weights/biases ([out,in] as nn.Linear); rw/rb: 5 RenderingNet ones.
+    Returns the re-laid-out (and, for sweeps that contract over the output index, transposed) copies the
+    kernels read.  Tiny (<= 256x304) device ops once per step."""
+    dev = iw[0].device
+    pk = {}
+    W = []
+    w0 = torch.zeros(256, spec.K0, device=dev)
+    w0[:, :spec.E] = iw[0][:, :spec.E]  # the 45 MANO pose-cond columns multiply zeros (shape_net.py:104-106)
+    W.append(w0)
+    W += [iw[1].contiguous(), iw[2].contiguous(), iw[3].contiguous()]
+    W.append((iw[4] / math.sqrt(2)).contiguous())  # cat([x, input]) / sqrt(2) folded into the weight
+    W += [iw[5].contiguous(), iw[6].contiguous(), iw[7].contiguous()]
+    w8 = torch.cat([iw[8][1:], iw[8][:1]], 0).contiguous()  # rows: feat(256) then sdf
+    W.append(w8)
+    pk["W"] = W
+    pk["b"] = [b.contiguous() for b in ib[:8]] + [torch.cat([ib[8][1:], ib[8][:1]]).contiguous()]
+    pk["w8_sdf"] = iw[8][0].contiguous()
+    pk["b8_sdf"] = ib[8][0]
+    # transposes [K_l][pad4(N_l)] for the sweeps that contract over the output index
+    WT = []
+    for l in range(9):
+        n, k = W[l].shape
+        wt = torch.zeros(k, pad4(n), device=dev)
+        wt[:, :n] = W[l].t()
+        WT.append(wt)
+    pk["WT"] = WT
+    r0 = torch.zeros(256, spec.Kr, device=dev)
+    r0[:, :spec.rin_dim] = rw[0]
+    R = [r0, rw[1].contiguous(), rw[2].contiguous(), rw[3].contiguous(), rw[4].contiguous()]
+    pk["R"] = R
+    pk["rb"] = [b.contiguous() for b in rb]
+    if need_bwd:
+        RT = []
+        for l in range(5):
+            n, k = R[l].shape
+            rt = torch.zeros(k, pad4(n), device=dev)
+            rt[:, :n] = R[l].t()
+            RT.append(rt)
+        pk["RT"] = RT
+    return pk
+
+
+class NodeField:
+    """runs one node's field on a batch of points; owns its scratch pool."""
+
+    def __init__(self, spec: FieldSpec, device):
+        self.spec = spec
+        self.pool = Pool(device)
+        self.device = device
+
+    # ------------------------------------------------------------------ deformation
+    def _deform(self, x, P, ppf, dfm, want_w):
+        """x [P,4] deformed-space points -> xc [P,4].  dfm: dict(tfs [B,nb,16], verts [B,778,3], skin_w)."""
+        sp = self.spec
+        xc = self.pool.get("xc", P, 4)
+        if sp.n_bones == 1:
+            K.invskin_fwd(x, P, ppf, None, dfm["tfs"], 1, xc)
+            return xc, None
+        w = self.pool.get("w_def", P, 16) if want_w else None
+        K.knn_invlbs(x, P, ppf, dfm["verts"], dfm["skin_w"], tfs=dfm["tfs"], w_out=w, xc_out=xc)
+        return xc, w
+
+    # ------------------------------------------------------------------ implicit net trunk
+    def _trunk(self, pk, xc, P, barf_w, keep_all):
+        sp, pool = self.spec, self.pool
+        in0 = pool.get("in0", P, sp.K0)
+        h = [pool.get(f"h{l}" if (keep_all or l == 3) else f"h_pp{l & 1}", P, 256) for l in range(8)]
+        K.embed_fwd(xc, 3, sp.L, P, in0, out2=h[3][:, sp.skip_out:], barf_w=barf_w)
+        W, b = pk["W"], pk["b"]
+        G.gemm_nt(in0, W[0], h[0], bias=b[0], epi=G.EPI_SOFTPLUS, K=sp.K0)
+        G.gemm_nt(h[0], W[1], h[1], bias=b[1], epi=G.EPI_SOFTPLUS)
+        G.gemm_nt(h[1], W[2], h[2], bias=b[2], epi=G.EPI_SOFTPLUS)
+        G.gemm_nt(h[2], W[3], h[3][:, :sp.skip_out], bias=b[3], epi=G.EPI_SOFTPLUS, N=sp.skip_out)
+        G.gemm_nt(h[3], W[4], h[4], bias=b[4], epi=G.EPI_SOFTPLUS)
+        G.gemm_nt(h[4], W[5], h[5], bias=b[5], epi=G.EPI_SOFTPLUS)
+        G.gemm_nt(h[5], W[6], h[6], bias=b[6], epi=G.EPI_SOFTPLUS)
+        G.gemm_nt(h[6], W[7], h[7], bias=b[7], epi=G.EPI_SOFTPLUS)
+        return in0, h
+
+    def sdf_only(self, pk, x, P, ppf, dfm, barf_w, out_sdf):
+        """no-grad SDF query of the sampler (sdf_func_with_deformer, volsdf_utils.py:150-169).  out_sdf [P,1]."""
+        xc, _ = self._deform(x, P, ppf, dfm, want_w=False)
+        # ping-pong activations: only two [P,256] buffers (+ the skip buffer) stay live
+        _, h = self._trunk(pk, xc, P, barf_w, keep_all=False)
+        K.rowdot(h[7], pk["w8_sdf"], 256, float(pk["b8_sdf"]), P, out_sdf)
+
+    # ------------------------------------------------------------------ full forward
+    def forward(self, pk, x, P, ppf, dfm, barf_w, pose_embed, time_code, training):
+        """-> dict(sdf [P,1], rgb [P,4], normal = rin[:,3:6], xc, feat = rin[:,14:270])."""
+        sp, pool = self.spec, self.pool
+        xc, w_def = self._deform(x, P, ppf, dfm, want_w=training)
+        in0, h = self._trunk(pk, xc, P, barf_w, keep_all=True)
+        rin = pool.get("rin", P, sp.Kr)
+        sdf = pool.get("sdf", P, 1)
+        G.gemm_nt(h[7], pk["W"][8], rin[:, RIN_FEAT:RIN_FEAT + FEAT], bias=pk["b"][8], N=257, n_split=256,
+                  out_raw=sdf)
+        # ---- reverse sweep: t_l = d sdf / d a_l, ge = d sdf / d embed, g = d sdf / d xc ----
+        WT = pk["WT"]
+        # t[3] always has its own buffer: its columns 217..219 are K-padding of the next GEMM and must stay zero
+        t = [pool.get(f"t{l}" if (training or l == 3) else f"t_pp{l & 1}", P, 256) for l in range(8)]
+        ge = pool.get("ge", P, sp.K0)
+        K.seed_dsp(h[7], pk["w8_sdf"], 256, P, t[7])
+        for l in range(7, 0, -1):
+            if l == 4:
+                G.gemm_nt(t[4], WT[4], t[3][:, :sp.skip_out], epi=G.EPI_MUL_DSP, aux1=h[3], N=256,
+                          n_split=sp.skip_out, out_raw=ge)
+            elif l == 3:
+                G.gemm_nt(t[3], WT[3], t[2], epi=G.EPI_MUL_DSP, aux1=h[2], K=sp.skip_pad)
+            else:
+                G.gemm_nt(t[l], WT[l], t[l - 1], epi=G.EPI_MUL_DSP, aux1=h[l - 1])
+        G.gemm_nt(t[0], WT[0], ge, N=sp.K0, accumulate=True)
+        g = pool.get("g", P, 4)
+        K.embed_bwd(xc, sp.L, P, ge, g, barf_w=barf_w)
+        # ---- canonical normal + render-net input assembly ----
+        if sp.n_bones == 1:
+            w_c = None
+        else:
+            w_c = pool.get("w_cano", P, 16)
+            K.knn_invlbs(xc, P, ppf, dfm["verts_c"], dfm["skin_w"], w_out=w_c)
+        K.copy_cols(xc, rin[:, RIN_X:RIN_X + 3], 3, P)
+        K.normal_fwd(g, w_c, dfm["tfs"], sp.n_bones, P, ppf, rin[:, RIN_N:RIN_N + 3])
+        K.frame_bcast(pose_embed, P, ppf, rin, RIN_POSE)
+        if sp.time:
+            K.frame_bcast(time_code, P, ppf, rin, RIN_FEAT + FEAT)
+        # ---- rendering net ----
+        R, rb = pk["R"], pk["rb"]
+        r = [pool.get(f"r{l}", P, 256) for l in range(4)]
+        G.gemm_nt(rin, R[0], r[0], bias=rb[0], epi=G.EPI_RELU, K=sp.Kr)
+        G.gemm_nt(r[0], R[1], r[1], bias=rb[1], epi=G.EPI_RELU)
+        G.gemm_nt(r[1], R[2], r[2], bias=rb[2], epi=G.EPI_RELU)
+        G.gemm_nt(r[2], R[3], r[3], bias=rb[3], epi=G.EPI_RELU)
+        rgb = pool.get("rgb", P, 4)
+        G.gemm_nt(r[3], R[4], rgb, bias=rb[4], epi=G.EPI_SIGMOID, N=3)
+        self.saved = dict(P=P, ppf=ppf, xc=xc, w_def=w_def, w_c=w_c, in0=in0, h=h, t=t, ge=ge, g=g, rin=rin, r=r,
+                          rgb=rgb, sdf=sdf, dfm=dfm, barf_w=barf_w, pk=pk)
+        return dict(sdf=sdf, rgb=rgb, normal=rin[:, RIN_N:RIN_N + 3], xc=xc, feat=rin[:, RIN_FEAT:RIN_FEAT + FEAT],
+                    grad=g)
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, d_sdf, d_rgb, d_normal, n_frames):
+        """d_sdf [P] / [P,1], d_rgb [P,3], d_normal [P,3] (may be None) -> dict of gradients:
+        iw[9], ib[9] (w.r.t. the EFFECTIVE implicit weights as passed to pack_weights), rw[5], rb[5],
+        tfs [B,nb,16], pose_embed [B,8], time_code [B,32] (object)."""
+        sp, pool = self.spec, self.pool
+        sv = self.saved
+        P, ppf, pk = sv["P"], sv["ppf"], sv["pk"]
+        h, t, rin, r, rgb, xc = sv["h"], sv["t"], sv["rin"], sv["r"], sv["rgb"], sv["xc"]
+        dev = self.device
+        W, WT, R, RT = pk["W"], pk["WT"], pk["R"], pk["RT"]
+        dR = [torch.zeros_like(m) for m in R]
+        dRb = [torch.zeros_like(b) for b in pk["rb"]]
+        dW = [torch.zeros_like(m) for m in W]
+        dWb = [torch.zeros_like(b) for b in pk["b"]]
+        # ---------- rendering net ----------
+        dy = pool.get("dy4", P, 4)
+        sg = rgb[:, :3]
+        dy[:, :3] = d_rgb * sg * (1.0 - sg)  # sigmoid'  (3 columns, elementwise)
+        G.wgrad(dy, r[3], dR[4], dRb[4], N=3, K=256)
+        rr = [pool.get(f"rr{i}", P, 256) for i in range(2)]
+        G.gemm_nt(dy, RT[4], rr[1], epi=G.EPI_MUL_DRELU, aux1=r[3], K=4)
+        cur = rr[1]
+        for l in (3, 2, 1):
+            G.wgrad(cur, r[l - 1], dR[l], dRb[l])
+            nxt = rr[0] if cur is rr[1] else rr[1]
+            G.gemm_nt(cur, RT[l], nxt, epi=G.EPI_MUL_DRELU, aux1=r[l - 1])
+            cur = nxt
+        G.wgrad(cur, rin, dR[0], dRb[0], K=sp.Kr)
+        d_rin = pool.get("d_rin", P, sp.Kr)
+        G.gemm_nt(cur, RT[0], d_rin, N=sp.Kr)
+        B = n_frames
+        d_pose = torch.zeros(B, 8, device=dev)
+        K.frame_colsum(d_rin, RIN_POSE, 8, P, ppf, d_pose)
+        d_time = None
+        if sp.time:
+            d_time = torch.zeros(B, sp.time, device=dev)
+            K.frame_colsum(d_rin, RIN_FEAT + FEAT, sp.time, P, ppf, d_time)
+        # ---------- normal ----------
+        nbar = pool.get("nbar", P, 4)
+        K.copy_cols(d_rin[:, RIN_N:RIN_N + 3], nbar, 3, P)
+        if d_normal is not None:
+            K.copy_cols(d_normal, nbar, 3, P, accumulate=True)
+        gbar = pool.get("gbar", P, 4)
+        dtfs = torch.zeros(B, sp.n_bones, 16, device=dev)
+        K.normal_bwd(sv["g"], sv["w_c"], sv["dfm"]["tfs"], sp.n_bones, P, ppf, nbar, gbar, dtfs)
+        # ---------- second-order path: gbar -> embedding -> ascending sweep ----------
+        xbar = pool.get("xbar", P, 4)
+        K.copy_cols(d_rin[:, RIN_X:RIN_X + 3], xbar, 3, P)
+        gebar = pool.get("gebar", P, sp.K0)
+        K.embed_bwd2(xc, sp.L, P, sv["ge"], gbar, gebar, xbar=xbar, barf_w=sv["barf_w"])
+        a2 = [pool.get(f"a2_{l}", P, 256) for l in range(8)]
+        vb = [pool.get(f"vb{i}", P, 256) for i in range(2)]
+        # l = 0: tbar_0 = W0 vbar_0 ; ubar_0 = tbar*s ; a2_0 = 100*tbar*t*(1-s)
+        G.wgrad(t[0], gebar, dW[0], None, K=sp.K0, accumulate=True)
+        G.gemm_nt(gebar, W[0], vb[0], epi=G.EPI_DBWD, aux1=h[0], aux2=t[0], out2=a2[0], K=sp.K0)
+        cur = vb[0]
+        for l in range(1, 8):
+            nxt = vb[1] if cur is vb[0] else vb[0]
+            if l == 3:
+                G.wgrad(t[3], cur, dW[3], None, N=sp.skip_out, accumulate=True)
+                # output lands in the first 217 columns of the vbar_4 buffer; the skip part is gebar
+                G.gemm_nt(cur, W[3], nxt[:, :sp.skip_out], epi=G.EPI_DBWD, aux1=h[3], aux2=t[3], out2=a2[3],
+                          N=sp.skip_out)
+                K.copy_cols(gebar, nxt[:, sp.skip_out:], sp.E, P)
+            else:
+                G.wgrad(t[l], cur, dW[l], None, accumulate=True)
+                G.gemm_nt(cur, W[l], nxt, epi=G.EPI_DBWD, aux1=h[l], aux2=t[l], out2=a2[l])
+            cur = nxt
+        # cur = ubar_7 -> gradient of the sdf row of W8
+        d_w8sdf = torch.zeros(256, device=dev)
+        K.colsum(cur, 256, P, d_w8sdf)
+        # ---------- first-order backward sweep ----------
+        ob = pool.get("out_bar", P, 260)
+        K.copy_cols(d_rin[:, RIN_FEAT:RIN_FEAT + FEAT], ob, FEAT, P)
+        K.copy_cols(d_sdf.reshape(P, 1), ob[:, 256:257], 1, P)
+        G.wgrad(ob, h[7], dW[8], dWb[8], N=257, accumulate=True)
+        rb_ = [pool.get(f"rb{i}", P, 256) for i in range(2)]
+        G.gemm_nt(ob, WT[8], rb_[0], epi=G.EPI_MUL_DSP, aux1=h[7], aux2=a2[7], K=260)
+        cur = rb_[0]
+        ebar = pool.get("ebar", P, sp.K0)
+        for l in range(7, 0, -1):
+            nxt = rb_[1] if cur is rb_[0] else rb_[0]
+            if l == 4:
+                G.wgrad(cur, h[3], dW[4], dWb[4], accumulate=True)
+                G.gemm_nt(cur, WT[4], nxt[:, :sp.skip_out], epi=G.EPI_MUL_DSP, aux1=h[3], aux2=a2[3], N=256,
+                          n_split=sp.skip_out, out_raw=ebar)
+                # keep K-padding columns of r_3 (217..219) zero for the next GEMM
+                nxt[:, sp.skip_out:sp.skip_pad].zero_()
+            elif l == 3:
+                G.wgrad(cur, h[2], dW[3], dWb[3], N=sp.skip_out, accumulate=True)
+                G.gemm_nt(cur, WT[3], nxt, epi=G.EPI_MUL_DSP, aux1=h[2], aux2=a2[2], K=sp.skip_pad)
+            else:
+                G.wgrad(cur, h[l - 1], dW[l], dWb[l], accumulate=True)
+                G.gemm_nt(cur, WT[l], nxt, epi=G.EPI_MUL_DSP, aux1=h[l - 1], aux2=a2[l - 1])
+            cur = nxt
+        G.wgrad(cur, sv["in0"], dW[0], dWb[0], K=sp.K0, accumulate=True)
+        G.gemm_nt(cur, WT[0], ebar, N=sp.K0, accumulate=True)
+        K.embed_bwd(xc, sp.L, P, ebar, xbar, barf_w=sv["barf_w"], accumulate=True)
+        # ---------- deformation ----------
+        K.invskin_bwd(xc, sv["w_def"], sv["dfm"]["tfs"], sp.n_bones, P, ppf, xbar, dtfs)
+        # ---------- map back to the layouts of the effective nn.Linear weights ----------
+        g_iw = []
+        d0 = dW[0][:, :sp.E]
+        g_iw.append(d0)
+        g_iw += [dW[1], dW[2], dW[3]]
+        g_iw.append(dW[4] / math.sqrt(2))
+        g_iw += [dW[5], dW[6], dW[7]]
+        d8 = torch.cat([dW[8][256:257] + d_w8sdf[None], dW[8][:256]], 0)
+        g_iw.append(d8)
+        g_ib = dWb[:8] + [torch.cat([dWb[8][256:257], dWb[8][:256]])]
+        g_rw = [dR[0][:, :sp.rin_dim], dR[1], dR[2], dR[3], dR[4]]
+        return dict(iw=g_iw, ib=g_ib, rw=g_rw, rb=dRb, tfs=dtfs, pose_embed=d_pose, time_code=d_time)

@@ -1,0 +1,153 @@
+"""Python wrappers (ctypes) for the non-GEMM entry points of libholdhip.so (include/hold_hip.h).
+
+All tensors are fp32 CUDA tensors with unit inner stride; row strides are forwarded as leading
+dimensions so kernels can read/write column slices of wider buffers in place.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import CompositeDesc, call, ptr
+
+
+def _ld(t):
+    if t.dim() == 1:
+        return 1
+    assert t.stride(-1) == 1
+    return t.stride(0)
+
+
+def ray_points(cam_loc, ray_dirs, z, S, out):
+    call("hold_ray_points", ptr(cam_loc), ptr(ray_dirs), ptr(z), _ld(z), S, cam_loc.shape[0], ptr(out), _ld(out))
+
+
+def embed_fwd(x, d_in, L, P, out, out2=None, barf_w=None, cond=None, pts_per_frame=1):
+    call("hold_embed_fwd", ptr(x), _ld(x), d_in, L, ptr(barf_w), P, ptr(out), _ld(out), ptr(out2),
+         _ld(out2) if out2 is not None else 0, ptr(cond), 0 if cond is None else cond.shape[1], pts_per_frame)
+
+
+def embed_bwd(x, L, P, ge, gx, barf_w=None, accumulate=False):
+    call("hold_embed_bwd", ptr(x), _ld(x), L, ptr(barf_w), P, ptr(ge), _ld(ge), ptr(gx), _ld(gx), int(accumulate))
+
+
+def embed_bwd2(x, L, P, ge, gbar, gebar, xbar=None, barf_w=None):
+    call("hold_embed_bwd2", ptr(x), _ld(x), L, ptr(barf_w), P, ptr(ge), _ld(ge), ptr(gbar), _ld(gbar), ptr(gebar),
+         _ld(gebar), ptr(xbar), _ld(xbar) if xbar is not None else 0)
+
+
+def knn_invlbs(x, P, pts_per_frame, verts, skin_w, tfs=None, w_out=None, xc_out=None):
+    """verts [B,V,3] (per frame) or [1,V,3] / [V,3] (shared)."""
+    v = verts if verts.dim() == 3 else verts[None]
+    stride = 0 if v.shape[0] == 1 else v.stride(0)
+    call("hold_knn_invlbs_fwd", ptr(x), _ld(x), P, pts_per_frame, ptr(v), stride, v.shape[1], ptr(skin_w), ptr(tfs),
+         ptr(w_out), ptr(xc_out), _ld(xc_out) if xc_out is not None else 0)
+
+
+def invskin_fwd(x, P, pts_per_frame, w, tfs, n_bones, xc):
+    call("hold_invskin_fwd", ptr(x), _ld(x), P, pts_per_frame, ptr(w), ptr(tfs), n_bones, ptr(xc), _ld(xc))
+
+
+def invskin_bwd(xc, w, tfs, n_bones, P, pts_per_frame, xcbar, dtfs):
+    call("hold_invskin_bwd", ptr(xc), _ld(xc), ptr(w), ptr(tfs), n_bones, P, pts_per_frame, ptr(xcbar), _ld(xcbar),
+         ptr(dtfs))
+
+
+def normal_fwd(g, w, tfs, n_bones, P, pts_per_frame, n_out):
+    call("hold_normal_fwd", ptr(g), _ld(g), ptr(w), ptr(tfs), n_bones, P, pts_per_frame, ptr(n_out), _ld(n_out))
+
+
+def normal_bwd(g, w, tfs, n_bones, P, pts_per_frame, nbar, gbar, dtfs):
+    call("hold_normal_bwd", ptr(g), _ld(g), ptr(w), ptr(tfs), n_bones, P, pts_per_frame, ptr(nbar), _ld(nbar),
+         ptr(gbar), _ld(gbar), ptr(dtfs))
+
+
+def frame_colsum(X, col0, ncols, P, pts_per_frame, out):
+    call("hold_frame_colsum", ptr(X), _ld(X), col0, ncols, P, pts_per_frame, ptr(out))
+
+
+def frame_bcast(src, P, pts_per_frame, out, col0):
+    call("hold_frame_bcast", ptr(src), src.shape[1], P, pts_per_frame, ptr(out), _ld(out), col0)
+
+
+def copy_cols(src, dst, ncols, P, accumulate=False):
+    call("hold_copy_cols", ptr(src), _ld(src), ptr(dst), _ld(dst), ncols, P, int(accumulate))
+
+
+def bg_points(cam_loc, ray_dirs, depth, S, R, out):
+    call("hold_bg_points", ptr(cam_loc), ptr(ray_dirs), ptr(depth), S, cam_loc.shape[0], float(R), ptr(out), _ld(out))
+
+
+def rowdot(A, w, K, b, P, out):
+    call("hold_rowdot", ptr(A), _ld(A), ptr(w), K, float(b), P, ptr(out), _ld(out))
+
+
+def seed_dsp(h, w, N, P, t):
+    call("hold_seed_dsp", ptr(h), _ld(h), ptr(w), N, P, ptr(t), _ld(t))
+
+
+def colsum(X, N, P, out):
+    call("hold_colsum", ptr(X), _ld(X), N, P, ptr(out))
+
+
+# ------------------------------------------------------------------------------------------ sampler
+def sampler_init(cam_loc, ray_dirs, R, near, n0, eps, t_rand, z, beta, far, err_flag):
+    call("hold_sampler_init", ptr(cam_loc), ptr(ray_dirs), cam_loc.shape[0], float(R), float(near), n0, float(eps),
+         ptr(t_rand), ptr(z), _ld(z), ptr(beta), ptr(far), ptr(err_flag))
+
+
+def sampler_beta(z, sdf, S, n_rays, sdf_new, slot, n_new, beta, beta0, eps, beta_iters, maxbeta_bits):
+    call("hold_sampler_beta", ptr(z), ptr(sdf), _ld(z), S, n_rays, ptr(sdf_new), ptr(slot), n_new, ptr(beta),
+         float(beta0), float(eps), beta_iters, ptr(maxbeta_bits))
+
+
+def sampler_sample(z, sdf, S, n_rays, beta, more, add_tiny, u, n_new, samples_out, slot_out):
+    u_stride = 0 if u.dim() == 1 else u.stride(0)
+    call("hold_sampler_sample", ptr(z), ptr(sdf), _ld(z), S, n_rays, ptr(beta), int(more), float(add_tiny), ptr(u),
+         u_stride, n_new, ptr(samples_out), ptr(slot_out))
+
+
+def sampler_final(z_samples, ns, z, idx_extra, nx, far, near, n_rays, out):
+    call("hold_sampler_final", ptr(z_samples), ns, ptr(z), _ld(z), ptr(idx_extra), nx, ptr(far), float(near), n_rays,
+         ptr(out), _ld(out))
+
+
+# ------------------------------------------------------------------------------------------ compositor
+def make_composite_desc(S, n_rays, z, sdf, color, normal, class_ids, betas):
+    d = CompositeDesc()
+    d.n_nodes, d.S, d.n_rays = len(z), S, n_rays
+    for i in range(len(z)):
+        d.z[i], d.sdf[i] = z[i].data_ptr(), sdf[i].data_ptr()
+        d.color[i], d.normal[i] = color[i].data_ptr(), normal[i].data_ptr()
+        d.ldc[i], d.ldn[i] = _ld(color[i]), _ld(normal[i])
+        d.class_id[i] = class_ids[i]
+        d.beta[i] = float(betas[i])
+    return d
+
+
+def composite_fwd(d, out_node, out_comp, out_sem, out_w=None, out_zmerge=None):
+    for i, o in enumerate(out_node):
+        d.out_node[i] = o.data_ptr()
+    d.out_comp, d.out_sem = out_comp.data_ptr(), out_sem.data_ptr()
+    d.out_w = out_w.data_ptr() if out_w is not None else None
+    d.out_zmerge = out_zmerge.data_ptr() if out_zmerge is not None else None
+    call("hold_composite_fwd", C.byref(d))
+
+
+def composite_bwd(d, d_node, d_comp, d_sem, d_sdf, d_color, d_normal, d_beta):
+    for i in range(d.n_nodes):
+        d.d_node[i], d.d_sdf[i] = d_node[i].data_ptr(), d_sdf[i].data_ptr()
+        d.d_color[i], d.d_normal[i] = d_color[i].data_ptr(), d_normal[i].data_ptr()
+    d.d_comp, d.d_sem, d.d_beta = d_comp.data_ptr(), d_sem.data_ptr(), d_beta.data_ptr()
+    call("hold_composite_bwd", C.byref(d))
+
+
+def bg_composite_fwd(z_desc, sdf, rgb, S, n_rays, out_rgb, w_out=None):
+    call("hold_bg_composite_fwd", ptr(z_desc), ptr(sdf), ptr(rgb), _ld(rgb), S, n_rays, ptr(out_rgb), ptr(w_out))
+
+
+def bg_composite_bwd(z_desc, sdf, rgb, S, n_rays, d_out, d_sdf, d_rgb):
+    call("hold_bg_composite_bwd", ptr(z_desc), ptr(sdf), ptr(rgb), _ld(rgb), S, n_rays, ptr(d_out), ptr(d_sdf),
+         ptr(d_rgb))

@@ -1,0 +1,199 @@
+"""Articulation servers: MANO forward LBS and the rigid object transform, per FRAME (not per ray).
+
+Mirrors the call surface of the reference's ``MANOServer`` / ``ObjectServer``
+(code/src/model/mano/server.py:20-133, code/src/model/obj/server.py:19-56,
+code/src/model/obj/object_model.py:12-70, code/src/utils/external/lbs.py:139-251).
+
+These run on B <= ~50 frames of 778 vertices -- about 1e-5 of the path's FLOPs.  The differentiable
+path below is expressed with batched torch ops on the GPU so pose/shape/translation gradients come from
+autograd; the fused HIP kernel ``hold_mano_lbs_fwd`` (csrc/mano.hip) serves the no-grad callers
+(rendering, the sampler's posed vertices, pose refinement evaluation).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+TIP_IDS = (744, 320, 443, 554, 671)
+
+
+class VertexJointSelector(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("extra_joints_idxs", torch.tensor(TIP_IDS, dtype=torch.long))
+
+
+class ManoLayer(nn.Module):
+    """Buffers named as the reference's MANO layer registers them (state_dict compatibility:
+    ``...server.human_layer.{v_template,shapedirs,posedirs,J_regressor,parents,lbs_weights,hand_mean,pose_mean}``)."""
+
+    def __init__(self, model: dict, is_rhand=True, dtype=torch.float32):
+        super().__init__()
+        t = lambda a: torch.as_tensor(np.asarray(a), dtype=dtype)
+        self.is_rhand = is_rhand
+        self.faces = np.asarray(model["f"])
+        self.register_buffer("faces_tensor", torch.as_tensor(self.faces.astype(np.int64)))
+        self.register_buffer("v_template", t(model["v_template"]))
+        self.register_buffer("shapedirs", t(np.asarray(model["shapedirs"])[:, :, :10]))
+        self.register_buffer("J_regressor", t(model["J_regressor"]))
+        pd = np.asarray(model["posedirs"])
+        self.register_buffer("posedirs", t(np.reshape(pd, [-1, pd.shape[-1]]).T))
+        parents = torch.as_tensor(np.asarray(model["kintree_table"])[0].astype(np.int64)).clone()
+        parents[0] = -1
+        self.register_buffer("parents", parents)
+        self.bone_parents = np.asarray(model["kintree_table"])[0]
+        self.register_buffer("lbs_weights", t(model["weights"]))
+        hm = t(model["hands_mean"])
+        self.register_buffer("hand_mean", hm)
+        self.register_buffer("pose_mean", torch.cat([torch.zeros(3, dtype=dtype), hm]))
+        self.vertex_joint_selector = VertexJointSelector()
+        # member parameters the reference layer carries (unused by HOLD's forward, kept for checkpoints)
+        for name, dim in [("betas", 10), ("global_orient", 3), ("body_pose", 3), ("transl", 3), ("hand_pose", 45)]:
+            self.register_parameter(name, nn.Parameter(torch.zeros(1, dim, dtype=dtype), requires_grad=False))
+        self._parent_list = [int(p) for p in parents.tolist()]
+
+
+def rodrigues(rot_vecs):
+    angle = torch.norm(rot_vecs + 1e-8, dim=1, keepdim=True)  # lbs.py:313 quirk kept
+    d = rot_vecs / angle
+    c, s = torch.cos(angle)[:, None], torch.sin(angle)[:, None]
+    rx, ry, rz = d[:, 0:1], d[:, 1:2], d[:, 2:3]
+    z = torch.zeros_like(rx)
+    Km = torch.cat([z, -rz, ry, rz, z, -rx, -ry, rx, z], 1).view(-1, 3, 3)
+    return torch.eye(3, dtype=rot_vecs.dtype, device=rot_vecs.device)[None] + s * Km + (1 - c) * torch.bmm(Km, Km)
+
+
+def mano_lbs(layer: ManoLayer, betas, full_pose):
+    """-> verts [B,778,3], joints [B,16,3], A [B,16,4,4] (relative bone transforms), v_posed [B,778,3]."""
+    B = full_pose.shape[0]
+    dt, dev = full_pose.dtype, full_pose.device
+    pose = full_pose + layer.pose_mean
+    v_shaped = layer.v_template + torch.einsum("bl,mkl->bmk", betas, layer.shapedirs)
+    J = torch.einsum("bik,ji->bjk", v_shaped, layer.J_regressor)
+    rot = rodrigues(pose.reshape(-1, 3)).view(B, 16, 3, 3)
+    pf = (rot[:, 1:] - torch.eye(3, dtype=dt, device=dev)).reshape(B, -1)
+    v_posed = v_shaped + torch.matmul(pf, layer.posedirs).view(B, -1, 3)
+    par = layer._parent_list
+    rel = torch.cat([J[:, :1], J[:, 1:] - J[:, par[1:]]], 1)
+    tm = torch.cat([F.pad(rot.reshape(-1, 3, 3), [0, 0, 0, 1]),
+                    F.pad(rel.reshape(-1, 3, 1), [0, 0, 0, 1], value=1.0)], 2).reshape(B, 16, 4, 4)
+    chain = [tm[:, 0]]
+    for i in range(1, 16):
+        chain.append(torch.matmul(chain[par[i]], tm[:, i]))
+    T = torch.stack(chain, 1)
+    Jh = F.pad(J.unsqueeze(-1), [0, 0, 0, 1])
+    A = T - F.pad(torch.matmul(T, Jh), [3, 0, 0, 0, 0, 0, 0, 0])
+    Tv = torch.matmul(layer.lbs_weights[None].expand(B, -1, -1), A.view(B, 16, 16)).view(B, -1, 4, 4)
+    verts = (Tv[:, :, :3, :3] @ v_posed.unsqueeze(-1)).squeeze(-1) + Tv[:, :, :3, 3]
+    return verts, T[:, :, :3, 3], A, v_posed
+
+
+class MANOServer(nn.Module):
+    """GenericServer/MANOServer of code/src/model/mano/server.py."""
+
+    def __init__(self, betas, is_rhand, model: dict):
+        super().__init__()
+        self.human_layer = ManoLayer(model, is_rhand)
+        self.faces = self.human_layer.faces
+        self.bone_parents = self.human_layer.bone_parents.astype(int)
+        self.bone_parents[0] = -1
+        self.betas = None if betas is None else torch.as_tensor(np.asarray(betas), dtype=torch.float32)
+        pc = torch.zeros(1, 62)
+        pc[0, 0] = 1
+        pc[0, 7:52] = -self.human_layer.hand_mean
+        if self.betas is not None:
+            pc[0, -10:] = self.betas
+        self.param_canonical = pc
+        self.cano_params = torch.split(pc, [1, 3, 48, 10], dim=1)
+        with torch.no_grad():
+            out = self.forward(*self.cano_params, absolute=True)
+        self.register_buffer("verts_c", out["verts"], persistent=False)
+        self.register_buffer("joints_c", out["jnts"], persistent=False)
+        self.register_buffer("tfs_c_inv", out["tfs"].squeeze(0).inverse(), persistent=False)
+
+    def forward(self, scene_scale, transl, thetas, betas, absolute=False):
+        hl = self.human_layer
+        dev = hl.v_template.device
+        scene_scale, transl, thetas, betas = (a.to(dev) for a in (scene_scale, transl, thetas, betas))
+        verts, joints, A, v_posed = mano_lbs(hl, betas, thetas)
+        joints = torch.cat([joints, verts[:, list(TIP_IDS)]], 1)
+        s = scene_scale.view(-1, 1, 1)
+        t = transl.view(-1, 1, 3)
+        out = {"verts": verts * s + t * s, "jnts": joints * s + t * s}
+        top = A[:, :, :3, :] * s.view(-1, 1, 1, 1)
+        top = torch.cat([top[..., :3], top[..., 3:] + (t * s).view(-1, 1, 3, 1)], -1)
+        tf = torch.cat([top, A[:, :, 3:, :]], 2)
+        if not absolute:
+            tf = torch.einsum("bnij,njk->bnik", tf, self.tfs_c_inv)
+        out["tfs"] = tf
+        out["skin_weights"] = hl.lbs_weights[None].expand(verts.shape[0], -1, -1)
+        out["v_posed"] = v_posed
+        return out
+
+    def forward_param(self, param_dict):
+        get = lambda k: next(v for kk, v in param_dict.items() if k in kk)
+        full_pose = torch.cat((get("global_orient"), get("pose")), dim=1)
+        B = full_pose.shape[0]
+        return self.forward(get("scene_scale").view(-1).repeat(B), get("transl"), full_pose, get("betas").repeat(B, 1))
+
+
+def axis_angle_to_matrix(aa):
+    """common/rot.py:105-138,777-805."""
+    angles = torch.norm(aa, p=2, dim=-1, keepdim=True)
+    half = angles * 0.5
+    small = angles.abs() < 1e-6
+    soa = torch.where(small, 0.5 - (angles * angles) / 48,
+                      torch.sin(half) / torch.where(small, torch.ones_like(angles), angles))
+    q = torch.cat([torch.cos(half), aa * soa], -1)
+    r, i, j, k = torch.unbind(q, -1)
+    two_s = 2.0 / (q * q).sum(-1)
+    o = torch.stack((1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
+                     two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
+                     two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
+    return o.reshape(q.shape[:-1] + (3, 3))
+
+
+class ObjectModel(nn.Module):
+    def __init__(self, entity: dict):
+        super().__init__()
+        self.register_buffer("obj_scale", torch.tensor(np.array([entity["obj_scale"]]), dtype=torch.float32))
+        self.register_buffer("v3d_cano", torch.as_tensor(entity["pts.cano"], dtype=torch.float32))
+        nm = torch.as_tensor(entity["norm_mat"], dtype=torch.float32)
+        self.register_buffer("norm_mat", nm)
+        self.register_buffer("denorm_mat", torch.inverse(nm))
+
+    def forward(self, rot, trans, scene_scale=None, want_verts=True):
+        dev, dt = self.v3d_cano.device, self.v3d_cano.dtype
+        B = rot.shape[0]
+        scene_scale = torch.ones(B, device=dev) if scene_scale is None else scene_scale.view(B).to(dev)
+        R = axis_angle_to_matrix(rot.to(dev)).view(B, 3, 3)
+        top = torch.cat([R, trans.to(dev).view(B, 3, 1)], 2)
+        bottom = torch.tensor([0.0, 0.0, 0.0, 1.0], device=dev, dtype=dt).view(1, 1, 4).expand(B, 1, 4)
+        tf = torch.cat([top, bottom], 1)
+        sm = torch.diag_embed(torch.cat([scene_scale[:, None].expand(B, 3), torch.ones(B, 1, device=dev)], 1))
+        om = torch.diag(torch.cat([self.obj_scale.expand(3), torch.ones(1, device=dev)]))[None]
+        tf = sm @ tf @ om @ self.denorm_mat[None]
+        out = {"T": tf}
+        if want_verts:
+            vp = torch.cat([self.v3d_cano, torch.ones(self.v3d_cano.shape[0], 1, device=dev)], 1)
+            v = torch.einsum("bij,nj->bni", tf, vp)
+            out["vertices"] = v[:, :, :3] / v[:, :, 3:4]
+        return out
+
+
+class ObjectServer(nn.Module):
+    def __init__(self, entity: dict):
+        super().__init__()
+        self.object_model = ObjectModel(entity)
+        self.verts_c = self.object_model.v3d_cano[None]
+
+    def forward(self, scene_scale, transl, thetas, absolute=False):
+        o = self.object_model(rot=thetas, trans=transl, scene_scale=scene_scale)
+        return {"verts": o["vertices"], "obj_tfs": o["T"][:, None, :, :]}
+
+    def forward_param(self, param_dict):
+        get = lambda k: next(v for kk, v in param_dict.items() if k in kk)
+        go = get("global_orient")
+        return self.forward(get("scene_scale").view(-1).repeat(go.shape[0]), get("transl"), go)

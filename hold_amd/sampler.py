@@ -1,0 +1,137 @@
+"""ErrorBoundSampler on the HIP kernels -- same constructor arguments and ``get_z_vals`` contract as
+code/src/engine/ray_sampler.py:88-352 (VolSDF Algorithm 1), with the SDF query injected as a callable.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import kernels as K
+from .field import Pool
+
+
+class UniformSampler:
+    """code/src/engine/ray_sampler.py:38-85 (only what HOLDNet needs: the inverse-sphere z values)."""
+
+    def __init__(self, scene_bounding_sphere, near, N_samples, take_sphere_intersection=False, far=-1):
+        self.near = near
+        self.far = 2.0 * scene_bounding_sphere if far == -1 else far
+        self.N_samples = N_samples
+        self.scene_bounding_sphere = scene_bounding_sphere
+        self.take_sphere_intersection = take_sphere_intersection
+
+    def get_z_vals(self, ray_dirs, cam_loc, training, t_rand=None):
+        assert not self.take_sphere_intersection
+        n = ray_dirs.shape[0]
+        dev = ray_dirs.device
+        t = torch.linspace(0.0, 1.0, steps=self.N_samples, device=dev)
+        z = (self.near * (1.0 - t) + self.far * t).unsqueeze(0).repeat(n, 1)
+        if training:
+            mids = 0.5 * (z[..., 1:] + z[..., :-1])
+            upper = torch.cat([mids, z[..., -1:]], -1)
+            lower = torch.cat([z[..., :1], mids], -1)
+            if t_rand is None:
+                t_rand = torch.rand(z.shape).to(dev)  # CPU generator, as the reference (:76)
+            z = lower + (upper - lower) * t_rand
+        return z
+
+    def inverse_sample(self, ray_dirs, cam_loc, is_training, sdf_bounding_sphere, t_rand=None):
+        return self.get_z_vals(ray_dirs, cam_loc, is_training, t_rand) * (1.0 / sdf_bounding_sphere)
+
+
+class ErrorBoundSampler:
+    def __init__(self, scene_bounding_sphere, near=0.0, N_samples=64, N_samples_eval=128, N_samples_extra=32,
+                 eps=0.1, beta_iters=10, max_total_iters=5, inverse_sphere_bg=True, N_samples_inverse_sphere=32,
+                 add_tiny=1e-6, rng_device="cpu"):
+        self.R = float(scene_bounding_sphere)
+        self.near = float(near)
+        self.N_samples = N_samples
+        self.N_samples_eval = N_samples_eval
+        self.N_samples_extra = N_samples_extra
+        self.eps = eps
+        self.beta_iters = beta_iters
+        self.max_total_iters = max_total_iters
+        self.add_tiny = add_tiny
+        self.inverse_sphere_bg = inverse_sphere_bg
+        assert inverse_sphere_bg, "HOLD always samples up to the bounding-sphere exit (node.py:33-35)"
+        self.inverse_sphere_sampler = UniformSampler(1.0, 0.0, 32, False, far=1.0)
+        self.rng_device = rng_device  # "cpu" reproduces the reference's generator stream; "cuda" avoids the H2D copy
+        self.pool = None
+        self.last_iters = 0
+
+    def _rand(self, shape, dev):
+        if self.rng_device == "cpu":
+            return torch.rand(shape).to(dev)
+        return torch.rand(shape, device=dev)
+
+    def get_z_vals(self, sdf_query, ray_dirs, cam_loc, beta0, is_training, rng=None):
+        """sdf_query(x [P,4], P, out [P,1]) evaluates the node's SDF at deformed-space points.
+        Returns z_vals [N, N_samples + 2 + N_samples_extra], sorted, no grad."""
+        dev = ray_dirs.device
+        N = ray_dirs.shape[0]
+        if self.pool is None:
+            self.pool = Pool(dev)
+        pool = self.pool
+        n0 = self.N_samples_eval
+        ld = n0 * self.max_total_iters
+        z = pool.get("z", N, ld)
+        sdf = pool.get("sdf", N, ld)
+        beta = pool.get("beta", N, 1)
+        far = pool.get("far", N, 1)
+        flags = pool.get("flags", 1, 4, torch.int32)
+        flags.zero_()
+        t_rand = None
+        if is_training:
+            t_rand = (rng["t_uniform"] if rng is not None else self._rand((N, n0), dev)).contiguous()
+        K.sampler_init(cam_loc, ray_dirs, self.R, self.near, n0, self.eps, t_rand, z, beta, far, flags[:, 0:1])
+        pts = pool.get("pts", N * n0, 4)
+        sdf_new = pool.get("sdf_new", N * n0, 1)
+        samples = z  # first round: the first n0 columns of the window
+        slot = pool.get("slot", N, n0, torch.int32)
+        samp = pool.get("samples", N, n0)
+        S, iters = n0, 0
+        beta0 = float(beta0)
+        u_more = torch.linspace(0.0, 1.0, steps=n0, device=dev)
+        while True:
+            K.ray_points(cam_loc, ray_dirs, samples, n0, pts)
+            sdf_query(pts, N * n0, sdf_new)
+            flags[:, 1:2].zero_()
+            if iters == 0:
+                K.copy_cols(sdf_new.view(N, n0), sdf, n0, N)
+                K.sampler_beta(z, sdf, S, N, None, None, 0, beta, beta0, self.eps, self.beta_iters, flags[:, 1:2])
+            else:
+                K.sampler_beta(z, sdf, S, N, sdf_new, slot, n0, beta, beta0, self.eps, self.beta_iters,
+                               flags[:, 1:2])
+            iters += 1
+            fl = flags.cpu()
+            if int(fl[0, 0]) != 0:
+                raise RuntimeError("BOUNDING SPHERE PROBLEM!")  # ray_sampler.py:16-18
+            max_beta = float(fl[0, 1:2].view(torch.float32))
+            not_converge = max_beta > beta0
+            if not_converge and iters < self.max_total_iters:
+                K.sampler_sample(z, sdf, S, N, beta, True, self.add_tiny, u_more, n0, samp, slot)
+                S += n0
+                samples = samp
+                continue
+            ns = self.N_samples
+            zs = pool.get("z_samples", N, ns)
+            if is_training:
+                u = (rng["u_final"] if rng is not None else self._rand((N, ns), dev)).contiguous()
+            else:
+                u = torch.linspace(0.0, 1.0, steps=ns, device=dev)
+            K.sampler_sample(z, sdf, S, N, beta, False, self.add_tiny, u, ns, zs, None)
+            break
+        self.last_iters = iters
+        nx = self.N_samples_extra
+        if nx > 0:
+            if is_training:
+                perm = rng["perm"] if rng is not None else torch.randperm(S)
+                idx = perm[:nx]
+            else:
+                idx = torch.linspace(0, S - 1, nx).long()
+            idx = idx.to(device=dev, dtype=torch.int32)
+        else:
+            idx = None
+        out = torch.empty(N, ns + 2 + nx, device=dev)
+        K.sampler_final(zs, ns, z, idx, nx, far, self.near, N, out)
+        self.last_S = S
+        return out

@@ -80,6 +80,139 @@ int hold_wgrad(const float* R, int32_t ldr, const float* X, int32_t ldx, int32_t
                float* dW, int32_t lddw, float* db, int32_t accumulate, int32_t splits, float* workspace,
                hold_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Per-point kernels (hold_amd/csrc/points.hip)
+ * ---------------------------------------------------------------------------------------- */
+
+/* out[(r*S+s)][0..2] = cam_loc[r] + z[r][s] * ray_dirs[r]
+ * (code/src/model/renderables/mano_node.py:111, code/src/engine/ray_sampler.py:162) */
+int hold_ray_points(const float* cam_loc, const float* ray_dirs, const float* z, int32_t ldz, int32_t S,
+                    int64_t n_rays, float* out, int32_t ldo, hold_stream_t stream);
+
+/* Fourier positional encoding [x, sin(2^k x), cos(2^k x)]_{k<L} (+ optional BARF per-column weights,
+ * + optional per-frame condition vector appended), written to out (and a second copy to out2 for the
+ * skip connection).  code/src/engine/embedders.py:18-50, :92-122; shape_net.py:98-116. */
+int hold_embed_fwd(const float* x, int32_t ldx, int32_t d_in, int32_t L, const float* barf_w, int64_t P, float* out,
+                   int32_t ldo, float* out2, int32_t ldo2, const float* cond, int32_t cond_dim,
+                   int64_t pts_per_frame, hold_stream_t stream);
+/* gx[p][:] (+)= (d embed / d x)^T ge[p][:]   (d_in = 3).  Chain rule torch autograd applies for
+ * code/src/engine/volsdf_utils.py:89-96 (gradient of sdf w.r.t. canonical points). */
+int hold_embed_bwd(const float* x, int32_t ldx, int32_t L, const float* barf_w, int64_t P, const float* ge,
+                   int32_t ldge, float* gx, int32_t ldgx, int32_t accumulate, hold_stream_t stream);
+/* double backward of the line above: gebar = (d embed/dx) gbar ; xbar += gbar * (d2 embed/dx2 . ge) */
+int hold_embed_bwd2(const float* x, int32_t ldx, int32_t L, const float* barf_w, int64_t P, const float* ge,
+                    int32_t ldge, const float* gbar, int32_t ldgb, float* gebar, int32_t ldgeb, float* xbar,
+                    int32_t ldxb, hold_stream_t stream);
+
+/* KNN(K=15) skinning-weight lookup against the frame's posed (or the canonical) MANO vertices, fused
+ * with inverse LBS when xc_out != NULL:  w = sum_k softmax-like conf_k * W[idx_k]  (detached),
+ * x_c = (sum_j w_j T_j)^-1 [x;1].   Replaces pytorch3d.ops.knn_points + KNNDeformer.forward /
+ * query_skinning_weights_multi / skinning (code/src/model/mano/deformer.py:34-68, :84-105, :145-170).
+ * verts: [B][n_verts][3] with frame stride verts_frame_stride floats (0 = shared canonical verts);
+ * skin_w [n_verts][16]; tfs [B][16][4][4]; w_out [P][16] (nullable); xc_out [P][ldxc] (nullable). */
+int hold_knn_invlbs_fwd(const float* x, int32_t ldx, int64_t P, int64_t pts_per_frame, const float* verts,
+                        int64_t verts_frame_stride, int32_t n_verts, const float* skin_w, const float* tfs,
+                        float* w_out, float* xc_out, int32_t ldxc, hold_stream_t stream);
+/* x_c = (sum_j w_j T_j)^-1 [x;1] with given weights (n_bones = 16) or a single rigid transform per
+ * frame (n_bones = 1: ObjectDeformer.forward inverse, code/src/model/obj/deformer.py:10-41). */
+int hold_invskin_fwd(const float* x, int32_t ldx, int64_t P, int64_t pts_per_frame, const float* w, const float* tfs,
+                     int32_t n_bones, float* xc, int32_t ldxc, hold_stream_t stream);
+int hold_invskin_bwd(const float* xc, int32_t ldxc, const float* w, const float* tfs, int32_t n_bones, int64_t P,
+                     int64_t pts_per_frame, const float* xcbar, int32_t ldxb, float* dtfs /* [B][n_bones][16], += */,
+                     hold_stream_t stream);
+/* canonical normal n = normalize(g . J^-1, eps 1e-6), J = sum_j w_j T_j[:3,:3]
+ * (extract_features, code/src/engine/volsdf_utils.py:68-81, :100-102) and its backward. */
+int hold_normal_fwd(const float* g, int32_t ldg, const float* w, const float* tfs, int32_t n_bones, int64_t P,
+                    int64_t pts_per_frame, float* n_out, int32_t ldn, hold_stream_t stream);
+int hold_normal_bwd(const float* g, int32_t ldg, const float* w, const float* tfs, int32_t n_bones, int64_t P,
+                    int64_t pts_per_frame, const float* nbar, int32_t ldnb, float* gbar, int32_t ldgb,
+                    float* dtfs /* += */, hold_stream_t stream);
+/* helpers: per-frame column sums (+=), per-frame broadcast into columns, strided column copy */
+int hold_frame_colsum(const float* X, int32_t ldx, int32_t col0, int32_t ncols, int64_t P, int64_t pts_per_frame,
+                      float* out /* [B][ncols], += */, hold_stream_t stream);
+int hold_frame_bcast(const float* src, int32_t ncols, int64_t P, int64_t pts_per_frame, float* out, int32_t ldo,
+                     int32_t col0, hold_stream_t stream);
+int hold_copy_cols(const float* src, int32_t lds, float* dst, int32_t ldd, int32_t ncols, int64_t P,
+                   int32_t accumulate, hold_stream_t stream);
+
+/* NeRF++ inverted-sphere re-parameterisation (background.py:102-135): out[p] = (unit xyz, 1/r) */
+int hold_bg_points(const float* cam_loc, const float* ray_dirs, const float* depth, int32_t S, int64_t n_rays, float R,
+                   float* out, int32_t ldo, hold_stream_t stream);
+/* out[p] = A[p][:K] . w + b  (sdf-only last layer of ImplicitNet for the no-grad sampler queries) */
+int hold_rowdot(const float* A, int32_t lda, const float* w, int32_t K, float b, int64_t P, float* out, int32_t ldo,
+                hold_stream_t stream);
+/* t[p][n] = w[n] * softplus'(h[p][n]): seed of the d sdf/d x reverse sweep (volsdf_utils.py:89-96) */
+int hold_seed_dsp(const float* h, int32_t ldh, const float* w, int32_t N, int64_t P, float* t, int32_t ldt,
+                  hold_stream_t stream);
+/* out[n] += sum_p X[p][n] */
+int hold_colsum(const float* X, int32_t ldx, int32_t N, int64_t P, float* out, hold_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * VolSDF error-bound sampler (hold_amd/csrc/sampler.hip) -- ErrorBoundSampler.get_z_vals,
+ * code/src/engine/ray_sampler.py:128-352; one call per numbered step of the reference loop.
+ * Windows z/sdf are [n_rays][ld] with the first S entries valid and sorted.
+ * ---------------------------------------------------------------------------------------- */
+/* :54-80 + :152-156 : far = sphere exit, z = 128 uniform (stratified with t_rand in training),
+ * beta = sqrt(sum dists^2 / (4 log(1+eps))).  *err_flag = 1 if a ray misses the sphere (:16-18). */
+int hold_sampler_init(const float* cam_loc, const float* ray_dirs, int64_t n_rays, float R, float near, int32_t n0,
+                      float eps, const float* t_rand, float* z, int32_t ldz, float* beta, float* far_out,
+                      int32_t* err_flag, hold_stream_t stream);
+/* :179-220 : (scatter sdf of the previous round's new samples), d* bound, beta bisection;
+ * atomically maxes beta into *maxbeta_bits (float bits; caller zeroes it) for the global test at :244 */
+int hold_sampler_beta(const float* z, float* sdf, int32_t ld, int32_t S, int64_t n_rays, const float* sdf_new,
+                      const int32_t* slot, int32_t n_new, float* beta, float beta0, float eps, int32_t beta_iters,
+                      uint32_t* maxbeta_bits, hold_stream_t stream);
+/* :223-311 : pdf (error bound if more, opacity weights otherwise) -> CDF -> inverse CDF at u
+ * ([n_new] shared when u_stride = 0, else [n_rays][n_new]); if more, stable-merges the samples into
+ * the window (slot_out[j] = merged index of sample j; sdf at those slots is filled next round). */
+int hold_sampler_sample(float* z, float* sdf, int32_t ld, int32_t S, int64_t n_rays, const float* beta, int32_t more,
+                        float add_tiny, const float* u, int64_t u_stride, int32_t n_new, float* samples_out,
+                        int32_t* slot_out, hold_stream_t stream);
+/* :313-336 : sort([z_samples, near, far, z[:, idx_extra]]) */
+int hold_sampler_final(const float* z_samples, int32_t ns, const float* z, int32_t ld, const int32_t* idx_extra,
+                       int32_t nx, const float* far, float near, int64_t n_rays, float* out, int32_t ldo,
+                       hold_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Compositor (hold_amd/csrc/composite.hip): LaplaceDensity (code/src/engine/density.py:21-30),
+ * density2weight (code/src/engine/volsdf_utils.py:220-251), integrate (rendering.py:18-22),
+ * merge_factors with the off-by-one trim (code/src/hold/hold_utils.py:76-121) and
+ * volumetric_render (:243-271) for every node and for the merged composite.
+ * Packed per-ray outputs: [rgb3, sum_w, normal3, depth, bg_weight, 0,0,0].
+ * ---------------------------------------------------------------------------------------- */
+#define HOLD_MAX_NODES 3
+#define HOLD_RENDER_W 12
+typedef struct hold_composite_desc {
+  int32_t n_nodes, S;
+  int64_t n_rays;
+  const float* z[HOLD_MAX_NODES];      /* [n_rays][S] sorted                      */
+  const float* sdf[HOLD_MAX_NODES];    /* [n_rays][S]                             */
+  const float* color[HOLD_MAX_NODES];  /* [n_rays*S][ldc]                         */
+  const float* normal[HOLD_MAX_NODES]; /* [n_rays*S][ldn]                         */
+  int32_t ldc[HOLD_MAX_NODES], ldn[HOLD_MAX_NODES], class_id[HOLD_MAX_NODES];
+  float beta[HOLD_MAX_NODES];          /* |beta_param| + beta_min                 */
+  float* out_node[HOLD_MAX_NODES];     /* [n_rays][HOLD_RENDER_W]                 */
+  float* out_comp;                     /* [n_rays][HOLD_RENDER_W]                 */
+  float* out_sem;                      /* [n_rays][4] composite fg semantics      */
+  float* out_w;                        /* [n_rays][n_nodes*S-2*n_nodes+1] or NULL */
+  float* out_zmerge;                   /* same shape or NULL                      */
+  /* backward only */
+  const float* d_node[HOLD_MAX_NODES]; /* [n_rays][HOLD_RENDER_W]                 */
+  const float* d_comp;
+  const float* d_sem;
+  float* d_sdf[HOLD_MAX_NODES];        /* [n_rays][S]                             */
+  float* d_color[HOLD_MAX_NODES];      /* [n_rays*S][3]                           */
+  float* d_normal[HOLD_MAX_NODES];     /* [n_rays*S][3]                           */
+  float* d_beta;                       /* [HOLD_MAX_NODES], +=                    */
+} hold_composite_desc;
+int hold_composite_fwd(const hold_composite_desc* d, hold_stream_t stream);
+int hold_composite_bwd(const hold_composite_desc* d, hold_stream_t stream);
+/* Background.bg_volume_rendering + integrate (code/src/model/renderables/background.py:95-100,137-165) */
+int hold_bg_composite_fwd(const float* z_desc, const float* sdf, const float* rgb, int32_t ld_rgb, int32_t S,
+                          int64_t n_rays, float* out_rgb, float* w_out, hold_stream_t stream);
+int hold_bg_composite_bwd(const float* z_desc, const float* sdf, const float* rgb, int32_t ld_rgb, int32_t S,
+                          int64_t n_rays, const float* d_out, float* d_sdf, float* d_rgb, hold_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -478,10 +478,13 @@ def volumetric_render(f, is_training=False):
     return out
 
 
-def merge_factors(flist):
-    """code/src/hold/hold_utils.py:76-121 (incl. the CVPR off-by-one trim at :112-118)."""
+def merge_factors(flist, stable=False):
+    """code/src/hold/hold_utils.py:76-121 (incl. the CVPR off-by-one trim at :112-118).
+    The reference calls torch.sort without ``stable``: the order of EQUAL z values (both nodes always
+    contain near=0 and the sphere exit, and in eval mode share the uniform 'extra' samples) is
+    backend-defined.  ``stable=True`` pins it to "earlier node first", the order the HIP merge uses."""
     comp = {k: torch.cat([f[k] for f in flist], 1) for k in flist[0]}
-    z, idx = torch.sort(comp["z_vals"], dim=1)
+    z, idx = torch.sort(comp["z_vals"], dim=1, stable=stable)
     out = {"z_vals": z}
     for k, v in comp.items():
         if k != "z_vals":
@@ -668,7 +671,7 @@ def node_forward(osc: OracleScene, sd, node, inp, ray_dirs, cam_loc, is_training
 
 
 def holdnet_forward(osc: OracleScene, sd, inp, is_training=False, rng=None, z_override=None,
-                    current_epoch=0, barf_alpha_iter=None, extras=None):
+                    current_epoch=0, barf_alpha_iter=None, extras=None, stable_merge=False):
     """HOLDNet.forward (code/src/hold/hold_net.py:53-134) without the kaolin loss targets."""
     dt = osc.dtype
     ray_dirs, cam = get_camera_params(inp["uv"], inp["extrinsics"], inp["intrinsics"])
@@ -686,7 +689,7 @@ def holdnet_forward(osc: OracleScene, sd, inp, is_training=False, rng=None, z_ov
                                    None if z_override is None else z_override[node],
                                    current_epoch, barf_alpha_iter, ex)
     out = {}
-    comp = merge_factors(list(fdict.values()))
+    comp = merge_factors(list(fdict.values()), stable=stable_merge)
     for f in fdict.values():
         f["z_max"] = f["z_vals"][:, -1]
     out.update(volumetric_render(comp, is_training))
