@@ -355,18 +355,19 @@ __global__ void bg_composite_bwd_kernel(const float* __restrict__ zflip, const f
   const long ray = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (ray >= N) return;
   const float g0 = dout[ray * 3], g1 = dout[ray * 3 + 1], g2 = dout[ray * 3 + 2];
-  // forward pass for T, then reverse for suffix sums
+  // exclusive prefix of the free energy at the LAST sample first (the 1e10 closing interval is kept out of
+  // the running sum: adding and re-subtracting ~1e9 would wipe the small terms), then walk backwards
   float run = 0.f;
   float suffix = 0.f;
-  for (int s = 0; s < S; ++s) {
-    const float d = (s == S - 1) ? 1e10f : (zflip[ray * S + s] - zflip[ray * S + s + 1]);
+  for (int s = 0; s < S - 1; ++s) {
+    const float d = zflip[ray * S + s] - zflip[ray * S + s + 1];
     run += d * fabsf(sdf[ray * S + s]);
   }
   for (int s = S - 1; s >= 0; --s) {
     const float d = (s == S - 1) ? 1e10f : (zflip[ray * S + s] - zflip[ray * S + s + 1]);
     const float sd = sdf[ray * S + s];
     const float fe = d * fabsf(sd);
-    run -= fe;  // exclusive sum
+    if (s < S - 1) run -= fe;  // exclusive sum for sample s
     const float T = expf(-run), ef = expf(-fe);
     const float w = (1.0f - ef) * T;
     const float* c = rgb + (ray * S + s) * ldr;

@@ -81,6 +81,7 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
     W.append(w8)
     pk["W"] = W
     pk["b"] = [b.contiguous() for b in ib[:8]] + [torch.cat([ib[8][1:], ib[8][:1]]).contiguous()]
+    pk["iw0_cols"] = iw[0].shape[1]
     pk["w8_sdf"] = iw[8][0].contiguous()
     pk["b8_sdf"] = ib[8][0]
     # transposes [K_l][pad4(N_l)] for the sweeps that contract over the output index
@@ -306,7 +307,8 @@ class NodeField:
         K.invskin_bwd(xc, sv["w_def"], sv["dfm"]["tfs"], sp.n_bones, P, ppf, xbar, dtfs)
         # ---------- map back to the layouts of the effective nn.Linear weights ----------
         g_iw = []
-        d0 = dW[0][:, :sp.E]
+        d0 = torch.zeros(256, pk["iw0_cols"], device=dev)  # zeroed MANO cond columns get zero gradient
+        d0[:, :sp.E] = dW[0][:, :sp.E]
         g_iw.append(d0)
         g_iw += [dW[1], dW[2], dW[3]]
         g_iw.append(dW[4] / math.sqrt(2))

@@ -10,6 +10,27 @@ from ._lib import (EPI_DBWD, EPI_MUL_DRELU, EPI_MUL_DSIG, EPI_MUL_DSP, EPI_NONE,
                    EPI_SOFTPLUS, GemmDesc, check, ptr, stream_ptr)
 
 
+# when set to a list, every launch appends (start_event, end_event, algorithmic_flops, kernel_name); the events
+# are recorded on torch's current stream, which is the stream the kernel is launched on.
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(e0, flops, name):
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    PROFILE.append((e0, e1, flops, name))
+
+
 def _ld(t):
     assert t.stride(-1) == 1, "innermost dim must be contiguous"
     return t.stride(0)
@@ -42,7 +63,9 @@ def gemm_nt(A, W, out, *, bias=None, epi=EPI_NONE, alpha=1.0, N=None, K=None, n_
     if out2 is not None:
         d.out2, d.ldout2 = ptr(out2), _ld(out2)
     d.accumulate = 1 if accumulate else 0
+    e0 = _prof_begin()
     check(_lib.lib().hold_gemm_nt(C.byref(d), stream_ptr()), "hold_gemm_nt")
+    _prof_end(e0, 2.0 * P * N * K, "gemm_nt_kernel")
     return out
 
 
@@ -68,6 +91,8 @@ def wgrad(R, X, dW, db=None, *, N=None, K=None, accumulate=False, splits=None):
         splits = max(1, min(1024 // tiles, (P + 255) // 256))
     L = _lib.lib()
     ws = _workspace(L.hold_wgrad_workspace_floats(N, K, splits), R.device)
+    e0 = _prof_begin()
     check(L.hold_wgrad(ptr(R), _ld(R), ptr(X), _ld(X), P, N, K, ptr(dW), _ld(dW), ptr(db), 1 if accumulate else 0,
                        splits, ptr(ws), stream_ptr()), "hold_wgrad")
+    _prof_end(e0, 2.0 * P * N * K, "wgrad_kernel")
     return dW

@@ -1,0 +1,48 @@
+"""Data parallelism for the hot path: one process per GPU, rays/frames sharded across ranks, weights
+replicated, ONE flat-bucket all-reduce of all gradients per optimiser step (RCCL over xGMI when the
+backend is "nccl"; gloo on CPU for the tests).  The reference has no distributed code;
+2.19 M fp32 gradients = 8.8 MB, ring all-reduce ~0.1 ms on 8 GPUs -- no overlap machinery needed."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def grad_params(module):
+    return [p for p in module.parameters() if p.requires_grad]
+
+
+def allreduce_grads(params, group=None, average=True):
+    """sum (or mean) every parameter's .grad across ranks through one contiguous buffer.  Parameters whose
+    grad is None on this rank (e.g. pose rows of frames owned by other ranks) contribute zeros."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0
+    if not params:
+        return 0
+    dev = params[0].device
+    sizes = [p.numel() for p in params]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    off = 0
+    for p, n in zip(params, sizes):
+        if p.grad is not None:
+            flat[off:off + n].copy_(p.grad.reshape(-1))
+        off += n
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat /= dist.get_world_size(group)
+    off = 0
+    for p, n in zip(params, sizes):
+        g = flat[off:off + n].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += n
+    return flat.numel() * 4
+
+
+def shard_frames(frame_ids, rank, world):
+    """contiguous frame ranges per rank (mirrors the reference's --agent_id sharding, eval_datasets.py:43-50)."""
+    n = len(frame_ids)
+    per = (n + world - 1) // world
+    return frame_ids[rank * per:(rank + 1) * per]

@@ -125,7 +125,7 @@ class ErrorBoundSampler:
         if nx > 0:
             if is_training:
                 perm = rng["perm"] if rng is not None else torch.randperm(S)
-                idx = perm[:nx]
+                idx = (perm(S) if callable(perm) else perm)[:nx]
             else:
                 idx = torch.linspace(0, S - 1, nx).long()
             idx = idx.to(device=dev, dtype=torch.int32)

@@ -262,7 +262,8 @@ def error_bound_sample(z_vals, sdf_fn, cam_loc, ray_dirs, beta0, R, is_training=
     near_t = near * torch.ones(N, 1, dtype=dt)
     far = sphere_far(cam_loc, ray_dirs, R)
     if is_training:
-        idx = rng["perm"][:N_extra]
+        perm = rng["perm"]
+        idx = (perm(z_vals.shape[1]) if callable(perm) else perm)[:N_extra]
     else:
         idx = torch.linspace(0, z_vals.shape[1] - 1, N_extra).long()
     extra = torch.cat([near_t, far, z_vals[:, idx]], -1)
