@@ -92,6 +92,7 @@ SIGNATURES = {
     "hold_composite_bwd": [C.POINTER(CompositeDesc), _P],
     "hold_bg_composite_fwd": [_P, _P, _P, _I, _I, _L, _P, _P, _P],
     "hold_bg_composite_bwd": [_P, _P, _P, _I, _I, _L, _P, _P, _P, _P],
+    "hold_diag_mfma_peak": [_P, _I, _I, _P],
 }
 
 

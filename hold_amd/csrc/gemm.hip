@@ -16,6 +16,7 @@
 // LDS row stride 36 floats makes the b128 fragment reads and the b128 staging writes conflict-free.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/hold_hip.h"
 
@@ -26,15 +27,26 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32, LSTR = 36;
 
+// softplus(y, beta=100, threshold=20) = y for 100y > 20, else (max(z,0) + log1p(exp(-|z|))) / 100, z = 100y.
+// exp/log run on the hardware transcendental units (v_exp_f32 / v_log_f32); log1p switches to its series
+// for small arguments, so the absolute error stays ~1e-9 (x 1/100), the class of fp32 GEMM reordering noise.
 __device__ __forceinline__ float softplus100(float y) {
-  float z = y * 100.0f;
-  return z > 20.0f ? y : log1pf(expf(z)) * 0.01f;
+  const float z = y * 100.0f;
+  if (z > 20.0f) return y;
+  const float e = __expf(-fabsf(z));
+  const float l = (e > 1e-3f) ? __logf(1.0f + e) : e * (1.0f - e * (0.5f - 0.33333334f * e));
+  return (fmaxf(z, 0.f) + l) * 0.01f;
 }
-// softplus'(x) recovered from h = softplus(x): sigmoid(100x) = 1 - exp(-100h)
-__device__ __forceinline__ float dsp_from_h(float h) { return -expm1f(-100.0f * h); }
+// softplus'(x) recovered from h = softplus(x): sigmoid(100x) = 1 - exp(-100h) (series near 0 keeps the
+// relative accuracy of the small derivatives)
+__device__ __forceinline__ float dsp_from_h(float h) {
+  const float x = 100.0f * h;
+  if (x < 0.05f) return x * (1.0f - x * (0.5f - x * (0.16666667f - 0.041666668f * x)));
+  return 1.0f - __expf(-x);
+}
 
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(hold_gemm_desc d) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(hold_gemm_desc d, int total_tiles, int stagger) {
   __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LSTR];
   float* sA = smem;
   float* sW = smem + 2 * BM * LSTR;
@@ -44,16 +56,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(hold_gemm_desc d) {
   const int wm = wave >> 1, wn = wave & 1;
   const int hh = lane >> 5, li = lane & 31;
   const int ntn = (d.N + BN - 1) / BN;
-  const int mt_blk = blockIdx.x / ntn, nt_blk = blockIdx.x % ntn;
-  const long m0 = (long)mt_blk * BM;
-  const int n0 = nt_blk * BN;
+  const int nk = (d.K + BK - 1) / BK;
 
   // staging assignment: 4 float4 per thread per operand
   const int srow = tid >> 3;        // 0..31 (+32*j)
   const int scol = (tid & 7) * 4;   // 0..28
   f32x4 ra[4], rw[4];
 
-  auto load_tiles = [&](int kt) {
+  auto load_tiles = [&](long m0, int n0, int kt) {
     const int k = kt * BK + scol;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -74,6 +84,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(hold_gemm_desc d) {
     }
   };
 
+  // Persistent blocks: the grid is 2 blocks per CU, each walks tiles blockIdx.x, +gridDim.x, ...  The
+  // second half of the grid (the blocks that share CUs with the first half) starts half a tile late, so
+  // one block's prologue / epilogue overlaps the other's MFMA phase instead of coinciding with it, and
+  // the first K-chunk of the NEXT tile is fetched before the epilogue of the current one.
+  if ((stagger & 255) && blockIdx.x >= (gridDim.x >> 1)) {
+    for (int i = 0; i < (stagger & 255); ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  int tile = blockIdx.x;
+  if (tile < total_tiles) load_tiles((long)(tile / ntn) * BM, (tile % ntn) * BN, 0);
+
+  for (; tile < total_tiles; tile += gridDim.x) {
+  const long m0 = (long)(tile / ntn) * BM;
+  const int n0 = (tile % ntn) * BN;
+
   f32x16 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -82,14 +106,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(hold_gemm_desc d) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int nk = (d.K + BK - 1) / BK;
-  load_tiles(0);
   store_tiles(0);
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tiles(kt + 1);
+    if (kt + 1 < nk && !(stagger & 256)) load_tiles(m0, n0, kt + 1);
     const float* pa = sA + buf * BM * LSTR + (wm * 64 + li) * LSTR + hh * 16;
     const float* pw = sW + buf * BN * LSTR + (wn * 64 + li) * LSTR + hh * 16;
 #pragma unroll
@@ -106,60 +128,140 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(hold_gemm_desc d) {
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b1[c], acc[1][1], 0, 0, 0);
       }
     }
-    if (kt + 1 < nk) store_tiles(buf ^ 1);
-    __syncthreads();
+    if (kt + 1 < nk && !(stagger & 256)) store_tiles(buf ^ 1);
+    if (!(stagger & 512)) __syncthreads();
+  }
+  if (stagger & 1024) continue;
+  {
+    const int nt_ = tile + gridDim.x;
+    if (nt_ < total_tiles) load_tiles((long)(nt_ / ntn) * BM, (nt_ % ntn) * BN, 0);
   }
 
-  // ---- epilogue: lane owns output column n (fixed), 16 points per MFMA tile ----
+  // ---- epilogue ----
+  // The accumulator tile is transposed through LDS (the staging buffers are free after the last
+  // barrier) so that every lane handles 4 CONSECUTIVE output columns of one point: aux reads and the
+  // result stores become 16-byte accesses, 16 lanes covering a 256-byte row segment.
+  constexpr int CSTR = 68;
+  float* sc = smem + wave * (64 * CSTR);
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int n = n0 + wn * 64 + b * 32 + li;
-    if (n >= d.N) continue;
-    const float bias = d.bias ? d.bias[n] : 0.f;
-    const bool raw = n >= d.n_split;
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long p = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (p >= d.P) continue;
-        float y = acc[a][b][r] * d.alpha + bias;
-        if (raw) {
-          float* o = d.C2 + p * (long)d.ldc2 + (n - d.n_split);
-          *o = d.accumulate ? *o + y : y;
-          continue;
+      for (int r = 0; r < 16; ++r)
+        sc[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * CSTR + b * 32 + li] = acc[a][b][r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  auto al16 = [](const void* q, int ld) { return (((uintptr_t)q & 15) == 0) && ((ld & 3) == 0); };
+  bool vec_ok = al16(d.C, d.ldc) && (!d.bias || al16(d.bias, 0));
+  if (EPI == HOLD_EPI_MUL_DSP) vec_ok = vec_ok && al16(d.aux1, d.ldaux1) && (!d.aux2 || al16(d.aux2, d.ldaux2));
+  if (EPI == HOLD_EPI_MUL_DRELU || EPI == HOLD_EPI_MUL_DSIG) vec_ok = vec_ok && al16(d.aux1, d.ldaux1);
+  if (EPI == HOLD_EPI_DBWD)
+    vec_ok = vec_ok && al16(d.aux1, d.ldaux1) && al16(d.aux2, d.ldaux2) && al16(d.out2, d.ldout2);
+
+  auto epi_scalar = [&](long p, int n, float acc_v) {
+    float y = acc_v * d.alpha + (d.bias ? d.bias[n] : 0.f);
+    if (n >= d.n_split) {
+      float* o = d.C2 + p * (long)d.ldc2 + (n - d.n_split);
+      *o = d.accumulate ? *o + y : y;
+      return;
+    }
+    float* o = d.C + p * (long)d.ldc + n;
+    if (EPI == HOLD_EPI_NONE) {
+      *o = d.accumulate ? *o + y : y;
+    } else if (EPI == HOLD_EPI_SOFTPLUS) {
+      *o = softplus100(y);
+    } else if (EPI == HOLD_EPI_RELU) {
+      *o = fmaxf(y, 0.f);
+    } else if (EPI == HOLD_EPI_SIGMOID) {
+      *o = 1.0f / (1.0f + __expf(-y));
+    } else if (EPI == HOLD_EPI_MUL_DSP) {
+      float v = y * dsp_from_h(d.aux1[p * (long)d.ldaux1 + n]);
+      if (d.aux2) v += d.aux2[p * (long)d.ldaux2 + n];
+      *o = v;
+    } else if (EPI == HOLD_EPI_MUL_DRELU) {
+      *o = d.aux1[p * (long)d.ldaux1 + n] > 0.f ? y : 0.f;
+    } else if (EPI == HOLD_EPI_DBWD) {
+      const float h = d.aux1[p * (long)d.ldaux1 + n];
+      const float t = d.aux2[p * (long)d.ldaux2 + n];
+      const float e = __expf(-100.0f * h);
+      *o = y * dsp_from_h(h);
+      d.out2[p * (long)d.ldout2 + n] = 100.0f * y * t * e;
+    } else if (EPI == HOLD_EPI_MUL_DSIG) {
+      const float sg = d.aux1[p * (long)d.ldaux1 + n];
+      *o = y * sg * (1.0f - sg);
+    }
+  };
+
+  const int c4 = (lane & 15) * 4;
+  const int n = n0 + wn * 64 + c4;
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int row = it * 4 + (lane >> 4);
+    const long p = m0 + wm * 64 + row;
+    if (p >= d.P || n >= d.N) continue;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(sc + row * CSTR + c4);
+    if (vec_ok && n + 3 < d.n_split) {
+      f32x4 y = v * d.alpha;
+      if (d.bias) y += *reinterpret_cast<const f32x4*>(d.bias + n);
+      f32x4* o = reinterpret_cast<f32x4*>(d.C + p * (long)d.ldc + n);
+      if (EPI == HOLD_EPI_NONE) {
+        if (d.accumulate) y += *o;
+        *o = y;
+      } else if (EPI == HOLD_EPI_SOFTPLUS) {
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = softplus100(y[j]);
+        *o = r;
+      } else if (EPI == HOLD_EPI_RELU) {
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = fmaxf(y[j], 0.f);
+        *o = r;
+      } else if (EPI == HOLD_EPI_SIGMOID) {
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = 1.0f / (1.0f + __expf(-y[j]));
+        *o = r;
+      } else if (EPI == HOLD_EPI_MUL_DSP) {
+        const f32x4 h = *reinterpret_cast<const f32x4*>(d.aux1 + p * (long)d.ldaux1 + n);
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = y[j] * dsp_from_h(h[j]);
+        if (d.aux2) r += *reinterpret_cast<const f32x4*>(d.aux2 + p * (long)d.ldaux2 + n);
+        *o = r;
+      } else if (EPI == HOLD_EPI_MUL_DRELU) {
+        const f32x4 h = *reinterpret_cast<const f32x4*>(d.aux1 + p * (long)d.ldaux1 + n);
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = h[j] > 0.f ? y[j] : 0.f;
+        *o = r;
+      } else if (EPI == HOLD_EPI_DBWD) {
+        const f32x4 h = *reinterpret_cast<const f32x4*>(d.aux1 + p * (long)d.ldaux1 + n);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(d.aux2 + p * (long)d.ldaux2 + n);
+        f32x4 r, r2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float e = __expf(-100.0f * h[j]);
+          r[j] = y[j] * dsp_from_h(h[j]);
+          r2[j] = 100.0f * y[j] * t[j] * e;
         }
-        float* o = d.C + p * (long)d.ldc + n;
-        if (EPI == HOLD_EPI_NONE) {
-          *o = d.accumulate ? *o + y : y;
-        } else if (EPI == HOLD_EPI_SOFTPLUS) {
-          *o = softplus100(y);
-        } else if (EPI == HOLD_EPI_RELU) {
-          *o = fmaxf(y, 0.f);
-        } else if (EPI == HOLD_EPI_SIGMOID) {
-          *o = 1.0f / (1.0f + expf(-y));
-        } else if (EPI == HOLD_EPI_MUL_DSP) {
-          const float h = d.aux1[p * (long)d.ldaux1 + n];
-          float v = y * dsp_from_h(h);
-          if (d.aux2) v += d.aux2[p * (long)d.ldaux2 + n];
-          *o = v;
-        } else if (EPI == HOLD_EPI_MUL_DRELU) {
-          const float h = d.aux1[p * (long)d.ldaux1 + n];
-          *o = h > 0.f ? y : 0.f;
-        } else if (EPI == HOLD_EPI_DBWD) {
-          const float h = d.aux1[p * (long)d.ldaux1 + n];
-          const float t = d.aux2[p * (long)d.ldaux2 + n];
-          const float e = expf(-100.0f * h);  // 1 - s
-          const float s = -expm1f(-100.0f * h);
-          *o = y * s;
-          d.out2[p * (long)d.ldout2 + n] = 100.0f * y * t * e;
-        } else if (EPI == HOLD_EPI_MUL_DSIG) {
-          const float sg = d.aux1[p * (long)d.ldaux1 + n];
-          *o = y * sg * (1.0f - sg);
-        }
+        *o = r;
+        *reinterpret_cast<f32x4*>(d.out2 + p * (long)d.ldout2 + n) = r2;
+      } else if (EPI == HOLD_EPI_MUL_DSIG) {
+        const f32x4 sg = *reinterpret_cast<const f32x4*>(d.aux1 + p * (long)d.ldaux1 + n);
+        *o = y * sg * (1.0f - sg);
       }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n + j < d.N) epi_scalar(p, n + j, v[j]);
     }
   }
+  __syncthreads();  // epilogue staging reads done before the next tile overwrites the LDS
+  }  // tile loop
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -266,28 +368,43 @@ extern "C" int hold_gemm_nt(const hold_gemm_desc* dp, hold_stream_t stream) {
   if (d.P == 0) return HOLD_OK;
   const long mt = ((long)d.P + BM - 1) / BM;
   const int nt = (d.N + BN - 1) / BN;
-  dim3 grid((unsigned)(mt * nt)), block(256);
+  const long tiles_l = mt * nt;
+  if (tiles_l > 0x7fffffffL) return HOLD_E_ARG;
+  const int tiles = (int)tiles_l;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return HOLD_E_LAUNCH;
+    n_cu = prop.multiProcessorCount;
+  }
+  const int resident = 2 * n_cu;  // two 72 KiB blocks per CU
+  dim3 grid((unsigned)(tiles < resident ? tiles : resident)), block(256);
+  // stagger the second half of a full persistent grid by ~half a tile (s_sleep(127) = 8128 cycles each)
+  const int nkk = (d.K + BK - 1) / BK;
+  int stagger = (tiles >= 2 * resident) ? (nkk >= 6 ? 2 : 1) : 0;
+  if (const char* dbg = getenv("HOLD_GEMM_DEBUG")) stagger |= atoi(dbg);  // timing ablations only (wrong results)
   hipStream_t s = (hipStream_t)stream;
   switch (d.epilogue) {
-    case HOLD_EPI_NONE: hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_NONE>, grid, block, 0, s, d); break;
-    case HOLD_EPI_SOFTPLUS: hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_SOFTPLUS>, grid, block, 0, s, d); break;
-    case HOLD_EPI_RELU: hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_RELU>, grid, block, 0, s, d); break;
-    case HOLD_EPI_SIGMOID: hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_SIGMOID>, grid, block, 0, s, d); break;
+    case HOLD_EPI_NONE: hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_NONE>, grid, block, 0, s, d, tiles, stagger); break;
+    case HOLD_EPI_SOFTPLUS: hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_SOFTPLUS>, grid, block, 0, s, d, tiles, stagger); break;
+    case HOLD_EPI_RELU: hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_RELU>, grid, block, 0, s, d, tiles, stagger); break;
+    case HOLD_EPI_SIGMOID: hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_SIGMOID>, grid, block, 0, s, d, tiles, stagger); break;
     case HOLD_EPI_MUL_DSP:
       if (!d.aux1) return HOLD_E_ARG;
-      hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_MUL_DSP>, grid, block, 0, s, d);
+      hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_MUL_DSP>, grid, block, 0, s, d, tiles, stagger);
       break;
     case HOLD_EPI_MUL_DRELU:
       if (!d.aux1) return HOLD_E_ARG;
-      hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_MUL_DRELU>, grid, block, 0, s, d);
+      hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_MUL_DRELU>, grid, block, 0, s, d, tiles, stagger);
       break;
     case HOLD_EPI_DBWD:
       if (!d.aux1 || !d.aux2 || !d.out2) return HOLD_E_ARG;
-      hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_DBWD>, grid, block, 0, s, d);
+      hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_DBWD>, grid, block, 0, s, d, tiles, stagger);
       break;
     case HOLD_EPI_MUL_DSIG:
       if (!d.aux1) return HOLD_E_ARG;
-      hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_MUL_DSIG>, grid, block, 0, s, d);
+      hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_MUL_DSIG>, grid, block, 0, s, d, tiles, stagger);
       break;
     default: return HOLD_E_ARG;
   }

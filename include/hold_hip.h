@@ -213,6 +213,10 @@ int hold_bg_composite_fwd(const float* z_desc, const float* sdf, const float* rg
 int hold_bg_composite_bwd(const float* z_desc, const float* sdf, const float* rgb, int32_t ld_rgb, int32_t S,
                           int64_t n_rays, const float* d_out, float* d_sdf, float* d_rgb, hold_stream_t stream);
 
+/* diagnostic: pure v_mfma_f32_32x32x2_f32 issue loop (blocks x 256 threads, iters x 64 MFMAs per wave);
+ * out needs blocks*256 floats.  Used only to calibrate the MFMA ceiling at the sustained clock. */
+int hold_diag_mfma_peak(float* out, int32_t blocks, int32_t iters, hold_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,3 +41,18 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 10
 print(f"wgrad P={P} 256x256: {ms:.3f} ms {2.0 * P * 65536 / ms / 1e9:.1f} TFLOP/s")
+
+from hold_amd import _lib
+blocks, iters = 512 * 8, 512
+o = torch.empty(blocks * 256, device=dev)
+for _ in range(2):
+    _lib.call("hold_diag_mfma_peak", _lib.ptr(o), blocks, iters)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+_lib.call("hold_diag_mfma_peak", _lib.ptr(o), blocks, iters)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1)
+fl = blocks * 4 * iters * 64 * (2.0 * 32 * 32 * 2)
+print(f"pure MFMA f32 32x32x2 loop (2 waves/SIMD): {ms:.3f} ms {fl / ms / 1e9:.1f} TFLOP/s")
