@@ -31,7 +31,9 @@ class ManoLayer(nn.Module):
 
     def __init__(self, model: dict, is_rhand=True, dtype=torch.float32):
         super().__init__()
-        t = lambda a: torch.as_tensor(np.asarray(a), dtype=dtype)
+        def t(a):  # the licensed MANO pickle stores a scipy-sparse J_regressor and chumpy arrays
+            a = a.toarray() if hasattr(a, "toarray") else a
+            return torch.as_tensor(np.asarray(a, dtype=np.float64), dtype=dtype)
         self.is_rhand = is_rhand
         self.faces = np.asarray(model["f"])
         self.register_buffer("faces_tensor", torch.as_tensor(self.faces.astype(np.int64)))
