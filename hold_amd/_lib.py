@@ -63,6 +63,11 @@ class CompositeDesc(C.Structure):
     ]
 
 
+class ManoModel(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("v_template", "shapedirs", "posedirs", "J_regressor", "parents",
+                                          "lbs_weights", "pose_mean", "tfs_c_inv")]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 # every exported symbol of include/hold_hip.h with its argument types (stream is always last)
 SIGNATURES = {
@@ -93,6 +98,8 @@ SIGNATURES = {
     "hold_bg_composite_fwd": [_P, _P, _P, _I, _I, _L, _P, _P, _P],
     "hold_bg_composite_bwd": [_P, _P, _P, _I, _I, _L, _P, _P, _P, _P],
     "hold_diag_mfma_peak": [_P, _I, _I, _P],
+    "hold_mano_lbs_fwd": [C.POINTER(ManoModel), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "hold_mano_lbs_bwd": [C.POINTER(ManoModel), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
 }
 
 

@@ -4,10 +4,11 @@ Mirrors the call surface of the reference's ``MANOServer`` / ``ObjectServer``
 (code/src/model/mano/server.py:20-133, code/src/model/obj/server.py:19-56,
 code/src/model/obj/object_model.py:12-70, code/src/utils/external/lbs.py:139-251).
 
-These run on B <= ~50 frames of 778 vertices -- about 1e-5 of the path's FLOPs.  The differentiable
-path below is expressed with batched torch ops on the GPU so pose/shape/translation gradients come from
-autograd; the fused HIP kernel ``hold_mano_lbs_fwd`` (csrc/mano.hip) serves the no-grad callers
-(rendering, the sampler's posed vertices, pose refinement evaluation).
+These run on B <= ~50 frames of 778 vertices -- about 1e-5 of the path's FLOPs.  On the GPU
+``MANOServer.forward`` is ONE launch of the fused HIP kernel ``hold_mano_lbs_fwd`` (csrc/mano.hip) with a
+hand-derived backward ``hold_mano_lbs_bwd`` (pose / shape / translation gradients from d tfs and d verts).
+The torch expression ``mano_lbs`` below is used once, at construction time on the host, to derive the
+canonical-pose constants (verts_c, tfs_c_inv) exactly as the reference's constructor does.
 """
 from __future__ import annotations
 
@@ -33,7 +34,7 @@ class ManoLayer(nn.Module):
         super().__init__()
         def t(a):  # the licensed MANO pickle stores a scipy-sparse J_regressor and chumpy arrays
             a = a.toarray() if hasattr(a, "toarray") else a
-            return torch.as_tensor(np.asarray(a, dtype=np.float64), dtype=dtype)
+            return torch.as_tensor(np.ascontiguousarray(np.asarray(a, dtype=np.float64)), dtype=dtype).contiguous()
         self.is_rhand = is_rhand
         self.faces = np.asarray(model["f"])
         self.register_buffer("faces_tensor", torch.as_tensor(self.faces.astype(np.int64)))
@@ -92,6 +93,59 @@ def mano_lbs(layer: ManoLayer, betas, full_pose):
     return verts, T[:, :, :3, 3], A, v_posed
 
 
+class _ManoLbsFn(torch.autograd.Function):
+    """hold_mano_lbs_fwd / hold_mano_lbs_bwd (csrc/mano.hip): one launch per call, one workgroup per frame."""
+
+    @staticmethod
+    def forward(ctx, server, absolute, scene_scale, transl, thetas, betas):
+        import ctypes as C
+
+        from . import _lib
+
+        hl = server.human_layer
+        B = thetas.shape[0]
+        dev = thetas.device
+        mm = _lib.ManoModel()
+        par = server._parents_i32
+        for name, t in [("v_template", hl.v_template), ("shapedirs", hl.shapedirs), ("posedirs", hl.posedirs),
+                        ("J_regressor", hl.J_regressor), ("parents", par), ("lbs_weights", hl.lbs_weights),
+                        ("pose_mean", hl.pose_mean)]:
+            assert t.is_cuda and t.is_contiguous()
+            setattr(mm, name, t.data_ptr())
+        assert server.tfs_c_inv.is_contiguous()
+        mm.tfs_c_inv = None if absolute else server.tfs_c_inv.data_ptr()
+        args = [a.detach().contiguous().float() for a in (betas, thetas, scene_scale.reshape(-1), transl)]
+        verts = torch.empty(B, 778, 3, device=dev)
+        jnts = torch.empty(B, 21, 3, device=dev)
+        tfs = torch.empty(B, 16, 4, 4, device=dev)
+        v_posed = torch.empty(B, 778, 3, device=dev)
+        _lib.call("hold_mano_lbs_fwd", C.byref(mm), B, *[_lib.ptr(a) for a in args], _lib.ptr(verts), _lib.ptr(jnts),
+                  _lib.ptr(tfs), _lib.ptr(v_posed))
+        ctx.mm, ctx.args, ctx.keep = mm, args, (hl, server)
+        ctx.mark_non_differentiable(v_posed)
+        return verts, jnts, tfs, v_posed
+
+    @staticmethod
+    def backward(ctx, d_verts, d_jnts, d_tfs, _):
+        import ctypes as C
+
+        from . import _lib
+
+        betas, thetas, scale, transl = ctx.args
+        B = thetas.shape[0]
+        dev = thetas.device
+        if d_jnts is not None and bool((d_jnts != 0).any()):
+            raise NotImplementedError("gradients through MANO joints are not used on the hot path")
+        d_pose = torch.empty(B, 48, device=dev)
+        d_betas = torch.empty(B, 10, device=dev)
+        d_transl = torch.empty(B, 3, device=dev)
+        _lib.call("hold_mano_lbs_bwd", C.byref(ctx.mm), B, *[_lib.ptr(a) for a in (betas, thetas, scale, transl)],
+                  _lib.ptr(None if d_tfs is None else d_tfs.contiguous()),
+                  _lib.ptr(None if d_verts is None else d_verts.contiguous()), _lib.ptr(d_pose), _lib.ptr(d_betas),
+                  _lib.ptr(d_transl))
+        return None, None, None, d_transl, d_pose, d_betas
+
+
 class MANOServer(nn.Module):
     """GenericServer/MANOServer of code/src/model/mano/server.py."""
 
@@ -113,12 +167,18 @@ class MANOServer(nn.Module):
             out = self.forward(*self.cano_params, absolute=True)
         self.register_buffer("verts_c", out["verts"], persistent=False)
         self.register_buffer("joints_c", out["jnts"], persistent=False)
-        self.register_buffer("tfs_c_inv", out["tfs"].squeeze(0).inverse(), persistent=False)
+        self.register_buffer("tfs_c_inv", out["tfs"].squeeze(0).inverse().contiguous(), persistent=False)
+        self.register_buffer("_parents_i32", self.human_layer.parents.to(torch.int32), persistent=False)
 
     def forward(self, scene_scale, transl, thetas, betas, absolute=False):
         hl = self.human_layer
         dev = hl.v_template.device
         scene_scale, transl, thetas, betas = (a.to(dev) for a in (scene_scale, transl, thetas, betas))
+        if dev.type == "cuda":  # run-time path: the fused HIP kernel (fwd + hand-derived bwd)
+            verts, jnts, tfs, v_posed = _ManoLbsFn.apply(self, bool(absolute), scene_scale, transl, thetas, betas)
+            return {"verts": verts, "jnts": jnts, "tfs": tfs, "v_posed": v_posed,
+                    "skin_weights": hl.lbs_weights[None].expand(verts.shape[0], -1, -1)}
+        # construction-time only (canonical pose on the host before the module is moved to the GPU)
         verts, joints, A, v_posed = mano_lbs(hl, betas, thetas)
         joints = torch.cat([joints, verts[:, list(TIP_IDS)]], 1)
         s = scene_scale.view(-1, 1, 1)

@@ -213,6 +213,30 @@ int hold_bg_composite_fwd(const float* z_desc, const float* sdf, const float* rg
 int hold_bg_composite_bwd(const float* z_desc, const float* sdf, const float* rgb, int32_t ld_rgb, int32_t S,
                           int64_t n_rays, const float* d_out, float* d_sdf, float* d_rgb, hold_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * MANO forward LBS + server post-processing (hold_amd/csrc/mano.hip), one workgroup per frame.
+ * lbs() code/src/utils/external/lbs.py:139-251, MANO.forward body_models.py:601-685 (pose_mean, fingertips),
+ * GenericServer.forward code/src/model/mano/server.py:62-99 (scale/transl, tfs . tfs_c_inv).
+ * Outputs: verts [B][778][3], jnts [B][21][3] (nullable), tfs [B][16][4][4], v_posed [B][778][3] (nullable).
+ * Backward: given d_tfs and/or d_verts (either may be NULL) -> d_pose [B][48], d_betas [B][10], d_transl [B][3].
+ * ---------------------------------------------------------------------------------------- */
+typedef struct hold_mano_model {
+  const float* v_template;  /* [778][3]      */
+  const float* shapedirs;   /* [778][3][10]  */
+  const float* posedirs;    /* [135][2334]   */
+  const float* J_regressor; /* [16][778]     */
+  const int32_t* parents;   /* [16], parents[0] = -1 */
+  const float* lbs_weights; /* [778][16]     */
+  const float* pose_mean;   /* [48]          */
+  const float* tfs_c_inv;   /* [16][4][4] or NULL for absolute transforms */
+} hold_mano_model;
+int hold_mano_lbs_fwd(const hold_mano_model* m, int32_t n_frames, const float* betas, const float* full_pose,
+                      const float* scene_scale, const float* transl, float* verts, float* jnts, float* tfs,
+                      float* v_posed, hold_stream_t stream);
+int hold_mano_lbs_bwd(const hold_mano_model* m, int32_t n_frames, const float* betas, const float* full_pose,
+                      const float* scene_scale, const float* transl, const float* d_tfs, const float* d_verts,
+                      float* d_pose, float* d_betas, float* d_transl, hold_stream_t stream);
+
 /* diagnostic: pure v_mfma_f32_32x32x2_f32 issue loop (blocks x 256 threads, iters x 64 MFMAs per wave);
  * out needs blocks*256 floats.  Used only to calibrate the MFMA ceiling at the sustained clock. */
 int hold_diag_mfma_peak(float* out, int32_t blocks, int32_t iters, hold_stream_t stream);

@@ -231,3 +231,30 @@ def test_properties_at_scale():
     zo = {n: out[n + ".z_vals"][:4096].contiguous() for n in sc["entities"]}
     out1 = net(hip_input(b1, net), z_override=zo)
     assert float((out1["rgb"] - out["rgb"][:4096]).abs().max()) < 1e-5
+
+
+def test_mano_lbs_kernel_forward_backward(ctx):
+    """hold_mano_lbs_fwd/bwd vs torch autograd on the oracle's lbs: gradients through BOTH outputs the
+    callers differentiate (tfs for the renderer, verts for pose refinement)."""
+    sc, sd, osc = ctx["sc"], ctx["sd"], ctx["osc"]
+    n = sc["n_frames"]
+    pre = "nodes.right.params."
+    leaves = {k: sd[pre + k + ".weight"].clone().requires_grad_(True) for k in ("global_orient", "pose", "transl", "betas")}
+    full_pose = torch.cat([leaves["global_orient"], leaves["pose"]], 1)
+    scale = torch.full((n,), sc["scene_scale"])
+    o = ho.mano_server(osc.mano["right"], osc.tfs_c_inv["right"], scale, leaves["transl"], full_pose,
+                       leaves["betas"].expand(n, -1))
+    g = torch.Generator().manual_seed(3)
+    wv, wt = torch.randn(o["verts"].shape, generator=g), torch.randn(o["tfs"].shape, generator=g)
+    (o["verts"] * wv).sum().add((o["tfs"] * wt).sum()).backward()
+    net = hip_net(sc, ctx["sd_np"])
+    node = net.nodes["right"]
+    p = node.params(torch.arange(n, device="cuda"))
+    so = node.server(scale.cuda(), p["right.transl"], p["right.full_pose"], p["right.betas"])
+    for k in ("verts", "jnts", "tfs", "v_posed"):
+        assert rel_err(so[k], o[k]) < 1e-5, k
+    ((so["verts"] * wv.cuda()).sum() + (so["tfs"] * wt.cuda()).sum()).backward()
+    for k in ("global_orient", "pose", "transl", "betas"):
+        hg = getattr(node.params, k).weight.grad.cpu()
+        rel = float((hg - leaves[k].grad).norm() / leaves[k].grad.norm())
+        assert rel < 1e-4, (k, rel)
