@@ -80,6 +80,15 @@ def cpu_baseline(sc, sd_np, side, frame, threads=32):
                       f"oracle/hold_oracle.py (torch CPU restatement of the reference), {cores} threads"}
 
 
+def pmc_traffic():
+    """HBM bytes per gemm_nt launch from the separate rocprofv3 --pmc passes of this same command
+    (scripts/pmc.sh -> profiles/r01_pmc_traffic.json, FETCH_SIZE doubled per the gfx950 calibration)."""
+    f = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(f):
+        return None
+    return json.load(open(f)).get("hbm_bytes_per_launch")
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -173,10 +182,11 @@ def main():
             g = agg["gemm_nt_kernel"]
             ach = g[1] / g[0] / 1e12
             res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
                                "kernel": "gemm_nt_kernel (v_mfma_f32_32x32x2_f32)", "launches": g[2],
                                "avg_launch_ms": g[0] / g[2] * 1e3, "time_share": g[0] / dt,
-                               "flop_per_launch_avg": g[1] / g[2]}
+                               "flop_per_launch_avg": g[1] / g[2],
+                               "traffic_note": "bytes/launch from separate --pmc passes (profiles/r01_pmc_traffic.json)"}
             if "wgrad_kernel" in agg:
                 w = agg["wgrad_kernel"]
                 res["roofline"]["wgrad"] = {"achieved": w[1] / w[0] / 1e12, "launches": w[2], "time_share": w[0] / dt}

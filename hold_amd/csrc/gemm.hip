@@ -25,7 +25,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, LSTR = 36;
+constexpr int BM = 128;
 
 // softplus(y, beta=100, threshold=20) = y for 100y > 20, else (max(z,0) + log1p(exp(-|z|))) / 100, z = 100y.
 // exp/log run on the hardware transcendental units (v_exp_f32 / v_log_f32); log1p switches to its series
@@ -45,114 +45,93 @@ __device__ __forceinline__ float dsp_from_h(float h) {
   return 1.0f - __expf(-x);
 }
 
-template <int EPI>
+// NT = number of 32-wide output tiles per wave: 2 -> block tile 128 x 128 (BK 32), 4 -> 128 x 256 (BK 16).
+// The wide tile loads 24 KiB per 64 MFMAs/wave instead of 32 KiB (and streams A once instead of twice):
+// the kernel is limited by the per-CU load path (ablation in DESIGN.md), not by MFMA issue.
+template <int EPI, int NT>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(hold_gemm_desc d, int total_tiles, int stagger) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LSTR];
+  constexpr int BNc = 64 * NT;              // block outputs
+  constexpr int BKc = (NT == 2) ? 32 : 16;  // k per stage
+  constexpr int CH = BKc / 4;               // 16-byte chunks per staged row
+  constexpr int RPI = 64 / CH;              // rows per DMA instruction
+  constexpr int KSH = (NT == 2) ? 1 : 2;    // swizzle key = (row >> KSH) & (CH - 1)
+  constexpr int QN = BKc / 8;               // ds_read_b128 per fragment row per stage
+  constexpr int CSTR = 68;
+  __shared__ __attribute__((aligned(16))) float smem[4 * 64 * CSTR];  // 69.6 KiB: epilogue staging >= operand stages
   float* sA = smem;
-  float* sW = smem + 2 * BM * LSTR;
+  float* sW = smem + 2 * BM * BKc;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int hh = lane >> 5, li = lane & 31;
-  const int ntn = (d.N + BN - 1) / BN;
-  const int nk = (d.K + BK - 1) / BK;
+  const int ntn = (d.N + BNc - 1) / BNc;
+  const int nk = (d.K + BKc - 1) / BKc;
 
-  // staging assignment: 4 float4 per thread per operand
-  const int srow = tid >> 3;        // 0..31 (+32*j)
-  const int scol = (tid & 7) * 4;   // 0..28
-  f32x4 ra[4], rw[4];
-
-  auto load_tiles = [&](long m0, int n0, int kt) {
-    const int k = kt * BK + scol;
+  // ---- operand staging: global -> LDS DMA (global_load_lds_dwordx4), no VGPR round trip ----
+  // One wave instruction moves 64 x 16 B = RPI tile rows into a linear 1 KiB of LDS.  The LDS image is
+  // [rows][CH chunks of 16 B] with the chunk index XOR-swizzled by key(row): the DMA destination is
+  // lane-linear, so the swizzle is applied to the per-lane SOURCE address and again on the fragment reads
+  // (both sides or neither).  With these keys the ds_read_b128 fragment reads of a 16-lane group hit 16
+  // distinct 16-byte bank groups (conflict-free).
+  auto key = [](int row) { return (row >> KSH) & (CH - 1); };
+  auto stage = [&](long m0, int n0, int kt, int buf) {
+    const int k0 = kt * BKc;
+    if (k0 + BKc <= d.K) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const long p = m0 + srow + 32 * j;
-      const int n = n0 + srow + 32 * j;
-      f32x4 za = {0.f, 0.f, 0.f, 0.f}, zw = {0.f, 0.f, 0.f, 0.f};
-      if (p < d.P && k < d.K) za = *reinterpret_cast<const f32x4*>(d.A + p * (long)d.lda + k);
-      if (n < d.N && k < d.K) zw = *reinterpret_cast<const f32x4*>(d.W + (long)n * d.ldw + k);
-      ra[j] = za;
-      rw[j] = zw;
+      for (int j = 0; j < BM / RPI / 4; ++j) {
+        const int row = (wave * (BM / RPI / 4) + j) * RPI + lane / CH;
+        const int lc = (lane % CH) ^ key(row);
+        long p = m0 + row;
+        p = p < d.P ? p : (long)d.P - 1;
+        const float* ga = d.A + p * (long)d.lda + k0 + lc * 4;
+        float* la = sA + buf * (BM * BKc) + (wave * (BM / RPI / 4) + j) * 256;
+        if (!(stagger & 2048))
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
+                                           (__attribute__((address_space(3))) void*)la, 16, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < BNc / RPI / 4; ++j) {
+        const int row = (wave * (BNc / RPI / 4) + j) * RPI + lane / CH;
+        const int lc = (lane % CH) ^ key(row);
+        int n = n0 + row;
+        n = n < d.N ? n : d.N - 1;
+        const float* gw = d.W + (long)n * d.ldw + k0 + lc * 4;
+        float* lw = sW + buf * (BNc * BKc) + (wave * (BNc / RPI / 4) + j) * 256;
+        if (!(stagger & 4096))
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gw,
+                                           (__attribute__((address_space(3))) void*)lw, 16, 0, 0);
+      }
+    } else {  // ragged last chunk (K % BK != 0): masked register path into the same swizzled image
+      for (int e = tid; e < (BM + BNc) * CH; e += 256) {
+        const bool isA = e < BM * CH;
+        const int ee = isA ? e : e - BM * CH;
+        const int row = ee / CH, c = ee % CH;
+        const int k = k0 + c * 4;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if (isA) {
+          const long p = m0 + row;
+          if (p < d.P && k < d.K) z = *reinterpret_cast<const f32x4*>(d.A + p * (long)d.lda + k);
+          *reinterpret_cast<f32x4*>(sA + buf * (BM * BKc) + row * BKc + ((c ^ key(row)) << 2)) = z;
+        } else {
+          const int n = n0 + row;
+          if (n < d.N && k < d.K) z = *reinterpret_cast<const f32x4*>(d.W + (long)n * d.ldw + k);
+          *reinterpret_cast<f32x4*>(sW + buf * (BNc * BKc) + row * BKc + ((c ^ key(row)) << 2)) = z;
+        }
+      }
     }
   };
-  auto store_tiles = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      *reinterpret_cast<f32x4*>(sA + buf * BM * LSTR + (srow + 32 * j) * LSTR + scol) = ra[j];
-      *reinterpret_cast<f32x4*>(sW + buf * BN * LSTR + (srow + 32 * j) * LSTR + scol) = rw[j];
-    }
+  auto stage_wait = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   };
 
   // Persistent blocks: the grid is 2 blocks per CU, each walks tiles blockIdx.x, +gridDim.x, ...  The
   // second half of the grid (the blocks that share CUs with the first half) starts half a tile late, so
-  // one block's prologue / epilogue overlaps the other's MFMA phase instead of coinciding with it, and
-  // the first K-chunk of the NEXT tile is fetched before the epilogue of the current one.
+  // one block's prologue / epilogue overlaps the other's MFMA phase instead of coinciding with it.
   if ((stagger & 255) && blockIdx.x >= (gridDim.x >> 1)) {
     for (int i = 0; i < (stagger & 255); ++i) __builtin_amdgcn_s_sleep(127);
   }
-  int tile = blockIdx.x;
-  if (tile < total_tiles) load_tiles((long)(tile / ntn) * BM, (tile % ntn) * BN, 0);
-
-  for (; tile < total_tiles; tile += gridDim.x) {
-  const long m0 = (long)(tile / ntn) * BM;
-  const int n0 = (tile % ntn) * BN;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  store_tiles(0);
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk && !(stagger & 256)) load_tiles(m0, n0, kt + 1);
-    const float* pa = sA + buf * BM * LSTR + (wm * 64 + li) * LSTR + hh * 16;
-    const float* pw = sW + buf * BN * LSTR + (wn * 64 + li) * LSTR + hh * 16;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 a0 = *reinterpret_cast<const f32x4*>(pa + 4 * q);
-      f32x4 a1 = *reinterpret_cast<const f32x4*>(pa + 32 * LSTR + 4 * q);
-      f32x4 b0 = *reinterpret_cast<const f32x4*>(pw + 4 * q);
-      f32x4 b1 = *reinterpret_cast<const f32x4*>(pw + 32 * LSTR + 4 * q);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b0[c], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b1[c], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b0[c], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b1[c], acc[1][1], 0, 0, 0);
-      }
-    }
-    if (kt + 1 < nk && !(stagger & 256)) store_tiles(buf ^ 1);
-    if (!(stagger & 512)) __syncthreads();
-  }
-  if (stagger & 1024) continue;
-  {
-    const int nt_ = tile + gridDim.x;
-    if (nt_ < total_tiles) load_tiles((long)(nt_ / ntn) * BM, (nt_ % ntn) * BN, 0);
-  }
-
-  // ---- epilogue ----
-  // The accumulator tile is transposed through LDS (the staging buffers are free after the last
-  // barrier) so that every lane handles 4 CONSECUTIVE output columns of one point: aux reads and the
-  // result stores become 16-byte accesses, 16 lanes covering a 256-byte row segment.
-  constexpr int CSTR = 68;
-  float* sc = smem + wave * (64 * CSTR);
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        sc[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * CSTR + b * 32 + li] = acc[a][b][r];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
   auto al16 = [](const void* q, int ld) { return (((uintptr_t)q & 15) == 0) && ((ld & 3) == 0); };
   bool vec_ok = al16(d.C, d.ldc) && (!d.bias || al16(d.bias, 0));
@@ -195,72 +174,137 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(hold_gemm_desc d, int t
     }
   };
 
-  const int c4 = (lane & 15) * 4;
-  const int n = n0 + wn * 64 + c4;
-#pragma unroll 4
-  for (int it = 0; it < 16; ++it) {
-    const int row = it * 4 + (lane >> 4);
-    const long p = m0 + wm * 64 + row;
-    if (p >= d.P || n >= d.N) continue;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(sc + row * CSTR + c4);
-    if (vec_ok && n + 3 < d.n_split) {
-      f32x4 y = v * d.alpha;
-      if (d.bias) y += *reinterpret_cast<const f32x4*>(d.bias + n);
-      f32x4* o = reinterpret_cast<f32x4*>(d.C + p * (long)d.ldc + n);
-      if (EPI == HOLD_EPI_NONE) {
-        if (d.accumulate) y += *o;
-        *o = y;
-      } else if (EPI == HOLD_EPI_SOFTPLUS) {
-        f32x4 r;
+
+  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    const long m0 = (long)(tile / ntn) * BM;
+    const int n0 = (tile % ntn) * BNc;
+
+    f32x16 acc[2][NT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = softplus100(y[j]);
-        *o = r;
-      } else if (EPI == HOLD_EPI_RELU) {
-        f32x4 r;
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = fmaxf(y[j], 0.f);
-        *o = r;
-      } else if (EPI == HOLD_EPI_SIGMOID) {
-        f32x4 r;
+      for (int b = 0; b < NT; ++b)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = 1.0f / (1.0f + __expf(-y[j]));
-        *o = r;
-      } else if (EPI == HOLD_EPI_MUL_DSP) {
-        const f32x4 h = *reinterpret_cast<const f32x4*>(d.aux1 + p * (long)d.ldaux1 + n);
-        f32x4 r;
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    stage(m0, n0, 0, 0);
+    stage_wait();
+
+    const int rowa0 = wm * 64 + li, roww0 = wn * (32 * NT) + li;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk && !(stagger & 256)) stage(m0, n0, kt + 1, buf ^ 1);
+      const float* pa = sA + buf * (BM * BKc) + rowa0 * BKc;
+      const float* pw = sW + buf * (BNc * BKc) + roww0 * BKc;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = y[j] * dsp_from_h(h[j]);
-        if (d.aux2) r += *reinterpret_cast<const f32x4*>(d.aux2 + p * (long)d.ldaux2 + n);
-        *o = r;
-      } else if (EPI == HOLD_EPI_MUL_DRELU) {
-        const f32x4 h = *reinterpret_cast<const f32x4*>(d.aux1 + p * (long)d.ldaux1 + n);
-        f32x4 r;
+      for (int q = 0; q < QN; ++q) {
+        const int c = hh * QN + q;
+        f32x4 av[2], bv[NT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = h[j] > 0.f ? y[j] : 0.f;
-        *o = r;
-      } else if (EPI == HOLD_EPI_DBWD) {
-        const f32x4 h = *reinterpret_cast<const f32x4*>(d.aux1 + p * (long)d.ldaux1 + n);
-        const f32x4 t = *reinterpret_cast<const f32x4*>(d.aux2 + p * (long)d.ldaux2 + n);
-        f32x4 r, r2;
+        for (int a = 0; a < 2; ++a)
+          av[a] = *reinterpret_cast<const f32x4*>(pa + a * 32 * BKc + ((c ^ key(rowa0 + 32 * a)) << 2));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float e = __expf(-100.0f * h[j]);
-          r[j] = y[j] * dsp_from_h(h[j]);
-          r2[j] = 100.0f * y[j] * t[j] * e;
-        }
-        *o = r;
-        *reinterpret_cast<f32x4*>(d.out2 + p * (long)d.ldout2 + n) = r2;
-      } else if (EPI == HOLD_EPI_MUL_DSIG) {
-        const f32x4 sg = *reinterpret_cast<const f32x4*>(d.aux1 + p * (long)d.ldaux1 + n);
-        *o = y * sg * (1.0f - sg);
+        for (int b = 0; b < NT; ++b)
+          bv[b] = *reinterpret_cast<const f32x4*>(pw + b * 32 * BKc + ((c ^ key(roww0 + 32 * b)) << 2));
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][cc], bv[b][cc], acc[a][b], 0, 0, 0);
       }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (n + j < d.N) epi_scalar(p, n + j, v[j]);
+      if (!(stagger & 512)) stage_wait();
     }
-  }
-  __syncthreads();  // epilogue staging reads done before the next tile overwrites the LDS
+    if (stagger & 1024) continue;
+
+    // ---- epilogue ----
+    // The accumulator tile is transposed through LDS (the operand stages are free after the last barrier)
+    // 64 columns at a time, so that every lane handles 4 CONSECUTIVE output columns of one point: aux reads
+    // and the result stores become 16-byte accesses, 16 lanes covering a 256-byte row segment.
+    float* sc = smem + wave * (64 * CSTR);
+    const int c4 = (lane & 15) * 4;
+#pragma unroll
+    for (int half = 0; half < NT / 2; ++half) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            sc[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * CSTR + b * 32 + li] = acc[a][half * 2 + b][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int n = n0 + wn * (32 * NT) + half * 64 + c4;
+#pragma unroll 4
+      for (int it = 0; it < 16; ++it) {
+        const int row = it * 4 + (lane >> 4);
+        const long p = m0 + wm * 64 + row;
+        if (p >= d.P || n >= d.N) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sc + row * CSTR + c4);
+        if (vec_ok && n + 3 < d.n_split) {
+          f32x4 y = v * d.alpha;
+          if (d.bias) y += *reinterpret_cast<const f32x4*>(d.bias + n);
+          f32x4* o = reinterpret_cast<f32x4*>(d.C + p * (long)d.ldc + n);
+          if (EPI == HOLD_EPI_NONE) {
+            if (d.accumulate) y += *o;
+            *o = y;
+          } else if (EPI == HOLD_EPI_SOFTPLUS) {
+            f32x4 r;
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = softplus100(y[j]);
+            *o = r;
+          } else if (EPI == HOLD_EPI_RELU) {
+            f32x4 r;
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = fmaxf(y[j], 0.f);
+            *o = r;
+          } else if (EPI == HOLD_EPI_SIGMOID) {
+            f32x4 r;
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = 1.0f / (1.0f + __expf(-y[j]));
+            *o = r;
+          } else if (EPI == HOLD_EPI_MUL_DSP) {
+            const f32x4 h = *reinterpret_cast<const f32x4*>(d.aux1 + p * (long)d.ldaux1 + n);
+            f32x4 r;
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = y[j] * dsp_from_h(h[j]);
+            if (d.aux2) r += *reinterpret_cast<const f32x4*>(d.aux2 + p * (long)d.ldaux2 + n);
+            *o = r;
+          } else if (EPI == HOLD_EPI_MUL_DRELU) {
+            const f32x4 h = *reinterpret_cast<const f32x4*>(d.aux1 + p * (long)d.ldaux1 + n);
+            f32x4 r;
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = h[j] > 0.f ? y[j] : 0.f;
+            *o = r;
+          } else if (EPI == HOLD_EPI_DBWD) {
+            const f32x4 h = *reinterpret_cast<const f32x4*>(d.aux1 + p * (long)d.ldaux1 + n);
+            const f32x4 t = *reinterpret_cast<const f32x4*>(d.aux2 + p * (long)d.ldaux2 + n);
+            f32x4 r, r2;
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float e = __expf(-100.0f * h[j]);
+              r[j] = y[j] * dsp_from_h(h[j]);
+              r2[j] = 100.0f * y[j] * t[j] * e;
+            }
+            *o = r;
+            *reinterpret_cast<f32x4*>(d.out2 + p * (long)d.ldout2 + n) = r2;
+          } else if (EPI == HOLD_EPI_MUL_DSIG) {
+            const f32x4 sg = *reinterpret_cast<const f32x4*>(d.aux1 + p * (long)d.ldaux1 + n);
+            *o = y * sg * (1.0f - sg);
+          }
+        } else {
+    #pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (n + j < d.N) epi_scalar(p, n + j, v[j]);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __syncthreads();  // epilogue staging reads done before the next tile overwrites the LDS
   }  // tile loop
 }
 
@@ -357,17 +401,11 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, 
 
 extern "C" int hold_abi_version(void) { return 1; }
 
-extern "C" int hold_gemm_nt(const hold_gemm_desc* dp, hold_stream_t stream) {
-  if (!dp) return HOLD_E_ARG;
-  hold_gemm_desc d = *dp;
-  if (!d.A || !d.W || !d.C || d.P < 0 || d.N <= 0 || d.K <= 0) return HOLD_E_ARG;
-  if ((d.lda & 3) || (d.ldw & 3) || (d.K & 3)) return HOLD_E_ARG;
-  if (((uintptr_t)d.A & 15) || ((uintptr_t)d.W & 15)) return HOLD_E_ARG;
-  if (d.n_split <= 0 || d.n_split > d.N) d.n_split = d.N;
-  if (d.n_split < d.N && !d.C2) return HOLD_E_ARG;
-  if (d.P == 0) return HOLD_OK;
+template <int NT>
+static int launch_gemm(const hold_gemm_desc& d, hipStream_t s) {
+  constexpr int BNc = 64 * NT, BKc = (NT == 2) ? 32 : 16;
   const long mt = ((long)d.P + BM - 1) / BM;
-  const int nt = (d.N + BN - 1) / BN;
+  const int nt = (d.N + BNc - 1) / BNc;
   const long tiles_l = mt * nt;
   if (tiles_l > 0x7fffffffL) return HOLD_E_ARG;
   const int tiles = (int)tiles_l;
@@ -378,37 +416,45 @@ extern "C" int hold_gemm_nt(const hold_gemm_desc* dp, hold_stream_t stream) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return HOLD_E_LAUNCH;
     n_cu = prop.multiProcessorCount;
   }
-  const int resident = 2 * n_cu;  // two 72 KiB blocks per CU
+  const int resident = 2 * n_cu;  // two 69.6 KiB blocks per CU
   dim3 grid((unsigned)(tiles < resident ? tiles : resident)), block(256);
   // stagger the second half of a full persistent grid by ~half a tile (s_sleep(127) = 8128 cycles each)
-  const int nkk = (d.K + BK - 1) / BK;
-  int stagger = (tiles >= 2 * resident) ? (nkk >= 6 ? 2 : 1) : 0;
+  const int nkk = (d.K + BKc - 1) / BKc;
+  int stagger = (tiles >= 2 * resident) ? (nkk * BKc >= 192 ? 2 : 1) : 0;
   if (const char* dbg = getenv("HOLD_GEMM_DEBUG")) stagger |= atoi(dbg);  // timing ablations only (wrong results)
-  hipStream_t s = (hipStream_t)stream;
   switch (d.epilogue) {
-    case HOLD_EPI_NONE: hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_NONE>, grid, block, 0, s, d, tiles, stagger); break;
-    case HOLD_EPI_SOFTPLUS: hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_SOFTPLUS>, grid, block, 0, s, d, tiles, stagger); break;
-    case HOLD_EPI_RELU: hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_RELU>, grid, block, 0, s, d, tiles, stagger); break;
-    case HOLD_EPI_SIGMOID: hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_SIGMOID>, grid, block, 0, s, d, tiles, stagger); break;
-    case HOLD_EPI_MUL_DSP:
-      if (!d.aux1) return HOLD_E_ARG;
-      hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_MUL_DSP>, grid, block, 0, s, d, tiles, stagger);
-      break;
-    case HOLD_EPI_MUL_DRELU:
-      if (!d.aux1) return HOLD_E_ARG;
-      hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_MUL_DRELU>, grid, block, 0, s, d, tiles, stagger);
-      break;
-    case HOLD_EPI_DBWD:
-      if (!d.aux1 || !d.aux2 || !d.out2) return HOLD_E_ARG;
-      hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_DBWD>, grid, block, 0, s, d, tiles, stagger);
-      break;
-    case HOLD_EPI_MUL_DSIG:
-      if (!d.aux1) return HOLD_E_ARG;
-      hipLaunchKernelGGL(gemm_nt_kernel<HOLD_EPI_MUL_DSIG>, grid, block, 0, s, d, tiles, stagger);
-      break;
+#define HOLD_CASE(E) \
+  case E: hipLaunchKernelGGL((gemm_nt_kernel<E, NT>), grid, block, 0, s, d, tiles, stagger); break;
+    HOLD_CASE(HOLD_EPI_NONE)
+    HOLD_CASE(HOLD_EPI_SOFTPLUS)
+    HOLD_CASE(HOLD_EPI_RELU)
+    HOLD_CASE(HOLD_EPI_SIGMOID)
+    HOLD_CASE(HOLD_EPI_MUL_DSP)
+    HOLD_CASE(HOLD_EPI_MUL_DRELU)
+    HOLD_CASE(HOLD_EPI_DBWD)
+    HOLD_CASE(HOLD_EPI_MUL_DSIG)
+#undef HOLD_CASE
     default: return HOLD_E_ARG;
   }
   return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+}
+
+extern "C" int hold_gemm_nt(const hold_gemm_desc* dp, hold_stream_t stream) {
+  if (!dp) return HOLD_E_ARG;
+  hold_gemm_desc d = *dp;
+  if (!d.A || !d.W || !d.C || d.P < 0 || d.N <= 0 || d.K <= 0) return HOLD_E_ARG;
+  if ((d.lda & 3) || (d.ldw & 3) || (d.K & 3)) return HOLD_E_ARG;
+  if (((uintptr_t)d.A & 15) || ((uintptr_t)d.W & 15)) return HOLD_E_ARG;
+  if (d.n_split <= 0 || d.n_split > d.N) d.n_split = d.N;
+  if (d.n_split < d.N && !d.C2) return HOLD_E_ARG;
+  if ((d.epilogue == HOLD_EPI_MUL_DSP || d.epilogue == HOLD_EPI_MUL_DRELU || d.epilogue == HOLD_EPI_MUL_DSIG) && !d.aux1)
+    return HOLD_E_ARG;
+  if (d.epilogue == HOLD_EPI_DBWD && (!d.aux1 || !d.aux2 || !d.out2)) return HOLD_E_ARG;
+  if (d.P == 0) return HOLD_OK;
+  hipStream_t s = (hipStream_t)stream;
+  int wide = d.N > 128;
+  if (const char* w = getenv("HOLD_GEMM_TILE")) wide = atoi(w) == 256;
+  return wide ? launch_gemm<4>(d, s) : launch_gemm<2>(d, s);
 }
 
 extern "C" int64_t hold_wgrad_workspace_floats(int32_t N, int32_t K, int32_t splits) {
