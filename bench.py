@@ -187,6 +187,10 @@ def main():
                                "avg_launch_ms": g[0] / g[2] * 1e3, "time_share": g[0] / dt,
                                "flop_per_launch_avg": g[1] / g[2],
                                "traffic_note": "bytes/launch from separate --pmc passes (profiles/r01_pmc_traffic.json)"}
+            if "fused_sdf_kernel" in agg:
+                f_ = agg["fused_sdf_kernel"]
+                res["roofline"]["fused_sdf"] = {"achieved": f_[1] / f_[0] / 1e12, "launches": f_[2],
+                                                "time_share": f_[0] / dt}
             if "wgrad_kernel" in agg:
                 w = agg["wgrad_kernel"]
                 res["roofline"]["wgrad"] = {"achieved": w[1] / w[0] / 1e12, "launches": w[2], "time_share": w[0] / dt}

@@ -13,7 +13,7 @@
 
 namespace {
 
-constexpr int MAXN = 3, MAXSN = 128, MAXK = MAXN * MAXSN;
+constexpr int MAXN = 3, MAXSN = 192, MAXK = MAXN * MAXSN;  // S = 162 for N_samples = 128 (config C5)
 constexpr int WAVES = 4;
 constexpr int OUTW = 12;  // rgb3, mask1, normal3, depth1, bgw1, pad3
 

@@ -1,0 +1,227 @@
+// Fused SDF-only ImplicitNet evaluation for the sampler's no-grad queries (gfx950).
+// Reference: ImplicitNet.forward code/src/networks/shape_net.py:84-130 (embedding, 8 softplus(beta=100) layers, skip
+// concat /sqrt(2) at layer 4, sdf = row 0 of the last layer) as called from sdf_func_with_deformer
+// (code/src/engine/volsdf_utils.py:150-169) inside ErrorBoundSampler.get_z_vals (code/src/engine/ray_sampler.py:169-178).
+//
+// One workgroup (8 waves) owns 128 points for the WHOLE network: activations never leave LDS
+// ([128][260] fp32 = 130 KiB + the 39-wide embedding kept for the skip), only the weights stream in
+// (pre-packed in MFMA-fragment order, 2 MiB, L2-resident): 256 KiB per layer per 128 points = 4 B/clk/CU,
+// against 8 B/clk/CU + the activation round trip of the layer-by-layer GEMMs.  Roofline: fp32 MFMA
+// (v_mfma_f32_32x32x2_f32), 2 * 472 k MAC = 0.94 MFLOP per point; HBM traffic 16 B in + 4 B out per point.
+//
+// Wave w owns output features [32w, 32w+32) for all 128 points (4 accumulator tiles).  MFMA A operand =
+// activations (ds_read_b128, conflict-free with the 260-float row stride), B operand = packed weights
+// (one coalesced 1 KiB global load per 8 k-values per wave, prefetched two chunks ahead).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "../../include/hold_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int ASTR = 260, ESTR = 40, NE = 39;
+constexpr int L0_CHUNKS = 5, LK_CHUNKS = 32;         // K = 40 and 256, in chunks of 8
+constexpr int CHUNK_FLOATS = 8 * 64 * 4;             // [8 n-tiles][64 lanes][4]
+constexpr int SKIP_OUT = 217;
+
+__device__ __forceinline__ float softplus100(float y) {
+  const float z = y * 100.0f;
+  if (z > 20.0f) return y;
+  const float e = __expf(-fabsf(z));
+  const float l = (e > 1e-3f) ? __logf(1.0f + e) : e * (1.0f - e * (0.5f - 0.33333334f * e));
+  return (fmaxf(z, 0.f) + l) * 0.01f;
+}
+
+struct FusedArgs {
+  const float* xc; int ldx; long P;
+  const float* wpack;   // layer 0 (5 chunks) then layers 1..7 (32 chunks each), fragment order
+  const float* bias;    // [8][256]
+  const float* w8;      // [256] sdf row of the last layer
+  float b8;
+  const float* barf;    // [39] or null
+  float* sdf; int lds;
+};
+
+// MT m-tiles (32 points each) and NTW n-tiles (32 outputs each) per wave; 8 / NTW waves per block.
+//   <4,1>: 128 points, 8 waves, one block per CU (least weight traffic)
+//   <2,2>:  64 points, 4 waves, TWO independent blocks per CU: one block's per-layer epilogue (bias + softplus +
+//           LDS write-back, barriers) overlaps the other block's MFMA phase
+template <int MT, int NTW>
+__global__ __launch_bounds__(64 * (8 / NTW), (MT == 4) ? 2 : 2) void fused_sdf_kernel(FusedArgs a, int stagger) {
+  constexpr int PTS = 32 * MT, NTHR = 64 * (8 / NTW);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* act = smem;                   // [PTS][260]
+  float* emb = smem + PTS * ASTR;      // [PTS][40]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, li = lane & 31;
+  if (stagger && (blockIdx.x & 1))
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+
+  for (long blk = blockIdx.x; blk * PTS < a.P; blk += gridDim.x) {
+    const long p0 = blk * PTS;
+    // ---- embedding [x, sin(2^k x), cos(2^k x)] (embedders.py:18-50), optional BARF weights ----
+    for (int e = tid; e < PTS * ESTR; e += NTHR) {
+      const int p = e / ESTR, j = e % ESTR;
+      float v = 0.f;
+      const long gp = p0 + p;
+      if (j < NE && gp < a.P) {
+        if (j < 3) {
+          v = a.xc[gp * a.ldx + j];
+        } else {
+          const int q = (j - 3) / 3, dim = (j - 3) % 3, k = q >> 1;
+          const float arg = a.xc[gp * a.ldx + dim] * (float)(1 << k);
+          v = (q & 1) ? cosf(arg) : sinf(arg);
+        }
+        if (a.barf) v *= a.barf[j];
+      }
+      emb[p * ESTR + j] = v;
+      act[p * ASTR + j] = v;
+    }
+    __syncthreads();
+
+    const float* wl = a.wpack;
+    for (int layer = 0; layer < 8; ++layer) {
+      const int chunks = (layer == 0) ? L0_CHUNKS : LK_CHUNKS;
+      f32x16 acc[MT][NTW];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+      const f32x4* wp = reinterpret_cast<const f32x4*>(wl) + (wave * NTW) * 64 + lane;  // + chunk * 512 + n * 64
+      const float* arow = act + li * ASTR + hh * 4;
+      f32x4 b0[NTW], b1[NTW];
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) {
+        b0[n] = wp[n * 64];
+        b1[n] = (chunks > 1) ? wp[512 + n * 64] : b0[n];
+      }
+      for (int kc = 0; kc < chunks; kc += 2) {
+        {
+          f32x4 b[NTW];
+#pragma unroll
+          for (int n = 0; n < NTW; ++n) {
+            b[n] = b0[n];
+            if (kc + 2 < chunks) b0[n] = wp[(long)(kc + 2) * 512 + n * 64];
+          }
+          f32x4 av[MT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) av[m] = *reinterpret_cast<const f32x4*>(arow + m * 32 * ASTR + kc * 8);
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+              for (int n = 0; n < NTW; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][c], b[n][c], acc[m][n], 0, 0, 0);
+        }
+        if (kc + 1 < chunks) {
+          f32x4 b[NTW];
+#pragma unroll
+          for (int n = 0; n < NTW; ++n) {
+            b[n] = b1[n];
+            if (kc + 3 < chunks) b1[n] = wp[(long)(kc + 3) * 512 + n * 64];
+          }
+          f32x4 av[MT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) av[m] = *reinterpret_cast<const f32x4*>(arow + m * 32 * ASTR + (kc + 1) * 8);
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+              for (int n = 0; n < NTW; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][c], b[n][c], acc[m][n], 0, 0, 0);
+        }
+      }
+      wl += (long)chunks * CHUNK_FLOATS;
+      __syncthreads();  // every wave has finished READING this layer's input
+      // ---- epilogue: bias + softplus, written back in place as the next layer's input ----
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) {
+        const int n_own = (wave * NTW + n) * 32 + li;
+        const float bias = a.bias[layer * 256 + n_own];
+        const bool skip_col = (layer == 3) && (n_own >= SKIP_OUT);  // columns 217.. of layer 4's input = embedding
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int p = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            float v;
+            if (skip_col) v = emb[p * ESTR + (n_own - SKIP_OUT)];
+            else v = softplus100(acc[m][n][r] + bias);
+            act[p * ASTR + n_own] = v;
+          }
+      }
+      __syncthreads();
+    }
+    // ---- sdf = w8 . h7 + b8 : 4 threads per point, 64-wide partial dots ----
+    {
+      const int p = tid >> 2, q = tid & 3;
+      const f32x4* hrow = reinterpret_cast<const f32x4*>(act + p * ASTR + q * 64);
+      const f32x4* wrow = reinterpret_cast<const f32x4*>(a.w8 + q * 64);
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const f32x4 h = hrow[i], w = wrow[i];
+        s += h[0] * w[0] + h[1] * w[1] + h[2] * w[2] + h[3] * w[3];
+      }
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      if (q == 0 && p < PTS && p0 + p < a.P) a.sdf[(p0 + p) * a.lds] = s + a.b8;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t hold_fused_sdf_pack_floats(void) {
+  return (int64_t)(L0_CHUNKS + 7 * LK_CHUNKS) * CHUNK_FLOATS;
+}
+
+extern "C" int hold_fused_sdf(const float* xc, int32_t ldx, int64_t P, const float* wpack, const float* bias,
+                              const float* w8, float b8, const float* barf_w, float* sdf, int32_t ld_sdf,
+                              hold_stream_t st) {
+  if (!xc || !wpack || !bias || !w8 || !sdf || ldx < 3 || ld_sdf < 1 || P < 0) return HOLD_E_ARG;
+  if (((uintptr_t)wpack & 15) || ((uintptr_t)w8 & 15)) return HOLD_E_ARG;
+  if (P == 0) return HOLD_OK;
+  static int n_cu = 0;
+  static bool attr_set = false;
+  static int variant = -1;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return HOLD_E_LAUNCH;
+    n_cu = prop.multiProcessorCount;
+    const char* v = getenv("HOLD_FUSED_VARIANT");
+    variant = v ? atoi(v) : 128;  // 128-point blocks measured faster than 2 x 64 (99.5 vs 94.4 TFLOP/s)
+  }
+  const size_t sh128 = (size_t)(128 * ASTR + 128 * ESTR) * sizeof(float);  // 153 600 B, one block per CU
+  const size_t sh64 = (size_t)(64 * ASTR + 64 * ESTR) * sizeof(float);     //  76 800 B, two blocks per CU
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)fused_sdf_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sh128) != hipSuccess ||
+        hipFuncSetAttribute((const void*)fused_sdf_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sh64) != hipSuccess)
+      return HOLD_E_LAUNCH;
+    attr_set = true;
+  }
+  FusedArgs a = {xc, ldx, (long)P, wpack, bias, w8, b8, barf_w, sdf, ld_sdf};
+  if (variant == 128) {
+    const long blocks = (P + 127) / 128;
+    hipLaunchKernelGGL((fused_sdf_kernel<4, 1>), dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(512), sh128,
+                       (hipStream_t)st, a, 0);
+  } else {
+    const long blocks = (P + 63) / 64;
+    const long res = 2L * n_cu;
+    hipLaunchKernelGGL((fused_sdf_kernel<2, 2>), dim3((unsigned)(blocks < res ? blocks : res)), dim3(256), sh64,
+                       (hipStream_t)st, a, blocks >= 4 * res ? 3 : 0);
+  }
+  return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+}

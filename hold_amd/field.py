@@ -15,6 +15,7 @@ Buffers (fp32, ray-major points p = ray*S + s):
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
@@ -22,6 +23,7 @@ from . import gemm as G
 from . import kernels as K
 
 FEAT = 256
+FUSED_SDF = os.environ.get("HOLD_FUSED_SDF", "1") != "0"  # sampler queries through the fused LDS-resident kernel
 RIN_X, RIN_N, RIN_POSE, RIN_FEAT = 0, 3, 6, 14
 
 
@@ -92,6 +94,18 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
         wt[:, :n] = W[l].t()
         WT.append(wt)
     pk["WT"] = WT
+    # fragment-ordered pack for the fused SDF-only kernel (hold_fused_sdf)
+    parts = []
+    for l in range(8):
+        wl = W[l]
+        if wl.shape[0] < 256:
+            wl = torch.cat([wl, torch.zeros(256 - wl.shape[0], wl.shape[1], device=dev)], 0)
+        ch = wl.shape[1] // 8
+        parts.append(wl.reshape(8, 32, ch, 2, 4).permute(2, 0, 3, 1, 4).reshape(-1))
+    bias8 = torch.zeros(8, 256, device=dev)
+    for l in range(8):
+        bias8[l, :pk["b"][l].shape[0]] = pk["b"][l]
+    pk["fused"] = (torch.cat(parts).contiguous(), bias8.contiguous())
     r0 = torch.zeros(256, spec.Kr, device=dev)
     r0[:, :spec.rin_dim] = rw[0]
     R = [r0, rw[1].contiguous(), rw[2].contiguous(), rw[3].contiguous(), rw[4].contiguous()]
@@ -148,7 +162,11 @@ class NodeField:
     def sdf_only(self, pk, x, P, ppf, dfm, barf_w, out_sdf):
         """no-grad SDF query of the sampler (sdf_func_with_deformer, volsdf_utils.py:150-169).  out_sdf [P,1]."""
         xc, _ = self._deform(x, P, ppf, dfm, want_w=False)
-        # ping-pong activations: only two [P,256] buffers (+ the skip buffer) stay live
+        if FUSED_SDF:
+            wpack, bias8 = pk["fused"]
+            K.fused_sdf(xc, P, wpack, bias8, pk["w8_sdf"], float(pk["b8_sdf"]), barf_w, out_sdf)
+            return
+        # layer-by-layer variant (ping-pong activations: two [P,256] buffers + the skip buffer stay live)
         _, h = self._trunk(pk, xc, P, barf_w, keep_all=False)
         K.rowdot(h[7], pk["w8_sdf"], 256, float(pk["b8_sdf"]), P, out_sdf)
 

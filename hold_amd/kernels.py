@@ -84,6 +84,15 @@ def rowdot(A, w, K, b, P, out):
     call("hold_rowdot", ptr(A), _ld(A), ptr(w), K, float(b), P, ptr(out), _ld(out))
 
 
+def fused_sdf(xc, P, wpack, bias8, w8, b8, barf_w, out_sdf):
+    assert wpack.numel() == _lib.lib().hold_fused_sdf_pack_floats()
+    from . import gemm as _g
+    e0 = _g._prof_begin()
+    call("hold_fused_sdf", ptr(xc), _ld(xc), P, ptr(wpack), ptr(bias8), ptr(w8), float(b8), ptr(barf_w), ptr(out_sdf),
+         _ld(out_sdf))
+    _g._prof_end(e0, 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256), "fused_sdf_kernel")
+
+
 def seed_dsp(h, w, N, P, t):
     call("hold_seed_dsp", ptr(h), _ld(h), ptr(w), N, P, ptr(t), _ld(t))
 

@@ -237,9 +237,26 @@ int hold_mano_lbs_bwd(const hold_mano_model* m, int32_t n_frames, const float* b
                       const float* scene_scale, const float* transl, const float* d_tfs, const float* d_verts,
                       float* d_pose, float* d_betas, float* d_transl, hold_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused SDF-only ImplicitNet (hold_amd/csrc/fused_sdf.hip): embedding + 8 softplus layers + sdf row in ONE
+ * launch, activations resident in LDS, for the sampler's no-grad queries
+ * (shape_net.py:84-130 via volsdf_utils.py:150-169 inside ray_sampler.py:169-178).
+ * wpack: weights in MFMA-fragment order, hold_fused_sdf_pack_floats() floats:
+ *   for layer l (K_l = 40 for l = 0, else 256; layer 3 padded to 256 rows, layer 4 pre-scaled by 1/sqrt 2):
+ *   [K_l/8 chunks][8 n-tiles][2 halves h][32 rows i][4] = W_l[32*nt + i][8*chunk + 4*h + c]
+ * bias [8][256]; w8 [256] + b8 = sdf row of the last layer; barf_w [39] or NULL.
+ * ---------------------------------------------------------------------------------------- */
+int64_t hold_fused_sdf_pack_floats(void);
+int hold_fused_sdf(const float* xc, int32_t ldx, int64_t P, const float* wpack, const float* bias, const float* w8,
+                   float b8, const float* barf_w, float* sdf, int32_t ld_sdf, hold_stream_t stream);
+
 /* diagnostic: pure v_mfma_f32_32x32x2_f32 issue loop (blocks x 256 threads, iters x 64 MFMAs per wave);
- * out needs blocks*256 floats.  Used only to calibrate the MFMA ceiling at the sustained clock. */
-int hold_diag_mfma_peak(float* out, int32_t blocks, int32_t iters, hold_stream_t stream);
+ * out needs blocks*256 floats; random_operands != 0 feeds 32 pseudo-random operand values per lane (realistic
+ * switching power).  Used only to calibrate the MFMA ceiling at the sustained clock. */
+int hold_diag_mfma_peak(float* out, int32_t blocks, int32_t iters, int32_t random_operands, hold_stream_t stream);
+/* diagnostic: same MFMA count with A operands read from LDS (mode 2) and B streamed from wsrc (mode 3; >= 64 Ki floats);
+ * out needs blocks*512 floats */
+int hold_diag_mfma_lds(float* out, const float* wsrc, int32_t blocks, int32_t iters, int32_t mode, hold_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -90,3 +90,35 @@ def test_wgrad(P, N, K):
     refb = R.double().sum(0) + 1
     assert ((dW.double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
     assert ((db.double() - refb).abs().max() / refb.abs().max()).item() < 1e-5
+
+
+def test_fused_sdf_matches_layered_path():
+    """hold_fused_sdf (LDS-resident 8-layer trunk) against the layer-by-layer GEMM path on the same weights."""
+    import numpy as np
+    from hold_amd import field as F, kernels as K, synthetic as syn
+    dev = _dev()
+    sc = syn.make_scene(2)
+    sd = {k: torch.as_tensor(v).to(dev) for k, v in syn.make_state_dict(sc).items()}
+    for kind, node in (("hand", "right"), ("object", "object")):
+        spec = F.FieldSpec(kind)
+        pre = f"nodes.{node}."
+        eff = lambda p: sd[p + ".weight_v"] * (sd[p + ".weight_g"] / sd[p + ".weight_v"].norm(dim=1, keepdim=True))
+        iw = [eff(pre + f"implicit_network.lin{l}") for l in range(9)]
+        ib = [sd[pre + f"implicit_network.lin{l}.bias"] for l in range(9)]
+        rw = [eff(pre + f"rendering_network.lin{l}") for l in range(5)]
+        rb = [sd[pre + f"rendering_network.lin{l}.bias"] for l in range(5)]
+        pk = F.pack_weights(spec, iw, ib, rw, rb, need_bwd=False)
+        nf = F.NodeField(spec, dev)
+        P = 1000
+        g = torch.Generator().manual_seed(1)
+        xc = torch.zeros(P, 4, device=dev)
+        xc[:, :3] = (torch.rand(P, 3, generator=g) * 1.6 - 0.8).to(dev)
+        barf = (torch.rand(39, generator=g).to(dev) if kind == "object" else None)
+        _, h = nf._trunk(pk, xc, P, barf, keep_all=False)
+        ref = torch.empty(P, 1, device=dev)
+        K.rowdot(h[7], pk["w8_sdf"], 256, float(pk["b8_sdf"]), P, ref)
+        out = torch.full((P, 1), 7.0, device=dev)
+        wpack, bias8 = pk["fused"]
+        K.fused_sdf(xc, P, wpack, bias8, pk["w8_sdf"], float(pk["b8_sdf"]), barf, out)
+        err = float((out - ref).abs().max())
+        assert err < 2e-5 * max(1.0, float(ref.abs().max())), (kind, err)

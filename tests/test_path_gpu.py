@@ -274,3 +274,20 @@ def test_two_hand_scene_three_nodes():
         tol = 1e-3 if "normal" in k else 1e-4
         assert float((out[k].cpu() - oo[k].detach()).abs().max()) < tol * max(1.0, float(oo[k].abs().max())), k
     assert torch.equal(out["instance_map"].cpu(), oo["instance_map"])
+
+
+def test_c5_sampler_config_128_samples():
+    """config C5 sampling (N_samples = 128 -> 162 samples per node): shapes + invariants."""
+    import hold_amd
+    from hold_amd import synthetic as syn
+    from hold_amd.hold_net import DEFAULT_SAMPLER
+    sc = syn.make_scene(2)
+    so = dict(DEFAULT_SAMPLER, N_samples=128)
+    net = hold_amd.build_from_scene(sc, syn.make_state_dict(sc), device="cuda:0", sampler_opt=so)
+    net.eval()
+    uv = syn.make_uv(16, 16)
+    b = syn.make_batch(sc, [0], uv, 16, 16)
+    out = net(hip_input(b, net))
+    assert out["right.z_vals"].shape[1] == 162 and out["fg_weights"].shape[1] == 2 * 162 - 3
+    assert float((out["fg_weights"].sum(1) + out["bg_weights"] - 1).abs().max()) < 1e-4
+    assert torch.all(out["object.z_vals"][:, 1:] >= out["object.z_vals"][:, :-1])
