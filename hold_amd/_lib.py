@@ -98,6 +98,10 @@ SIGNATURES = {
     "hold_bg_composite_fwd": [_P, _P, _P, _I, _I, _L, _P, _P, _P],
     "hold_bg_composite_bwd": [_P, _P, _P, _I, _I, _L, _P, _P, _P, _P],
     "hold_diag_mfma_peak": [_P, _I, _I, _I, _P],
+    "hold_silhouette_fwd": [_P, _I, _I, _P, _I, _F, _F, _F, _F, _I, _I, _F, _F, _P, _P, _P],
+    "hold_silhouette_bwd": [_P, _I, _I, _P, _I, _F, _F, _F, _F, _I, _I, _F, _F, _P, _P, _P, _P, _P],
+    "hold_knn1_fwd": [_P, _I, _I, _P, _I, _P, _P, _P],
+    "hold_knn1_bwd": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P],
     "hold_diag_mfma_lds": [_P, _P, _I, _I, _I, _P],
     "hold_fused_sdf": [_P, _I, _L, _P, _P, _P, _F, _P, _P, _I, _P],
     "hold_mano_lbs_fwd": [C.POINTER(ManoModel), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
@@ -110,6 +114,8 @@ def _declare(L):
     L.hold_wgrad_workspace_floats.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     L.hold_wgrad_workspace_floats.restype = C.c_int64
     L.hold_fused_sdf_pack_floats.restype = C.c_int64
+    L.hold_silhouette_workspace_floats.argtypes = [C.c_int32, C.c_int32]
+    L.hold_silhouette_workspace_floats.restype = C.c_int64
     for name, args in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError here = symbol missing from the shared object
         fn.argtypes = args

@@ -250,6 +250,29 @@ int64_t hold_fused_sdf_pack_floats(void);
 int hold_fused_sdf(const float* xc, int32_t ldx, int64_t P, const float* wpack, const float* bias, const float* w8,
                    float b8, const float* barf_w, float* sdf, int32_t ld_sdf, hold_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Pose-refinement inner loop (hold_amd/csrc/silhouette.hip).
+ * Soft silhouette = pytorch3d MeshRenderer(MeshRasterizer(blur_radius, faces_per_pixel=100), SoftSilhouetteShader)
+ * as configured by code/src/fitting/utils.py:101-158 and called at code/src/fitting/model.py:136-138:
+ *   mask[b][i][j] = 1 - prod_f sigmoid(d_f / sigma) over faces with signed squared NDC distance d_f < blur_radius.
+ * v3d_c [B][V][3] camera-space vertices (OpenCV axes), faces [F][3] int32, pin-hole fx, fy, cx, cy in pixels.
+ * workspace: hold_silhouette_workspace_floats(B, F) floats.  Backward returns d L / d v3d_c ([B][V][3], overwritten);
+ * d_ndc_scratch needs B*V*2 floats.
+ * K = 1 nearest neighbour = pytorch3d.ops.knn_points(K=1) of the contact terms (code/src/fitting/loss.py:90,131-136):
+ *   d2 [B][Nq] squared distances, idx [B][Nq]; backward: dq overwritten, dt_accum += .
+ * ---------------------------------------------------------------------------------------- */
+int64_t hold_silhouette_workspace_floats(int32_t B, int32_t F);
+int hold_silhouette_fwd(const float* v3d_c, int32_t B, int32_t V, const int32_t* faces, int32_t F, float fx, float fy,
+                        float cx, float cy, int32_t H, int32_t W, float sigma, float blur_radius, float* workspace,
+                        float* mask, hold_stream_t stream);
+int hold_silhouette_bwd(const float* v3d_c, int32_t B, int32_t V, const int32_t* faces, int32_t F, float fx, float fy,
+                        float cx, float cy, int32_t H, int32_t W, float sigma, float blur_radius, float* workspace,
+                        const float* d_mask, float* d_ndc_scratch, float* d_v3d_c, hold_stream_t stream);
+int hold_knn1_fwd(const float* q, int32_t B, int32_t Nq, const float* t, int32_t Nt, float* d2, int32_t* idx,
+                  hold_stream_t stream);
+int hold_knn1_bwd(const float* q, int32_t B, int32_t Nq, const float* t, int32_t Nt, const int32_t* idx, const float* g,
+                  float* dq, float* dt_accum, hold_stream_t stream);
+
 /* diagnostic: pure v_mfma_f32_32x32x2_f32 issue loop (blocks x 256 threads, iters x 64 MFMAs per wave);
  * out needs blocks*256 floats; random_operands != 0 feeds 32 pseudo-random operand values per lane (realistic
  * switching power).  Used only to calibrate the MFMA ceiling at the sustained clock. */

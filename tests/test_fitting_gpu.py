@@ -1,0 +1,125 @@
+"""GPU parity of the pose-refinement kernels (soft silhouette, K=1 neighbour, fitting loop) against the torch
+restatement in oracle/fitting_oracle.py (pytorch3d itself is unavailable: parity of that dependency is unpinned)."""
+import numpy as np
+import pytest
+import torch
+
+from parity_common import hip_net, setup, syn
+from oracle import fitting_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene_verts(n_frames=2):
+    sc, sd_np, sd, osc = setup(n_frames=4)
+    net = hip_net(sc, sd_np)
+    node = net.nodes["right"]
+    idx = torch.arange(n_frames, device="cuda")
+    p = node.params(idx)
+    with torch.no_grad():
+        so = node.server(torch.full((n_frames,), 1.0, device="cuda"), p["right.transl"], p["right.full_pose"],
+                         p["right.betas"])
+    verts = so["verts"].clone()
+    verts[..., :2] -= verts[..., :2].mean(dim=1, keepdim=True)  # centred on the optical axis
+    verts[..., 2] += 0.45  # in front of the camera
+    faces = torch.as_tensor(node.server.faces.astype(np.int64), device="cuda")
+    return net, verts, faces
+
+
+@pytest.mark.parametrize("sigma", [1e-4, 1e-6])
+def test_silhouette_forward(sigma):
+    from hold_amd import fitting as ft
+    net, verts, faces = _scene_verts()
+    H = W = 64
+    fx = fy = 300.0
+    cx = cy = 32.0
+    blur = np.log(1.0 / 1e-4 - 1.0) * sigma
+    vs, fs = ft.seal_mano_mesh(verts, faces, True)
+    m = ft.soft_silhouette(vs, fs, fx, fy, cx, cy, H, W, sigma, blur).cpu()
+    vo, fo_ = fo.seal_mano_mesh(verts.cpu(), faces.cpu(), True)
+    ref = fo.soft_silhouette(vo, fo_, fx, fy, cx, cy, H, W, sigma, blur)
+    assert 0.03 < float(ref.mean()) < 0.9
+    diff = (m - ref).abs()
+    if sigma >= 1e-4:
+        assert float(diff.max()) < 2e-3
+    else:  # sigma 1e-6: the 0.15-pixel edge band amplifies fp32 differences of d by 1e6
+        assert float(diff.mean()) < 2e-3 and float((diff > 0.05).float().mean()) < 0.01
+
+
+def test_silhouette_backward():
+    from hold_amd import fitting as ft
+    net, verts, faces = _scene_verts(1)
+    H = W = 48
+    fx = fy = 220.0
+    cx = cy = 24.0
+    sigma = 1e-4
+    blur = np.log(1.0 / 1e-4 - 1.0) * sigma
+    g = torch.Generator().manual_seed(0)
+    wgt = torch.rand(1, H, W, generator=g)
+    v = verts.clone().requires_grad_(True)
+    vs, fs = ft.seal_mano_mesh(v, faces, True)
+    (ft.soft_silhouette(vs, fs, fx, fy, cx, cy, H, W, sigma, blur) * wgt.cuda()).sum().backward()
+    vc = verts.cpu().clone().requires_grad_(True)
+    vo, fo_ = fo.seal_mano_mesh(vc, faces.cpu(), True)
+    (fo.soft_silhouette(vo, fo_, fx, fy, cx, cy, H, W, sigma, blur) * wgt).sum().backward()
+    rel = float((v.grad.cpu() - vc.grad).norm() / vc.grad.norm())
+    assert rel < 2e-2, rel
+
+
+def test_knn1():
+    from hold_amd import fitting as ft
+    g = torch.Generator().manual_seed(1)
+    q = torch.randn(3, 70, 3, generator=g).cuda().requires_grad_(True)
+    t = torch.randn(3, 900, 3, generator=g).cuda().requires_grad_(True)
+    d = ft.knn1_sqdist(q, t)
+    ref = ((q[:, :, None] - t[:, None]) ** 2).sum(-1).min(-1).values
+    assert float((d - ref).abs().max()) < 1e-5
+    w = torch.rand(3, 70, generator=g).cuda()
+    gq, gt = torch.autograd.grad((d * w).sum(), (q, t))
+    rq, rt = torch.autograd.grad((ref * w).sum(), (q, t))
+    assert float((gq - rq).abs().max()) < 1e-5 and float((gt - rt).abs().max()) < 1e-5
+
+
+def test_fitting_loop_reduces_loss():
+    """Model.fit-style refinement: perturb hand translation / object pose, fit against masks rendered from the truth."""
+    from hold_amd import fitting as ft
+    sc, sd_np, sd, osc = setup(n_frames=4)
+    net = hip_net(sc, sd_np)
+    B = 3
+    dev = torch.device("cuda")
+    hand, obj = net.nodes["right"], net.nodes["object"]
+    idx = torch.arange(B, device=dev)
+    hp, op = hand.params(idx), obj.params(idx)
+    params = {"scene_scale": torch.tensor([1.0], device=dev), "right.global_orient": hp["right.global_orient"].detach(),
+              "right.pose": hp["right.pose"].detach(), "right.betas": hp["right.betas"][:1].detach(),
+              "right.transl": hp["right.transl"].detach(), "object.global_orient": op["object.global_orient"].detach(),
+              "object.transl": op["object.transl"].detach()}
+    w2c = torch.eye(4, device=dev).repeat(B, 1, 1)
+    w2c[:, 2, 3] = 0.9
+    K = torch.tensor([[260.0, 0, 40.0], [0, 260.0, 40.0], [0, 0, 1]], device=dev)
+    hand_faces = torch.as_tensor(hand.server.faces.astype(np.int64), device=dev)
+    # object mesh: a small lat-long sphere (radius 0.07) replaces the synthetic point cloud
+    nlat, nlon = 12, 16
+    th = torch.linspace(0.15, np.pi - 0.15, nlat)
+    ph = torch.linspace(0, 2 * np.pi, nlon + 1)[:-1]
+    sv = torch.stack([torch.sin(th)[:, None] * torch.cos(ph)[None], torch.sin(th)[:, None] * torch.sin(ph)[None],
+                      torch.cos(th)[:, None].expand(nlat, nlon)], -1).reshape(-1, 3) * 0.07
+    obj.server.object_model.v3d_cano = sv.to(dev)
+    fl = []
+    for a in range(nlat - 1):
+        for b in range(nlon):
+            i0, i1 = a * nlon + b, a * nlon + (b + 1) % nlon
+            fl += [[i0, i1, i0 + nlon], [i1, i1 + nlon, i0 + nlon]]
+    obj_faces = torch.tensor(fl, device=dev)
+    contact_idx = torch.arange(700, 778, device=dev)
+    gt = ft.FittingModel(hand.server, obj.server, hand_faces, obj_faces, params, w2c, K, (80, 80), None, contact_idx)
+    with torch.no_grad():
+        o = gt.fwd_params()
+    targets = {"right": (o["right.mask"] > 0.5).float(), "object": (o["object.mask"] > 0.5).float()}
+    p2 = dict(params)
+    p2["right.transl"] = params["right.transl"] + torch.tensor([0.01, -0.008, 0.0], device=dev)
+    p2["object.transl"] = params["object.transl"] + torch.tensor([-0.02, 0.015, 0.0], device=dev)
+    m = ft.FittingModel(hand.server, obj.server, hand_faces, obj_faces, p2, w2c, K, (80, 80), targets, contact_idx)
+    hist = m.fit(num_iterations=40)
+    assert hist[-1] < 0.7 * hist[0], (hist[0], hist[-1])
+    assert all(np.isfinite(hist))
