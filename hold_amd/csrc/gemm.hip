@@ -386,6 +386,142 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
   }
 }
 
+// LDS-staged weight gradient: the [rows][n] / [rows][k] operand tiles are brought in with global_load_lds
+// (16 B per lane, 1 KiB per wave instruction) instead of one global_load_dword per MFMA operand -- the dword
+// version is bound by the CU's texture-address path (64 VMEM instructions per 64 MFMAs per wave).  Fragments are
+// column reads of the row-major LDS image (ds_read_b32, consecutive lanes = consecutive banks, conflict-free).
+// KT = 32-wide k tiles per wave: 2 -> block tile 128 n x 128 k (32 rows per stage), 4 -> 128 n x 256 k (16 rows).
+template <int KT>
+__global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restrict__ R, int ldr,
+                                                           const float* __restrict__ X, int ldx, int P, int N, int K,
+                                                           int splits, float* __restrict__ part,
+                                                           float* __restrict__ part_b) {
+  constexpr int BKW = 64 * KT;              // block width along k
+  constexpr int PC = (KT == 4) ? 16 : 32;   // rows (reduction index) per stage
+  constexpr int STEPS = PC / 2;
+  constexpr int RI = PC * 128 / 256;        // DMA instructions per R stage (256 floats each)
+  constexpr int XI = PC * BKW / 256;
+  __shared__ __attribute__((aligned(16))) float smem[2 * PC * (128 + BKW)];
+  float* sR = smem;
+  float* sX = smem + 2 * PC * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int hh = lane >> 5, li = lane & 31;
+  const int ntn = (N + 127) / 128, ntk = (K + BKW - 1) / BKW;
+  const int tile = blockIdx.x % (ntn * ntk), split = blockIdx.x / (ntn * ntk);
+  const int n0 = (tile / ntk) * 128, k0 = (tile % ntk) * BKW;
+  const long chunks = ((long)P + PC - 1) / PC;
+  const long cper = (chunks + splits - 1) / splits;
+  const long c_begin = (long)split * cper, c_end = min(chunks, c_begin + cper);
+
+  auto stage = [&](long c, int buf) {
+    const long p0 = c * PC;
+    if (p0 + PC <= P) {
+#pragma unroll
+      for (int j = 0; j < RI / 4; ++j) {
+        const int ins = wave * (RI / 4) + j;
+        const int row = ins * 2 + (lane >> 5);
+        int col = n0 + (lane & 31) * 4;
+        col = col <= ldr - 4 ? col : ldr - 4;  // columns >= N are never stored; keep the address inside the row
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(R + (p0 + row) * (long)ldr + col),
+                                         (__attribute__((address_space(3))) void*)(sR + buf * PC * 128 + ins * 256), 16, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < XI / 4; ++j) {
+        const int ins = wave * (XI / 4) + j;
+        const int row = (BKW == 256) ? ins : ins * 2 + (lane >> 5);
+        int col = k0 + ((BKW == 256) ? lane : (lane & 31)) * 4;
+        col = col <= ldx - 4 ? col : ldx - 4;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (p0 + row) * (long)ldx + col),
+                                         (__attribute__((address_space(3))) void*)(sX + buf * PC * BKW + ins * 256), 16, 0, 0);
+      }
+    } else {  // ragged tail: rows >= P contribute zeros
+      for (int e = tid; e < PC * (128 + BKW) / 4; e += 256) {
+        const bool isR = e < PC * 32;
+        const int ee = isR ? e : e - PC * 32;
+        const int w4 = isR ? 32 : BKW / 4;
+        const int row = ee / w4, c4 = (ee % w4) * 4;
+        const long p = p0 + row;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if (isR) {
+          int col = n0 + c4;
+          col = col <= ldr - 4 ? col : ldr - 4;
+          if (p < P) z = *reinterpret_cast<const f32x4*>(R + p * (long)ldr + col);
+          *reinterpret_cast<f32x4*>(sR + buf * PC * 128 + row * 128 + c4) = z;
+        } else {
+          int col = k0 + c4;
+          col = col <= ldx - 4 ? col : ldx - 4;
+          if (p < P) z = *reinterpret_cast<const f32x4*>(X + p * (long)ldx + col);
+          *reinterpret_cast<f32x4*>(sX + buf * PC * BKW + row * BKW + c4) = z;
+        }
+      }
+    }
+  };
+  auto stage_wait = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+
+  f32x16 acc[2][KT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < KT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float bsum[2] = {0.f, 0.f};
+  const bool do_bias = (part_b != nullptr) && (tile % ntk == 0) && (wk == 0);
+
+  if (c_begin < c_end) {
+    stage(c_begin, 0);
+    stage_wait();
+  }
+  for (long c = c_begin; c < c_end; ++c) {
+    const int buf = (int)((c - c_begin) & 1);
+    if (c + 1 < c_end) stage(c + 1, buf ^ 1);
+    const float* pr = sR + buf * PC * 128 + (hh * STEPS) * 128 + wn * 64 + li;
+    const float* px = sX + buf * PC * BKW + (hh * STEPS) * BKW + wk * (32 * KT) + li;
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      float av[2], bv[KT];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) av[a] = pr[st * 128 + a * 32];
+#pragma unroll
+      for (int b = 0; b < KT; ++b) bv[b] = px[st * BKW + b * 32];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < KT; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+      bsum[0] += av[0];
+      bsum[1] += av[1];
+    }
+    stage_wait();
+  }
+  float* out = part + (long)split * N * K;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < KT; ++b) {
+      const int k = k0 + wk * (32 * KT) + b * 32 + li;
+      if (k >= K) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (n < N) out[(long)n * K + k] = acc[a][b][r];
+      }
+    }
+  if (do_bias) {
+    const float s0 = bsum[0] + __shfl_xor(bsum[0], 32);
+    const float s1 = bsum[1] + __shfl_xor(bsum[1], 32);
+    const int na = n0 + wn * 64 + li, nb = na + 32;
+    if (hh == 0) {
+      if (na < N) part_b[(long)split * N + na] = s0;
+      if (nb < N) part_b[(long)split * N + nb] = s1;
+    }
+  }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, long NK, int K, float* __restrict__ dW,
                                     int lddw, int accumulate) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -470,9 +606,23 @@ extern "C" int hold_wgrad(const float* R, int32_t ldr, const float* X, int32_t l
   if (splits > chunks) splits = (int)(chunks > 0 ? chunks : 1);
   float* part = workspace;
   float* part_b = db ? workspace + (long)splits * N * K : nullptr;
-  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-  hipLaunchKernelGGL(wgrad_kernel, dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits, part,
-                     part_b);
+  const bool lds_ok = !(ldr & 3) && !(ldx & 3) && !((uintptr_t)R & 15) && !((uintptr_t)X & 15) && ldr >= 4 && ldx >= 4 &&
+                      !getenv("HOLD_WGRAD_DIRECT");
+  if (lds_ok && K > 128) {
+    const int tiles = ((N + 127) / 128) * ((K + 255) / 256);
+    const long ch = ((long)P + 15) / 16;
+    if (splits > ch) splits = (int)(ch > 0 ? ch : 1);
+    hipLaunchKernelGGL((wgrad_lds_kernel<4>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits,
+                       part, part_b);
+  } else if (lds_ok) {
+    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+    hipLaunchKernelGGL((wgrad_lds_kernel<2>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits,
+                       part, part_b);
+  } else {
+    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+    hipLaunchKernelGGL(wgrad_kernel, dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits, part,
+                       part_b);
+  }
   const long NK = (long)N * K;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((NK + 255) / 256)), dim3(256), 0, s, part, splits, NK, K, dW,
                      lddw, accumulate);
