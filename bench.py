@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--cpu-rays", type=int, default=16, help="cpu baseline renders cpu_rays^2 rays of the frame")
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--shape-report", default="", help="write per-(kernel,N,K) launch aggregates to this json file")
     return ap.parse_args()
 
 
@@ -78,6 +79,19 @@ def cpu_baseline(sc, sd_np, side, frame, threads=32):
     return {"value": N / min(times), "unit": "rays/s", "cores": cores, "kind": "port",
             "sample": f"{N} rays ({W}x{W} pixel grid of the same synthetic frame), fwd+loss+bwd, best of 2, "
                       f"oracle/hold_oracle.py (torch CPU restatement of the reference), {cores} threads"}
+
+
+def gemm_shapes(prof):
+    """aggregate the live launch timings by kernel and (flops per launch) bucket"""
+    out = {}
+    for e0, e1, fl, name in prof:
+        key = f"{name}:{fl:.3e}"
+        a = out.setdefault(key, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += e0.elapsed_time(e1)
+        a[2] += fl
+    return {k: {"launches": v[0], "ms": v[1], "tflops": v[2] / v[1] / 1e9} for k, v in
+            sorted(out.items(), key=lambda kv: -kv[1][1])}
 
 
 def pmc_traffic():
@@ -179,6 +193,11 @@ def main():
                 a[0] += e0.elapsed_time(e1) * 1e-3
                 a[1] += fl
                 a[2] += 1
+            if args.shape_report:
+                shp = {}
+                for e0, e1, fl, name in prof:
+                    pass
+                json.dump({k: v for k, v in gemm_shapes(prof).items()}, open(args.shape_report, "w"), indent=1)
             g = agg["gemm_nt_kernel"]
             ach = g[1] / g[0] / 1e12
             res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -28,12 +28,12 @@ constexpr int L0_CHUNKS = 5, LK_CHUNKS = 32;         // K = 40 and 256, in chunk
 constexpr int CHUNK_FLOATS = 8 * 64 * 4;             // [8 n-tiles][64 lanes][4]
 constexpr int SKIP_OUT = 217;
 
+// softplus(y, beta = 100): max(y,0) + ln(1 + e^{-|100 y|}) / 100 on the hardware exp2/log2 units.  For 100y > 20 the
+// log term is < 2.1e-11 (the reference's threshold branch returns y exactly); the absolute error of the plain
+// log2(1+e) form is <= 6e-10 -- irrelevant for these value-only (no-gradient) sampler queries.
 __device__ __forceinline__ float softplus100(float y) {
-  const float z = y * 100.0f;
-  if (z > 20.0f) return y;
-  const float e = __expf(-fabsf(z));
-  const float l = (e > 1e-3f) ? __logf(1.0f + e) : e * (1.0f - e * (0.5f - 0.33333334f * e));
-  return (fmaxf(z, 0.f) + l) * 0.01f;
+  const float e = __builtin_amdgcn_exp2f(-144.26950408889634f * fabsf(y));           // e^{-|100 y|}
+  return fmaxf(y, 0.f) + 0.0069314718056f * __builtin_amdgcn_logf(1.0f + e);         // ln2/100 * log2(1+e)
 }
 
 struct FusedArgs {
@@ -58,8 +58,8 @@ __global__ __launch_bounds__(64 * (8 / NTW), (MT == 4) ? 2 : 2) void fused_sdf_k
   float* emb = smem + PTS * ASTR;      // [PTS][40]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, li = lane & 31;
-  if (stagger && (blockIdx.x & 1))
-    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  if ((stagger & 255) && (blockIdx.x & 1))
+    for (int i = 0; i < (stagger & 255); ++i) __builtin_amdgcn_s_sleep(127);
 
   for (long blk = blockIdx.x; blk * PTS < a.P; blk += gridDim.x) {
     const long p0 = blk * PTS;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64 * (8 / NTW), (MT == 4) ? 2 : 2) void fused_sdf_k
             for (int m = 0; m < MT; ++m)
 #pragma unroll
               for (int n = 0; n < NTW; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][c], b[n][c], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[n][c], av[m][c], acc[m][n], 0, 0, 0);
         }
         if (kc + 1 < chunks) {
           f32x4 b[NTW];
@@ -136,29 +136,41 @@ __global__ __launch_bounds__(64 * (8 / NTW), (MT == 4) ? 2 : 2) void fused_sdf_k
             for (int m = 0; m < MT; ++m)
 #pragma unroll
               for (int n = 0; n < NTW; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][c], b[n][c], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[n][c], av[m][c], acc[m][n], 0, 0, 0);
         }
       }
       wl += (long)chunks * CHUNK_FLOATS;
-      __syncthreads();  // every wave has finished READING this layer's input
+      if (stagger & 1024) continue;  // timing ablation: no epilogue at all
+      if (!(stagger & 512)) __syncthreads();  // every wave has finished READING this layer's input
       // ---- epilogue: bias + softplus, written back in place as the next layer's input ----
+      // D[i = feature][j = point]: lane (hh, li) holds point m*32+li and, per register group g = r>>2, the four
+      // consecutive features 8g + 4hh .. +3 of its n-tile -> one ds_write_b128 per group (conflict-free, stride 260)
 #pragma unroll
       for (int n = 0; n < NTW; ++n) {
-        const int n_own = (wave * NTW + n) * 32 + li;
-        const float bias = a.bias[layer * 256 + n_own];
-        const bool skip_col = (layer == 3) && (n_own >= SKIP_OUT);  // columns 217.. of layer 4's input = embedding
+        const int nb = (wave * NTW + n) * 32 + 4 * hh;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int g = 0; g < 4; ++g) {
+          const int n4 = nb + 8 * g;
+          const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + layer * 256 + n4);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int p = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            float v;
-            if (skip_col) v = emb[p * ESTR + (n_own - SKIP_OUT)];
-            else v = softplus100(acc[m][n][r] + bias);
-            act[p * ASTR + n_own] = v;
+          for (int m = 0; m < MT; ++m) {
+            const int p = m * 32 + li;
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float y = acc[m][n][4 * g + c] + bias[c];
+              v[c] = (stagger & 256) ? y * 0.01f : softplus100(y);
+            }
+            if (layer == 3 && n4 + 3 >= SKIP_OUT) {  // columns 217.. of layer 4's input = embedding
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                if (n4 + c >= SKIP_OUT) v[c] = emb[p * ESTR + (n4 + c - SKIP_OUT)];
+            }
+            *reinterpret_cast<f32x4*>(act + p * ASTR + n4) = v;
           }
+        }
       }
-      __syncthreads();
+      if (!(stagger & 512)) __syncthreads();
     }
     // ---- sdf = w8 . h7 + b8 : 4 threads per point, 64-wide partial dots ----
     {
@@ -216,7 +228,7 @@ extern "C" int hold_fused_sdf(const float* xc, int32_t ldx, int64_t P, const flo
   if (variant == 128) {
     const long blocks = (P + 127) / 128;
     hipLaunchKernelGGL((fused_sdf_kernel<4, 1>), dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(512), sh128,
-                       (hipStream_t)st, a, 0);
+                       (hipStream_t)st, a, getenv("HOLD_FUSED_DEBUG") ? atoi(getenv("HOLD_FUSED_DEBUG")) : 0);
   } else {
     const long blocks = (P + 63) / 64;
     const long res = 2L * n_cu;
