@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--res", type=int, default=512)
-    ap.add_argument("--chunk", type=int, default=8192, help="rays per microbatch")
+    ap.add_argument("--chunk", type=int, default=16384, help="rays per microbatch (≈60 GB of saved activations per fg node)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=16, help="cpu baseline renders cpu_rays^2 rays of the frame")
     ap.add_argument("--cpu-threads", type=int, default=32)

@@ -12,7 +12,9 @@ f = glob.glob("/tmp/pmc_$c/*counter_collection.csv")
 agg = collections.defaultdict(lambda: [0, 0.0])
 if f:
     for r in csv.DictReader(open(f[0])):
-        k = r["Kernel_Name"].split("(")[0][:60]
+        import re
+        m = re.search(r"(?:anonymous namespace\)::)?(\w+)(?:<|\()", r["Kernel_Name"].replace("void ", ""))
+        k = m.group(1) if m else r["Kernel_Name"][:40]
         agg[k][0] += 1
         agg[k][1] += float(r["Counter_Value"])
 out = {k: {"launches": v[0], "sum": v[1], "avg_per_launch": v[1] / v[0]} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]}
