@@ -110,8 +110,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
 
-    if world > 1:
+    force_dist = os.environ.get("HOLD_FORCE_DIST") == "1"  # exercise the RCCL path with a single rank (testing)
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
@@ -150,7 +152,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     if not args.no_profile:
@@ -161,10 +163,10 @@ def main():
         loss, n = step(args.warmup + i)
         rays += n
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -217,7 +219,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(sc, sd_np, args.cpu_rays, frame, args.cpu_threads)
             res["config"]["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
         print(json.dumps(res))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

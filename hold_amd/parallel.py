@@ -15,7 +15,7 @@ def grad_params(module):
 def allreduce_grads(params, group=None, average=True):
     """sum (or mean) every parameter's .grad across ranks through one contiguous buffer.  Parameters whose
     grad is None on this rank (e.g. pose rows of frames owned by other ranks) contribute zeros."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized():
         return 0
     if not params:
         return 0
