@@ -222,6 +222,87 @@ class NodeField:
         return dict(sdf=sdf, rgb=rgb, normal=rin[:, RIN_N:RIN_N + 3], xc=xc, feat=rin[:, RIN_FEAT:RIN_FEAT + FEAT],
                     grad=g)
 
+    # ------------------------------------------------------------------ eikonal samples (a13)
+    def grad_points_forward(self, pk, xc, P, barf_w):
+        """d sdf / d x at free canonical points (compute_gradient_samples, volsdf_utils.py:19-48): trunk forward +
+        reverse sweep only (no deformer, no colour net).  Keeps h / t / ge for grad_points_backward."""
+        sp, pool = self.spec, self.pool
+        in0, h = self._trunk(pk, xc, P, barf_w, keep_all=True)
+        WT = pk["WT"]
+        t = [pool.get(f"t{l}", P, 256) for l in range(8)]
+        ge = pool.get("ge", P, sp.K0)
+        K.seed_dsp(h[7], pk["w8_sdf"], 256, P, t[7])
+        for l in range(7, 0, -1):
+            if l == 4:
+                G.gemm_nt(t[4], WT[4], t[3][:, :sp.skip_out], epi=G.EPI_MUL_DSP, aux1=h[3], N=256,
+                          n_split=sp.skip_out, out_raw=ge)
+            elif l == 3:
+                G.gemm_nt(t[3], WT[3], t[2], epi=G.EPI_MUL_DSP, aux1=h[2], K=sp.skip_pad)
+            else:
+                G.gemm_nt(t[l], WT[l], t[l - 1], epi=G.EPI_MUL_DSP, aux1=h[l - 1])
+        G.gemm_nt(t[0], WT[0], ge, N=sp.K0, accumulate=True)
+        g = pool.get("g", P, 4)
+        K.embed_bwd(xc, sp.L, P, ge, g, barf_w=barf_w)
+        self.saved = dict(P=P, xc=xc, in0=in0, h=h, t=t, ge=ge, g=g, barf_w=barf_w, pk=pk)
+        return g
+
+    def grad_points_backward(self, gbar):
+        """gradient of a loss on g = d sdf/d x w.r.t. the effective implicit weights (second-order terms only:
+        the points themselves and sdf / features carry no upstream gradient)."""
+        sp, pool, sv = self.spec, self.pool, self.saved
+        P, pk, h, t, xc = sv["P"], sv["pk"], sv["h"], sv["t"], sv["xc"]
+        dev = self.device
+        W, WT = pk["W"], pk["WT"]
+        dW = [torch.zeros_like(m) for m in W]
+        dWb = [torch.zeros_like(b) for b in pk["b"]]
+        gb = pool.get("gbar", P, 4)
+        K.copy_cols(gbar.contiguous(), gb, 3, P)
+        gebar = pool.get("gebar", P, sp.K0)
+        K.embed_bwd2(xc, sp.L, P, sv["ge"], gb, gebar, xbar=None, barf_w=sv["barf_w"])
+        a2 = [pool.get(f"a2_{l}", P, 256) for l in range(8)]
+        vb = [pool.get(f"vb{i}", P, 256) for i in range(2)]
+        G.wgrad(t[0], gebar, dW[0], None, K=sp.K0, accumulate=True)
+        G.gemm_nt(gebar, W[0], vb[0], epi=G.EPI_DBWD, aux1=h[0], aux2=t[0], out2=a2[0], K=sp.K0)
+        cur = vb[0]
+        for l in range(1, 8):
+            nxt = vb[1] if cur is vb[0] else vb[0]
+            if l == 3:
+                G.wgrad(t[3], cur, dW[3], None, N=sp.skip_out, accumulate=True)
+                G.gemm_nt(cur, W[3], nxt[:, :sp.skip_out], epi=G.EPI_DBWD, aux1=h[3], aux2=t[3], out2=a2[3],
+                          N=sp.skip_out)
+                K.copy_cols(gebar, nxt[:, sp.skip_out:], sp.E, P)
+            else:
+                G.wgrad(t[l], cur, dW[l], None, accumulate=True)
+                G.gemm_nt(cur, W[l], nxt, epi=G.EPI_DBWD, aux1=h[l], aux2=t[l], out2=a2[l])
+            cur = nxt
+        d_w8sdf = torch.zeros(256, device=dev)
+        K.colsum(cur, 256, P, d_w8sdf)
+        # first-order sweep driven only by the second-order terms a2_l (out_bar = 0  =>  r_7 = a2_7)
+        rb_ = [pool.get(f"rb{i}", P, 256) for i in range(2)]
+        cur = a2[7]
+        for l in range(7, 0, -1):
+            nxt = rb_[1] if cur is rb_[0] else rb_[0]
+            if l == 4:
+                G.wgrad(cur, h[3], dW[4], dWb[4], accumulate=True)
+                G.gemm_nt(cur, WT[4], nxt[:, :sp.skip_out], epi=G.EPI_MUL_DSP, aux1=h[3], aux2=a2[3], N=sp.skip_out)
+                nxt[:, sp.skip_out:sp.skip_pad].zero_()
+            elif l == 3:
+                G.wgrad(cur, h[2], dW[3], dWb[3], N=sp.skip_out, accumulate=True)
+                G.gemm_nt(cur, WT[3], nxt, epi=G.EPI_MUL_DSP, aux1=h[2], aux2=a2[2], K=sp.skip_pad)
+            else:
+                G.wgrad(cur, h[l - 1], dW[l], dWb[l], accumulate=True)
+                G.gemm_nt(cur, WT[l], nxt, epi=G.EPI_MUL_DSP, aux1=h[l - 1], aux2=a2[l - 1])
+            cur = nxt
+        G.wgrad(cur, sv["in0"], dW[0], dWb[0], K=sp.K0, accumulate=True)
+        d0 = torch.zeros(256, pk["iw0_cols"], device=dev)
+        d0[:, :sp.E] = dW[0][:, :sp.E]
+        g_iw = [d0, dW[1], dW[2], dW[3], dW[4] / math.sqrt(2), dW[5], dW[6], dW[7]]
+        d8 = torch.zeros(257, 256, device=dev)
+        d8[0] = d_w8sdf
+        g_iw.append(d8)
+        g_ib = dWb[:8] + [torch.zeros(257, device=dev)]
+        return g_iw, g_ib
+
     # ------------------------------------------------------------------ backward
     def backward(self, d_sdf, d_rgb, d_normal, n_frames):
         """d_sdf [P] / [P,1], d_rgb [P,3], d_normal [P,3] (may be None) -> dict of gradients:

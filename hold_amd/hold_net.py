@@ -217,6 +217,26 @@ class _FieldFn(torch.autograd.Function):
                 *g["iw"], *g["ib"], *g["rw"], *g["rb"])
 
 
+class _EikonalFn(torch.autograd.Function):
+    """g = d sdf / d x at free canonical points with a differentiable (second-order) backward to the weights:
+    compute_gradient_samples + compute_gradient(create_graph=True), code/src/engine/volsdf_utils.py:6-48."""
+
+    @staticmethod
+    def forward(ctx, node, xc, barf_w, *weights):
+        iw, ib = weights[0:9], weights[9:18]
+        rw, rb = weights[18:23], weights[23:28]
+        pk = pack_weights(node.spec, iw, ib, rw, rb, need_bwd=True)
+        fld = node._eik_field(xc.device)
+        g = fld.grad_points_forward(pk, xc, xc.shape[0], barf_w)
+        ctx.node = node
+        return g[:, :3].clone()
+
+    @staticmethod
+    def backward(ctx, gbar):
+        g_iw, g_ib = ctx.node._eik_field(gbar.device).grad_points_backward(gbar.contiguous())
+        return (None, None, None, *g_iw, *g_ib, *([None] * 10))
+
+
 class _CompositeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, S, n_rays, class_ids, want_w, *args):
@@ -300,6 +320,22 @@ class Node(nn.Module):
     def step_embedding(self):
         self.implicit_network.embedder_obj.step()
 
+    def _eik_field(self, device):
+        f = getattr(self, "_eik", None)
+        if f is None or f.device != device:
+            f = self._eik = NodeField(self.spec, device)
+        return f
+
+    def eikonal_grad(self, points):
+        """grad_theta of the reference (volsdf_utils.compute_gradient_samples): d sdf / d x at canonical sample
+        points [B, n, 3] -> [B, n, 3], differentiable w.r.t. the implicit network's parameters."""
+        B, n, _ = points.shape
+        xc = torch.zeros(B * n, 4, device=points.device)
+        xc[:, :3] = points.reshape(-1, 3)
+        barf_w = self.implicit_network.embedder_obj.weights(points.device)
+        g = _EikonalFn.apply(self, xc, barf_w, *self._weights())
+        return g.view(B, n, 3)
+
     def _weights(self):
         iw, ib = self.implicit_network.effective()
         rw, rb = self.rendering_network.effective()
@@ -351,6 +387,17 @@ class MANONode(Node):
         self.params = GenericParams(n_frames, {"betas": 10, "global_orient": 3, "transl": 3, "pose": 45}, node_id)
         # canonical vertices / skinning table of the KNN deformer (mano/deformer.py:20-32)
         self.register_buffer("cano_verts", self.server.verts_c[0].clone(), persistent=False)
+
+    def sample_eikonal_points(self, batch_size, num=256, local_sigma=0.008, global_ratio=0.20):
+        """PointInSpace(global_sigma_xyz=[0.15, 0.06, 0.12]).get_points around random canonical MANO vertices
+        (hold_utils.py:22-58,230-240; volsdf_utils.py:28-35): num local + num*ratio global samples."""
+        dev = self.cano_verts.device
+        idx = torch.randperm(self.cano_verts.shape[0])[:num].to(dev)
+        v = self.cano_verts[idx][None].expand(batch_size, -1, -1)
+        local = v + torch.randn_like(v) * local_sigma
+        gs = torch.tensor([0.15, 0.06, 0.12], device=dev)
+        glob = torch.rand(batch_size, int(num * global_ratio), 3, device=dev) * (gs * 2) - gs
+        return torch.cat([local, glob], dim=1)
 
     def serve(self, input):
         nid = self.node_id

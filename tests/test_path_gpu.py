@@ -291,3 +291,38 @@ def test_c5_sampler_config_128_samples():
     assert out["right.z_vals"].shape[1] == 162 and out["fg_weights"].shape[1] == 2 * 162 - 3
     assert float((out["fg_weights"].sum(1) + out["bg_weights"] - 1).abs().max()) < 1e-4
     assert torch.all(out["object.z_vals"][:, 1:] >= out["object.z_vals"][:, :-1])
+
+
+def test_eikonal_gradient_samples_second_order(ctx):
+    """grad_theta = d sdf/d x at free canonical points and the gradient of the eikonal loss w.r.t. the weights
+    (double backward) against torch autograd on the oracle (loss_terms.get_eikonal_loss)."""
+    sc, sd, osc = ctx["sc"], ctx["sd"], ctx["osc"]
+    net = hip_net(sc, ctx["sd_np"], train=True)
+    for nid in ("right", "object"):
+        node = net.nodes[nid]
+        g = torch.Generator().manual_seed(7)
+        pts = (torch.rand(2, 150, 3, generator=g) * 0.5 - 0.25)
+        sdg = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+        x = pts.reshape(-1, 3).clone().requires_grad_(True)
+        cond = None if nid == "object" else torch.zeros(x.shape[0], 45)
+        bw = ho.barf_weights(4000, 6, 3) if nid == "object" else None
+        sdf = ho.implicit_net(sdg, f"nodes.{nid}.implicit_network", x, cond, 6, bw, zero_cond=nid != "object")[:, :1]
+        go = torch.autograd.grad(sdf, x, torch.ones_like(sdf), create_graph=True)[0]
+        lo = ((go.norm(2, dim=-1) - 1) ** 2).mean()
+        lo.backward()
+        net.zero_grad()
+        gh = node.eikonal_grad(pts.cuda())
+        assert rel_err(gh.reshape(-1, 3), go) < 1e-4
+        lh = ((gh.norm(2, dim=-1) - 1) ** 2).mean()
+        lh.backward()
+        for l in range(9):
+            for part in ("weight_v", "weight_g", "bias"):
+                name = f"nodes.{nid}.implicit_network.lin{l}.{part}"
+                og = sdg[name].grad
+                hg = dict(net.named_parameters())[name].grad
+                if og is None or float(og.norm()) < 1e-12:
+                    continue
+                rel = float((hg.cpu() - og).norm() / og.norm())
+                assert rel < 1e-3, (name, rel)
+    p = net.nodes["right"].sample_eikonal_points(2)
+    assert p.shape == (2, 256 + 51, 3)
