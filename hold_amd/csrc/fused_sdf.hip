@@ -58,7 +58,9 @@ __global__ __launch_bounds__(64 * (8 / NTW), (MT == 4) ? 2 : 2) void fused_sdf_k
   float* emb = smem + PTS * ASTR;      // [PTS][40]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, li = lane & 31;
-  if ((stagger & 255) && (blockIdx.x & 1))
+  // co-resident blocks (the second half of a 2-blocks-per-CU grid) start ~half a layer late so that one block's
+  // epilogue overlaps the other block's MFMA phase
+  if ((stagger & 255) && ((stagger & 2048) ? (blockIdx.x & 1) : (blockIdx.x >= (gridDim.x >> 1))))
     for (int i = 0; i < (stagger & 255); ++i) __builtin_amdgcn_s_sleep(127);
 
   for (long blk = blockIdx.x; blk * PTS < a.P; blk += gridDim.x) {
@@ -191,6 +193,157 @@ __global__ __launch_bounds__(64 * (8 / NTW), (MT == 4) ? 2 : 2) void fused_sdf_k
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Software-pipelined variant (the default).  The 128 points of a workgroup are two halves H0 / H1 of 64 points that run
+// half a layer apart: while the MFMAs of (layer L, half H) stream through the matrix pipe, the same wave's VALU does
+// the bias + softplus + LDS write-back of the PREVIOUS step's accumulators (the other half), so the matrix pipe no
+// longer idles during the per-layer epilogue (the un-pipelined kernel above spends ~14 % of its time there):
+//
+//   step 0: MFMA(0,H0)              step 2L  : MFMA(L,H0) | EPI(L-1,H1)         last: EPI(7,H1)
+//   step 1: MFMA(0,H1) | EPI(0,H0)  step 2L+1: MFMA(L,H1) | EPI(L,H0)
+//
+// One barrier per step.  Hazards: EPI(L,H) overwrites rows H in place, whose last readers (MFMA(L,H)) ran in the
+// previous step; MFMA(L+1,H) reads what EPI(L,H) wrote in the previous step; the two halves own disjoint LDS rows.
+// The weight stream is continuous across steps (chunk c+2 of this step, or chunk 0/1 of the next, is always in flight).
+template <int CHUNKS, int PH, bool EPI>
+__device__ __forceinline__ void pipe_step(const f32x4* __restrict__ wp, const f32x4* __restrict__ nxt,
+                                          const float* __restrict__ arow, f32x16 (&accC)[2], f32x4 (&bq)[2],
+                                          const f32x16 (&accP)[2], float* __restrict__ erow,
+                                          const float* __restrict__ emb_row, const float* __restrict__ bias_ptr,
+                                          int nb, bool skip) {
+  f32x4 bias[4];
+  if (EPI) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const f32x4*>(bias_ptr + 8 * g);
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accC[m][r] = 0.f;
+#pragma unroll
+  for (int c = 0; c < CHUNKS; ++c) {
+    const f32x4 b = bq[(c + PH) & 1];
+    if (c + 2 < CHUNKS) {
+      bq[(c + PH) & 1] = wp[(c + 2) * 512];
+    } else if (nxt) {
+      bq[(c + PH) & 1] = nxt[(c + 2 - CHUNKS) * 512];
+    }
+    f32x4 av[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) av[m] = *reinterpret_cast<const f32x4*>(arow + m * 32 * ASTR + c * 8);
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) accC[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[cc], av[m][cc], accC[m], 0, 0, 0);
+    if (EPI) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if ((u * CHUNKS) / 8 != c) continue;
+        const int m = u >> 2, g = u & 3, n4 = nb + 8 * g;
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = softplus100(accP[m][4 * g + k] + bias[g][k]);
+        if (skip && n4 + 3 >= SKIP_OUT) {  // columns 217.. of layer 4's input = embedding
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (n4 + k >= SKIP_OUT) v[k] = emb_row[m * 32 * ESTR + (n4 + k - SKIP_OUT)];
+        }
+        *reinterpret_cast<f32x4*>(erow + m * 32 * ASTR + n4) = v;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void fused_sdf_pipe_kernel(FusedArgs a) {
+  constexpr int PTS = 128, NTHR = 512;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* act = smem;                   // [128][260]
+  float* emb = smem + PTS * ASTR;      // [128][40]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, li = lane & 31;
+  const int nb = wave * 32 + 4 * hh;
+  const f32x4* w0 = reinterpret_cast<const f32x4*>(a.wpack) + wave * 64 + lane;
+  constexpr long LAYER0 = (long)L0_CHUNKS * 512, LAYERK = (long)LK_CHUNKS * 512;  // in f32x4 units
+
+  for (long blk = blockIdx.x; blk * PTS < a.P; blk += gridDim.x) {
+    const long p0 = blk * PTS;
+    f32x4 bq[2];
+    bq[0] = w0[0];
+    bq[1] = w0[512];
+    for (int e = tid; e < PTS * ESTR; e += NTHR) {
+      const int p = e / ESTR, j = e % ESTR;
+      float v = 0.f;
+      const long gp = p0 + p;
+      if (j < NE && gp < a.P) {
+        if (j < 3) {
+          v = a.xc[gp * a.ldx + j];
+        } else {
+          const int q = (j - 3) / 3, dim = (j - 3) % 3, k = q >> 1;
+          const float arg = a.xc[gp * a.ldx + dim] * (float)(1 << k);
+          v = (q & 1) ? cosf(arg) : sinf(arg);
+        }
+        if (a.barf) v *= a.barf[j];
+      }
+      emb[p * ESTR + j] = v;
+      act[p * ASTR + j] = v;
+    }
+    __syncthreads();
+
+    float* row0 = act + li * ASTR;                // half H0: points li, li + 32
+    float* row1 = act + (64 + li) * ASTR;         // half H1: points 64 + li, 96 + li
+    const float* emb0 = emb + li * ESTR;
+    const float* emb1 = emb + (64 + li) * ESTR;
+    f32x16 accA[2], accB[2];
+    // layer 0 (5 chunks, odd: the b-register parity flips after each of its two steps)
+    pipe_step<L0_CHUNKS, 0, false>(w0, w0, row0 + hh * 4, accA, bq, accB, nullptr, nullptr, nullptr, nb, false);
+    __syncthreads();
+    pipe_step<L0_CHUNKS, 1, true>(w0, w0 + LAYER0, row1 + hh * 4, accB, bq, accA, row0, emb0, a.bias + nb, nb, false);
+    __syncthreads();
+    const f32x4* wl = w0 + LAYER0;
+    for (int layer = 1; layer < 8; ++layer) {
+      // MFMA(layer, H0) | EPI(layer - 1, H1)
+      pipe_step<LK_CHUNKS, 0, true>(wl, wl, row0 + hh * 4, accA, bq, accB, row1, emb1,
+                                    a.bias + (layer - 1) * 256 + nb, nb, layer - 1 == 3);
+      __syncthreads();
+      // MFMA(layer, H1) | EPI(layer, H0)
+      pipe_step<LK_CHUNKS, 0, true>(wl, layer < 7 ? wl + LAYERK : nullptr, row1 + hh * 4, accB, bq, accA, row0, emb0,
+                                    a.bias + layer * 256 + nb, nb, layer == 3);
+      __syncthreads();
+      wl += LAYERK;
+    }
+    // EPI(7, H1)
+    {
+      const float* bp = a.bias + 7 * 256 + nb;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int m = u >> 2, g = u & 3, n4 = nb + 8 * g;
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(bp + 8 * g);
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = softplus100(accB[m][4 * g + k] + bias[k]);
+        *reinterpret_cast<f32x4*>(row1 + m * 32 * ASTR + n4) = v;
+      }
+    }
+    __syncthreads();
+    // ---- sdf = w8 . h7 + b8 : 4 threads per point, 64-wide partial dots ----
+    {
+      const int p = tid >> 2, q = tid & 3;
+      const f32x4* hrow = reinterpret_cast<const f32x4*>(act + p * ASTR + q * 64);
+      const f32x4* wrow = reinterpret_cast<const f32x4*>(a.w8 + q * 64);
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const f32x4 h = hrow[i], w = wrow[i];
+        s += h[0] * w[0] + h[1] * w[1] + h[2] * w[2] + h[3] * w[3];
+      }
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      if (q == 0 && p0 + p < a.P) a.sdf[(p0 + p) * a.lds] = s + a.b8;
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" int64_t hold_fused_sdf_pack_floats(void) {
@@ -212,7 +365,7 @@ extern "C" int hold_fused_sdf(const float* xc, int32_t ldx, int64_t P, const flo
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return HOLD_E_LAUNCH;
     n_cu = prop.multiProcessorCount;
     const char* v = getenv("HOLD_FUSED_VARIANT");
-    variant = v ? atoi(v) : 128;  // 128-point blocks measured faster than 2 x 64 (99.5 vs 94.4 TFLOP/s)
+    variant = v ? atoi(v) : 129;  // 129: software-pipelined 128-point blocks (default); 128: un-pipelined; 64: 2 x 64
   }
   const size_t sh128 = (size_t)(128 * ASTR + 128 * ESTR) * sizeof(float);  // 153 600 B, one block per CU
   const size_t sh64 = (size_t)(64 * ASTR + 64 * ESTR) * sizeof(float);     //  76 800 B, two blocks per CU
@@ -222,10 +375,17 @@ extern "C" int hold_fused_sdf(const float* xc, int32_t ldx, int64_t P, const flo
         hipFuncSetAttribute((const void*)fused_sdf_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)sh64) != hipSuccess)
       return HOLD_E_LAUNCH;
+    if (hipFuncSetAttribute((const void*)fused_sdf_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sh128) != hipSuccess)
+      return HOLD_E_LAUNCH;
     attr_set = true;
   }
   FusedArgs a = {xc, ldx, (long)P, wpack, bias, w8, b8, barf_w, sdf, ld_sdf};
-  if (variant == 128) {
+  if (variant == 129) {
+    const long blocks = (P + 127) / 128;
+    hipLaunchKernelGGL(fused_sdf_pipe_kernel, dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(512), sh128,
+                       (hipStream_t)st, a);
+  } else if (variant == 128) {
     const long blocks = (P + 127) / 128;
     hipLaunchKernelGGL((fused_sdf_kernel<4, 1>), dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(512), sh128,
                        (hipStream_t)st, a, getenv("HOLD_FUSED_DEBUG") ? atoi(getenv("HOLD_FUSED_DEBUG")) : 0);
@@ -233,7 +393,8 @@ extern "C" int hold_fused_sdf(const float* xc, int32_t ldx, int64_t P, const flo
     const long blocks = (P + 63) / 64;
     const long res = 2L * n_cu;
     hipLaunchKernelGGL((fused_sdf_kernel<2, 2>), dim3((unsigned)(blocks < res ? blocks : res)), dim3(256), sh64,
-                       (hipStream_t)st, a, blocks >= 4 * res ? 3 : 0);
+                       (hipStream_t)st, a,
+                       getenv("HOLD_FUSED_STAGGER") ? atoi(getenv("HOLD_FUSED_STAGGER")) : (blocks >= 4 * res ? 3 : 0));
   }
   return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
 }
