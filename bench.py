@@ -9,8 +9,9 @@ all-reduce.  Inputs (rays, poses, weights, gt) are resident in HBM before the ti
     python bench.py --gpus 1 --steps 2 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (dominant kernel =
-gemm_nt_kernel, fp32 MFMA, measured live with events on the launch stream over the timed region) and
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (the MFMA kernel with
+the largest share of the timed region -- chain / fused_sdf / gemm_nt / wgrad, all fp32 MFMA -- measured live with
+events on the launch stream; every kernel's figures under roofline.kernels) and
 `cpu_baseline` (the CPU oracle restatement of the reference timed on this box's host cores).
 """
 import argparse
@@ -97,13 +98,15 @@ def gemm_shapes(prof):
             sorted(out.items(), key=lambda kv: -kv[1][1])}
 
 
-def pmc_traffic():
-    """HBM bytes per gemm_nt launch from the separate rocprofv3 --pmc passes of this same command
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the separate rocprofv3 --pmc passes of this same command
     (scripts/pmc.sh -> profiles/r01_pmc_traffic.json, FETCH_SIZE doubled per the gfx950 calibration)."""
     f = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if not os.path.exists(f):
         return None
-    return json.load(open(f)).get("hbm_bytes_per_launch")
+    d = json.load(open(f))
+    k = d.get("kernels", {}).get(kernel)
+    return k.get("hbm_bytes_per_launch") if k else None
 
 
 def main():
@@ -213,21 +216,24 @@ def main():
                 for e0, e1, fl, name in prof:
                     pass
                 json.dump({k: v for k, v in gemm_shapes(prof).items()}, open(args.shape_report, "w"), indent=1)
-            g = agg["gemm_nt_kernel"]
-            ach = g[1] / g[0] / 1e12
-            res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
-                               "kernel": "gemm_nt_kernel (v_mfma_f32_32x32x2_f32)", "launches": g[2],
-                               "avg_launch_ms": g[0] / g[2] * 1e3, "time_share": g[0] / dt,
-                               "flop_per_launch_avg": g[1] / g[2],
-                               "traffic_note": "bytes/launch from separate --pmc passes (profiles/r01_pmc_traffic.json)"}
-            if "fused_sdf_kernel" in agg:
-                f_ = agg["fused_sdf_kernel"]
-                res["roofline"]["fused_sdf"] = {"achieved": f_[1] / f_[0] / 1e12, "launches": f_[2],
-                                                "time_share": f_[0] / dt}
-            if "wgrad_kernel" in agg:
-                w = agg["wgrad_kernel"]
-                res["roofline"]["wgrad"] = {"achieved": w[1] / w[0] / 1e12, "launches": w[2], "time_share": w[0] / dt}
+            labels = {"gemm_nt_kernel": "gemm_nt_kernel (one layer per launch, v_mfma_f32_32x32x2_f32)",
+                      "chain_kernel": "chain_kernel (7-8 trunk layers per launch, LDS-resident, v_mfma_f32_32x32x2_f32)",
+                      "fused_sdf_kernel": "fused_sdf_pipe_kernel (sampler SDF queries, v_mfma_f32_32x32x2_f32)",
+                      "wgrad_kernel": "wgrad_lds_kernel (weight gradients, v_mfma_f32_32x32x2_f32)"}
+            ent = {}
+            for name, (t_, fl_, n_) in agg.items():
+                ent[name] = {"achieved": fl_ / t_ / 1e12, "frac": fl_ / t_ / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                             "launches": n_, "avg_launch_ms": t_ / n_ * 1e3, "time_share": t_ / dt,
+                             "flop_per_launch_avg": fl_ / n_}
+            dom = max(ent, key=lambda k: ent[k]["time_share"])
+            res["roofline"] = {"bound": "mfma", "achieved": ent[dom]["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ent[dom]["frac"], "traffic": pmc_traffic(dom),
+                               "kernel": labels.get(dom, dom), "launches": ent[dom]["launches"],
+                               "avg_launch_ms": ent[dom]["avg_launch_ms"], "time_share": ent[dom]["time_share"],
+                               "flop_per_launch_avg": ent[dom]["flop_per_launch_avg"],
+                               "traffic_note": "HBM bytes/launch of this kernel from separate --pmc passes "
+                                               "(profiles/r01_pmc_traffic.json)",
+                               "kernels": ent}
         if not args.no_cpu_baseline and world == 1 and args.mode == "train" and not args.two_hands:
             res["cpu_baseline"] = cpu_baseline(sc, sd_np, args.cpu_rays, frame, args.cpu_threads)
             res["config"]["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]

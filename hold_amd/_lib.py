@@ -35,6 +35,18 @@ class GemmDesc(C.Structure):
     ]
 
 
+class ChainDesc(C.Structure):
+    _fields_ = [
+        ("P", C.c_int64),
+        ("mode", C.c_int32), ("n_layers", C.c_int32), ("first_chunks", C.c_int32), ("skip_layer", C.c_int32),
+        ("in_", C.c_void_p), ("ld_in", C.c_int32),
+        ("side", C.c_void_p), ("ld_side", C.c_int32),
+        ("wpack", C.c_void_p), ("ld", C.c_int32),
+        ("bias", C.c_void_p * 8), ("aux1", C.c_void_p * 8), ("aux2", C.c_void_p * 8),
+        ("out", C.c_void_p * 8), ("out2", C.c_void_p * 8),
+    ]
+
+
 _lib = None
 
 
@@ -104,6 +116,7 @@ SIGNATURES = {
     "hold_knn1_bwd": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P],
     "hold_diag_mfma_lds": [_P, _P, _I, _I, _I, _P],
     "hold_fused_sdf": [_P, _I, _L, _P, _P, _P, _F, _P, _P, _I, _P],
+    "hold_chain": [C.POINTER(ChainDesc), _P],
     "hold_mano_lbs_fwd": [C.POINTER(ManoModel), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "hold_mano_lbs_bwd": [C.POINTER(ManoModel), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
 }
@@ -114,6 +127,8 @@ def _declare(L):
     L.hold_wgrad_workspace_floats.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     L.hold_wgrad_workspace_floats.restype = C.c_int64
     L.hold_fused_sdf_pack_floats.restype = C.c_int64
+    L.hold_chain_pack_floats.argtypes = [C.c_int32, C.c_int32]
+    L.hold_chain_pack_floats.restype = C.c_int64
     L.hold_silhouette_workspace_floats.argtypes = [C.c_int32, C.c_int32]
     L.hold_silhouette_workspace_floats.restype = C.c_int64
     for name, args in SIGNATURES.items():

@@ -220,17 +220,26 @@ __device__ __forceinline__ void pipe_step(const f32x4* __restrict__ wp, const f3
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) accC[m][r] = 0.f;
+  f32x4 avn[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) avn[m] = *reinterpret_cast<const f32x4*>(arow + m * 32 * ASTR);
 #pragma unroll
   for (int c = 0; c < CHUNKS; ++c) {
+    // ---- issue: next chunk's activations, the weights two chunks ahead (pinned here: the scheduler would otherwise sink
+    // them next to their uses and expose the LDS / L2 latency) ----
     const f32x4 b = bq[(c + PH) & 1];
+    f32x4 av[2] = {avn[0], avn[1]};
+    if (c + 1 < CHUNKS) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) avn[m] = *reinterpret_cast<const f32x4*>(arow + m * 32 * ASTR + (c + 1) * 8);
+    }
     if (c + 2 < CHUNKS) {
       bq[(c + PH) & 1] = wp[(c + 2) * 512];
     } else if (nxt) {
       bq[(c + PH) & 1] = nxt[(c + 2 - CHUNKS) * 512];
     }
-    f32x4 av[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) av[m] = *reinterpret_cast<const f32x4*>(arow + m * 32 * ASTR + c * 8);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- compute ----
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
@@ -251,6 +260,7 @@ __device__ __forceinline__ void pipe_step(const f32x4* __restrict__ wp, const f3
         *reinterpret_cast<f32x4*>(erow + m * 32 * ASTR + n4) = v;
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 

@@ -24,6 +24,8 @@ from . import kernels as K
 
 FEAT = 256
 FUSED_SDF = os.environ.get("HOLD_FUSED_SDF", "1") != "0"  # sampler queries through the fused LDS-resident kernel
+# training-path sweeps as LDS-resident layer chains (hold_chain) instead of one hold_gemm_nt per layer
+USE_CHAIN = os.environ.get("HOLD_CHAIN", "1") != "0"
 RIN_X, RIN_N, RIN_POSE, RIN_FEAT = 0, 3, 6, 14
 
 
@@ -106,6 +108,13 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
     for l in range(8):
         bias8[l, :pk["b"][l].shape[0]] = pk["b"][l]
     pk["fused"] = (torch.cat(parts).contiguous(), bias8.contiguous())
+    # descending sweeps (hold_chain DSP): layer j contracts over the outputs of trunk layer l = 7 - j, M_j = W_l^T
+    parts = []
+    for l in range(7, 0, -1):
+        m = torch.zeros(256, 256, device=dev)
+        m[:W[l].shape[1], :W[l].shape[0]] = W[l].t()
+        parts.append(m.reshape(8, 32, 32, 2, 4).permute(2, 0, 3, 1, 4).reshape(-1))
+    pk["chain_bwd"] = torch.cat(parts).contiguous()
     r0 = torch.zeros(256, spec.Kr, device=dev)
     r0[:, :spec.rin_dim] = rw[0]
     R = [r0, rw[1].contiguous(), rw[2].contiguous(), rw[3].contiguous(), rw[4].contiguous()]
@@ -149,6 +158,11 @@ class NodeField:
         h = [pool.get(f"h{l}" if (keep_all or l == 3) else f"h_pp{l & 1}", P, 256) for l in range(8)]
         K.embed_fwd(xc, 3, sp.L, P, in0, out2=h[3][:, sp.skip_out:], barf_w=barf_w)
         W, b = pk["W"], pk["b"]
+        if USE_CHAIN and keep_all:
+            wpack, bias8 = pk["fused"]
+            K.chain(K.CHAIN_SOFTPLUS, P, in0, wpack, 8, 5, skip_layer=3, side=in0, bias=[bias8[l] for l in range(8)],
+                    out=h)
+            return in0, h
         G.gemm_nt(in0, W[0], h[0], bias=b[0], epi=G.EPI_SOFTPLUS, K=sp.K0)
         G.gemm_nt(h[0], W[1], h[1], bias=b[1], epi=G.EPI_SOFTPLUS)
         G.gemm_nt(h[1], W[2], h[2], bias=b[2], epi=G.EPI_SOFTPLUS)
@@ -158,6 +172,27 @@ class NodeField:
         G.gemm_nt(h[5], W[6], h[6], bias=b[6], epi=G.EPI_SOFTPLUS)
         G.gemm_nt(h[6], W[7], h[7], bias=b[7], epi=G.EPI_SOFTPLUS)
         return in0, h
+
+    def _reverse_sweep(self, pk, h, t, ge, P, keep_all):
+        """t_l = d sdf / d a_l for l = 7..0 and ge = d sdf / d embedding (what torch.autograd.grad(sdf, x) evaluates,
+        volsdf_utils.py:79-93)."""
+        sp, WT = self.spec, pk["WT"]
+        K.seed_dsp(h[7], pk["w8_sdf"], 256, P, t[7])
+        if USE_CHAIN:
+            outs = [t[l - 1] if (keep_all or l - 1 in (0, 3)) else None for l in range(7, 0, -1)]
+            K.chain(K.CHAIN_DSP, P, t[7], pk["chain_bwd"], 7, 32, skip_layer=3, aux1=[h[l - 1] for l in range(7, 0, -1)],
+                    out=outs)
+            K.copy_cols(t[3][:, sp.skip_out:], ge, sp.E, P)  # raw columns 217.. = d sdf / d (skip embedding)
+        else:
+            for l in range(7, 0, -1):
+                if l == 4:
+                    G.gemm_nt(t[4], WT[4], t[3][:, :sp.skip_out], epi=G.EPI_MUL_DSP, aux1=h[3], N=256,
+                              n_split=sp.skip_out, out_raw=ge)
+                elif l == 3:
+                    G.gemm_nt(t[3], WT[3], t[2], epi=G.EPI_MUL_DSP, aux1=h[2], K=sp.skip_pad)
+                else:
+                    G.gemm_nt(t[l], WT[l], t[l - 1], epi=G.EPI_MUL_DSP, aux1=h[l - 1])
+        G.gemm_nt(t[0], WT[0], ge, N=sp.K0, accumulate=True)
 
     def sdf_only(self, pk, x, P, ppf, dfm, barf_w, out_sdf):
         """no-grad SDF query of the sampler (sdf_func_with_deformer, volsdf_utils.py:150-169).  out_sdf [P,1]."""
@@ -185,16 +220,7 @@ class NodeField:
         # t[3] always has its own buffer: its columns 217..219 are K-padding of the next GEMM and must stay zero
         t = [pool.get(f"t{l}" if (training or l == 3) else f"t_pp{l & 1}", P, 256) for l in range(8)]
         ge = pool.get("ge", P, sp.K0)
-        K.seed_dsp(h[7], pk["w8_sdf"], 256, P, t[7])
-        for l in range(7, 0, -1):
-            if l == 4:
-                G.gemm_nt(t[4], WT[4], t[3][:, :sp.skip_out], epi=G.EPI_MUL_DSP, aux1=h[3], N=256,
-                          n_split=sp.skip_out, out_raw=ge)
-            elif l == 3:
-                G.gemm_nt(t[3], WT[3], t[2], epi=G.EPI_MUL_DSP, aux1=h[2], K=sp.skip_pad)
-            else:
-                G.gemm_nt(t[l], WT[l], t[l - 1], epi=G.EPI_MUL_DSP, aux1=h[l - 1])
-        G.gemm_nt(t[0], WT[0], ge, N=sp.K0, accumulate=True)
+        self._reverse_sweep(pk, h, t, ge, P, keep_all=training)
         g = pool.get("g", P, 4)
         K.embed_bwd(xc, sp.L, P, ge, g, barf_w=barf_w)
         # ---- canonical normal + render-net input assembly ----
@@ -222,6 +248,82 @@ class NodeField:
         return dict(sdf=sdf, rgb=rgb, normal=rin[:, RIN_N:RIN_N + 3], xc=xc, feat=rin[:, RIN_FEAT:RIN_FEAT + FEAT],
                     grad=g)
 
+    # ------------------------------------------------------------------ shared backward sweeps
+    def _second_order_sweep(self, pk, h, t, gebar, dW, P):
+        """ascending sweep of the double backward: tbar_l = W_l vbar_l, ubar_l = tbar_l * s_l,
+        a2_l = 100 * tbar_l * t_l * (1 - s_l); dW_l += t_l^T vbar_l.  Returns (a2[8], ubar_7)."""
+        sp, pool, W = self.spec, self.pool, pk["W"]
+        a2 = [pool.get(f"a2_{l}", P, 256) for l in range(8)]
+        if USE_CHAIN:
+            vb = [pool.get(f"vbc{l}", P, 256) for l in range(8)]
+            K.chain(K.CHAIN_DBWD, P, gebar, pk["fused"][0], 8, 5, skip_layer=3, side=gebar, aux1=h, aux2=t, out=vb,
+                    out2=a2)
+            G.wgrad(t[0], gebar, dW[0], None, K=sp.K0, accumulate=True)
+            for l in range(1, 8):
+                if l == 3:
+                    G.wgrad(t[3], vb[2], dW[3], None, N=sp.skip_out, accumulate=True)
+                else:
+                    G.wgrad(t[l], vb[l - 1], dW[l], None, accumulate=True)
+            return a2, vb[7]
+        vb = [pool.get(f"vb{i}", P, 256) for i in range(2)]
+        # l = 0: tbar_0 = W0 vbar_0 ; ubar_0 = tbar*s ; a2_0 = 100*tbar*t*(1-s)
+        G.wgrad(t[0], gebar, dW[0], None, K=sp.K0, accumulate=True)
+        G.gemm_nt(gebar, W[0], vb[0], epi=G.EPI_DBWD, aux1=h[0], aux2=t[0], out2=a2[0], K=sp.K0)
+        cur = vb[0]
+        for l in range(1, 8):
+            nxt = vb[1] if cur is vb[0] else vb[0]
+            if l == 3:
+                G.wgrad(t[3], cur, dW[3], None, N=sp.skip_out, accumulate=True)
+                # output lands in the first 217 columns of the vbar_4 buffer; the skip part is gebar
+                G.gemm_nt(cur, W[3], nxt[:, :sp.skip_out], epi=G.EPI_DBWD, aux1=h[3], aux2=t[3], out2=a2[3],
+                          N=sp.skip_out)
+                K.copy_cols(gebar, nxt[:, sp.skip_out:], sp.E, P)
+            else:
+                G.wgrad(t[l], cur, dW[l], None, accumulate=True)
+                G.gemm_nt(cur, W[l], nxt, epi=G.EPI_DBWD, aux1=h[l], aux2=t[l], out2=a2[l])
+            cur = nxt
+        return a2, cur
+
+    def _first_order_sweep(self, pk, h, a2, r7, in0, dW, dWb, ebar, P):
+        """descending sweep r_{l-1} = (W_l^T r_l) * s_{l-1} + a2_{l-1} from r_7 down to r_0 with
+        dW_l += r_l^T in_l, db_l += sum r_l; the skip columns of W_4^T r_4 go to ebar[:, :39] (if given).
+        Returns r_0."""
+        sp, pool, WT = self.spec, self.pool, pk["WT"]
+        if USE_CHAIN:
+            r = [pool.get(f"rbc{l}", P, 256) for l in range(7)] + [r7]
+            K.chain(K.CHAIN_DSP, P, r7, pk["chain_bwd"], 7, 32, skip_layer=3, aux1=[h[l - 1] for l in range(7, 0, -1)],
+                    aux2=[a2[l - 1] for l in range(7, 0, -1)], out=[r[l - 1] for l in range(7, 0, -1)])
+            if ebar is not None:
+                K.copy_cols(r[3][:, sp.skip_out:], ebar, sp.E, P)
+            for l in range(7, 0, -1):
+                if l == 3:
+                    G.wgrad(r[3], h[2], dW[3], dWb[3], N=sp.skip_out, accumulate=True)
+                else:
+                    G.wgrad(r[l], h[l - 1], dW[l], dWb[l], accumulate=True)
+            return r[0]
+        rb_ = [pool.get(f"rb{i}", P, 256) for i in range(2)]
+        cur = r7
+        for l in range(7, 0, -1):
+            nxt = rb_[1] if cur is rb_[0] else rb_[0]
+            if l == 4:
+                G.wgrad(cur, h[3], dW[4], dWb[4], accumulate=True)
+                if ebar is not None:
+                    G.gemm_nt(cur, WT[4], nxt[:, :sp.skip_out], epi=G.EPI_MUL_DSP, aux1=h[3], aux2=a2[3], N=256,
+                              n_split=sp.skip_out, out_raw=ebar)
+                else:
+                    G.gemm_nt(cur, WT[4], nxt[:, :sp.skip_out], epi=G.EPI_MUL_DSP, aux1=h[3], aux2=a2[3],
+                              N=sp.skip_out)
+                # keep K-padding columns of r_3 (217..219) zero for the next GEMM
+                nxt[:, sp.skip_out:sp.skip_pad].zero_()
+            elif l == 3:
+                G.wgrad(cur, h[2], dW[3], dWb[3], N=sp.skip_out, accumulate=True)
+                G.gemm_nt(cur, WT[3], nxt, epi=G.EPI_MUL_DSP, aux1=h[2], aux2=a2[2], K=sp.skip_pad)
+            else:
+                G.wgrad(cur, h[l - 1], dW[l], dWb[l], accumulate=True)
+                G.gemm_nt(cur, WT[l], nxt, epi=G.EPI_MUL_DSP, aux1=h[l - 1], aux2=a2[l - 1])
+            cur = nxt
+        return cur
+
     # ------------------------------------------------------------------ eikonal samples (a13)
     def grad_points_forward(self, pk, xc, P, barf_w):
         """d sdf / d x at free canonical points (compute_gradient_samples, volsdf_utils.py:19-48): trunk forward +
@@ -231,16 +333,7 @@ class NodeField:
         WT = pk["WT"]
         t = [pool.get(f"t{l}", P, 256) for l in range(8)]
         ge = pool.get("ge", P, sp.K0)
-        K.seed_dsp(h[7], pk["w8_sdf"], 256, P, t[7])
-        for l in range(7, 0, -1):
-            if l == 4:
-                G.gemm_nt(t[4], WT[4], t[3][:, :sp.skip_out], epi=G.EPI_MUL_DSP, aux1=h[3], N=256,
-                          n_split=sp.skip_out, out_raw=ge)
-            elif l == 3:
-                G.gemm_nt(t[3], WT[3], t[2], epi=G.EPI_MUL_DSP, aux1=h[2], K=sp.skip_pad)
-            else:
-                G.gemm_nt(t[l], WT[l], t[l - 1], epi=G.EPI_MUL_DSP, aux1=h[l - 1])
-        G.gemm_nt(t[0], WT[0], ge, N=sp.K0, accumulate=True)
+        self._reverse_sweep(pk, h, t, ge, P, keep_all=True)
         g = pool.get("g", P, 4)
         K.embed_bwd(xc, sp.L, P, ge, g, barf_w=barf_w)
         self.saved = dict(P=P, xc=xc, in0=in0, h=h, t=t, ge=ge, g=g, barf_w=barf_w, pk=pk)
@@ -259,40 +352,11 @@ class NodeField:
         K.copy_cols(gbar.contiguous(), gb, 3, P)
         gebar = pool.get("gebar", P, sp.K0)
         K.embed_bwd2(xc, sp.L, P, sv["ge"], gb, gebar, xbar=None, barf_w=sv["barf_w"])
-        a2 = [pool.get(f"a2_{l}", P, 256) for l in range(8)]
-        vb = [pool.get(f"vb{i}", P, 256) for i in range(2)]
-        G.wgrad(t[0], gebar, dW[0], None, K=sp.K0, accumulate=True)
-        G.gemm_nt(gebar, W[0], vb[0], epi=G.EPI_DBWD, aux1=h[0], aux2=t[0], out2=a2[0], K=sp.K0)
-        cur = vb[0]
-        for l in range(1, 8):
-            nxt = vb[1] if cur is vb[0] else vb[0]
-            if l == 3:
-                G.wgrad(t[3], cur, dW[3], None, N=sp.skip_out, accumulate=True)
-                G.gemm_nt(cur, W[3], nxt[:, :sp.skip_out], epi=G.EPI_DBWD, aux1=h[3], aux2=t[3], out2=a2[3],
-                          N=sp.skip_out)
-                K.copy_cols(gebar, nxt[:, sp.skip_out:], sp.E, P)
-            else:
-                G.wgrad(t[l], cur, dW[l], None, accumulate=True)
-                G.gemm_nt(cur, W[l], nxt, epi=G.EPI_DBWD, aux1=h[l], aux2=t[l], out2=a2[l])
-            cur = nxt
+        a2, u7 = self._second_order_sweep(pk, h, t, gebar, dW, P)
         d_w8sdf = torch.zeros(256, device=dev)
-        K.colsum(cur, 256, P, d_w8sdf)
+        K.colsum(u7, 256, P, d_w8sdf)
         # first-order sweep driven only by the second-order terms a2_l (out_bar = 0  =>  r_7 = a2_7)
-        rb_ = [pool.get(f"rb{i}", P, 256) for i in range(2)]
-        cur = a2[7]
-        for l in range(7, 0, -1):
-            nxt = rb_[1] if cur is rb_[0] else rb_[0]
-            if l == 4:
-                G.wgrad(cur, h[3], dW[4], dWb[4], accumulate=True)
-                G.gemm_nt(cur, WT[4], nxt[:, :sp.skip_out], epi=G.EPI_MUL_DSP, aux1=h[3], aux2=a2[3], N=sp.skip_out)
-                nxt[:, sp.skip_out:sp.skip_pad].zero_()
-            elif l == 3:
-                G.wgrad(cur, h[2], dW[3], dWb[3], N=sp.skip_out, accumulate=True)
-                G.gemm_nt(cur, WT[3], nxt, epi=G.EPI_MUL_DSP, aux1=h[2], aux2=a2[2], K=sp.skip_pad)
-            else:
-                G.wgrad(cur, h[l - 1], dW[l], dWb[l], accumulate=True)
-                G.gemm_nt(cur, WT[l], nxt, epi=G.EPI_MUL_DSP, aux1=h[l - 1], aux2=a2[l - 1])
-            cur = nxt
+        cur = self._first_order_sweep(pk, h, a2, a2[7], sv["in0"], dW, dWb, None, P)
         G.wgrad(cur, sv["in0"], dW[0], dWb[0], K=sp.K0, accumulate=True)
         d0 = torch.zeros(256, pk["iw0_cols"], device=dev)
         d0[:, :sp.E] = dW[0][:, :sp.E]
@@ -354,51 +418,19 @@ class NodeField:
         K.copy_cols(d_rin[:, RIN_X:RIN_X + 3], xbar, 3, P)
         gebar = pool.get("gebar", P, sp.K0)
         K.embed_bwd2(xc, sp.L, P, sv["ge"], gbar, gebar, xbar=xbar, barf_w=sv["barf_w"])
-        a2 = [pool.get(f"a2_{l}", P, 256) for l in range(8)]
-        vb = [pool.get(f"vb{i}", P, 256) for i in range(2)]
-        # l = 0: tbar_0 = W0 vbar_0 ; ubar_0 = tbar*s ; a2_0 = 100*tbar*t*(1-s)
-        G.wgrad(t[0], gebar, dW[0], None, K=sp.K0, accumulate=True)
-        G.gemm_nt(gebar, W[0], vb[0], epi=G.EPI_DBWD, aux1=h[0], aux2=t[0], out2=a2[0], K=sp.K0)
-        cur = vb[0]
-        for l in range(1, 8):
-            nxt = vb[1] if cur is vb[0] else vb[0]
-            if l == 3:
-                G.wgrad(t[3], cur, dW[3], None, N=sp.skip_out, accumulate=True)
-                # output lands in the first 217 columns of the vbar_4 buffer; the skip part is gebar
-                G.gemm_nt(cur, W[3], nxt[:, :sp.skip_out], epi=G.EPI_DBWD, aux1=h[3], aux2=t[3], out2=a2[3],
-                          N=sp.skip_out)
-                K.copy_cols(gebar, nxt[:, sp.skip_out:], sp.E, P)
-            else:
-                G.wgrad(t[l], cur, dW[l], None, accumulate=True)
-                G.gemm_nt(cur, W[l], nxt, epi=G.EPI_DBWD, aux1=h[l], aux2=t[l], out2=a2[l])
-            cur = nxt
-        # cur = ubar_7 -> gradient of the sdf row of W8
+        a2, u7 = self._second_order_sweep(pk, h, t, gebar, dW, P)
+        # ubar_7 -> gradient of the sdf row of W8
         d_w8sdf = torch.zeros(256, device=dev)
-        K.colsum(cur, 256, P, d_w8sdf)
+        K.colsum(u7, 256, P, d_w8sdf)
         # ---------- first-order backward sweep ----------
         ob = pool.get("out_bar", P, 260)
         K.copy_cols(d_rin[:, RIN_FEAT:RIN_FEAT + FEAT], ob, FEAT, P)
         K.copy_cols(d_sdf.reshape(P, 1), ob[:, 256:257], 1, P)
         G.wgrad(ob, h[7], dW[8], dWb[8], N=257, accumulate=True)
-        rb_ = [pool.get(f"rb{i}", P, 256) for i in range(2)]
-        G.gemm_nt(ob, WT[8], rb_[0], epi=G.EPI_MUL_DSP, aux1=h[7], aux2=a2[7], K=260)
-        cur = rb_[0]
+        r7 = pool.get("r7", P, 256)
+        G.gemm_nt(ob, WT[8], r7, epi=G.EPI_MUL_DSP, aux1=h[7], aux2=a2[7], K=260)
         ebar = pool.get("ebar", P, sp.K0)
-        for l in range(7, 0, -1):
-            nxt = rb_[1] if cur is rb_[0] else rb_[0]
-            if l == 4:
-                G.wgrad(cur, h[3], dW[4], dWb[4], accumulate=True)
-                G.gemm_nt(cur, WT[4], nxt[:, :sp.skip_out], epi=G.EPI_MUL_DSP, aux1=h[3], aux2=a2[3], N=256,
-                          n_split=sp.skip_out, out_raw=ebar)
-                # keep K-padding columns of r_3 (217..219) zero for the next GEMM
-                nxt[:, sp.skip_out:sp.skip_pad].zero_()
-            elif l == 3:
-                G.wgrad(cur, h[2], dW[3], dWb[3], N=sp.skip_out, accumulate=True)
-                G.gemm_nt(cur, WT[3], nxt, epi=G.EPI_MUL_DSP, aux1=h[2], aux2=a2[2], K=sp.skip_pad)
-            else:
-                G.wgrad(cur, h[l - 1], dW[l], dWb[l], accumulate=True)
-                G.gemm_nt(cur, WT[l], nxt, epi=G.EPI_MUL_DSP, aux1=h[l - 1], aux2=a2[l - 1])
-            cur = nxt
+        cur = self._first_order_sweep(pk, h, a2, r7, sv["in0"], dW, dWb, ebar, P)
         G.wgrad(cur, sv["in0"], dW[0], dWb[0], K=sp.K0, accumulate=True)
         G.gemm_nt(cur, WT[0], ebar, N=sp.K0, accumulate=True)
         K.embed_bwd(xc, sp.L, P, ebar, xbar, barf_w=sv["barf_w"], accumulate=True)

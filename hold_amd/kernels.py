@@ -93,6 +93,48 @@ def fused_sdf(xc, P, wpack, bias8, w8, b8, barf_w, out_sdf):
     _g._prof_end(e0, 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256), "fused_sdf_kernel")
 
 
+CHAIN_SOFTPLUS, CHAIN_DSP, CHAIN_DBWD = 0, 1, 2
+
+
+_CHAIN_MAX_ROWS = ((1 << 32) // 1024 - 1) // 128 * 128  # 32-bit byte offsets inside the kernel (ld = 256)
+
+
+def chain(mode, P, x_in, wpack, n_layers, first_chunks, skip_layer=-1, side=None, bias=None, aux1=None, aux2=None,
+          out=None, out2=None):
+    """hold_chain: n_layers consecutive 256-wide layers of one sweep with the activation resident in LDS.
+    bias: per-layer [256] tensors; aux1 / aux2 / out / out2: per-layer [P,256] tensors (one common row stride) or None
+    entries.  Batches beyond the kernel's 32-bit offset range are split by rows."""
+    from . import gemm as _g
+    assert wpack.numel() == _lib.lib().hold_chain_pack_floats(first_chunks, n_layers)
+    for r0 in range(0, P, _CHAIN_MAX_ROWS):
+        r1 = min(P, r0 + _CHAIN_MAX_ROWS)
+        d = _lib.ChainDesc()
+        d.P, d.mode, d.n_layers, d.first_chunks, d.skip_layer = r1 - r0, mode, n_layers, first_chunks, skip_layer
+        d.in_, d.ld_in = x_in[r0:r1].data_ptr(), _ld(x_in)
+        if side is not None:
+            d.side, d.ld_side = side[r0:r1].data_ptr(), _ld(side)
+        d.wpack = wpack.data_ptr()
+        ld = None
+        for name, lst in (("bias", bias), ("aux1", aux1), ("aux2", aux2), ("out", out), ("out2", out2)):
+            if lst is None:
+                continue
+            arr = getattr(d, name)
+            for j in range(n_layers):
+                t = lst[j]
+                if t is None:
+                    continue
+                if name == "bias":
+                    arr[j] = t.data_ptr()
+                    continue
+                arr[j] = t[r0:r1].data_ptr()
+                assert ld is None or ld == _ld(t)
+                ld = _ld(t)
+        d.ld = ld if ld is not None else 256
+        e0 = _g._prof_begin()
+        call("hold_chain", C.byref(d))
+        _g._prof_end(e0, 2.0 * (r1 - r0) * 256 * (8 * first_chunks + 256 * (n_layers - 1)), "chain_kernel")
+
+
 def seed_dsp(h, w, N, P, t):
     call("hold_seed_dsp", ptr(h), _ld(h), ptr(w), N, P, ptr(t), _ld(t))
 

@@ -251,6 +251,41 @@ int hold_fused_sdf(const float* xc, int32_t ldx, int64_t P, const float* wpack, 
                    float b8, const float* barf_w, float* sdf, int32_t ld_sdf, hold_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * LDS-resident layer chains of the ImplicitNet for the TRAINING path (hold_amd/csrc/chain.hip): up to 8 consecutive
+ * 256-wide layers of one sweep in one launch; the running activation stays in LDS, per-layer side inputs are read
+ * from and per-layer results written to HBM directly from the accumulators.  Replaces n_layers hold_gemm_nt calls of
+ *   SOFTPLUS: ImplicitNet.forward lin0..lin7          (shape_net.py:108-125), stores h_l
+ *   DSP     : the descending sweeps torch.autograd derives from it (d sdf/d a_l for the canonical normal,
+ *             volsdf_utils.py:79-93, and the first-order backward), v_{l-1} = (M_j v_l) * sp'(aux1_j) [+ aux2_j]
+ *   DBWD    : the ascending second-order sweep of create_graph=True (volsdf_utils.py:87):
+ *             tb = M_j vb ; out_j = tb * sp'(aux1_j) ; out2_j = 100 * tb * aux2_j * (1 - sp'(aux1_j))
+ * in [P][8*first_chunks] (first_chunks = 5: K = 40, or 32: K = 256); all other matrices [P][256] with row stride ld.
+ * wpack: hold_chain_pack_floats(first_chunks, n_layers) floats, layer j = matrix M_j [256 out][K_j in] (zero padded) in
+ *   MFMA-fragment order [K_j/8 chunks][8 n-tiles][2 halves h][32 rows i][4] = M_j[32*nt + i][8*chunk + 4*h + c]
+ *   (the layout of hold_fused_sdf's wpack).
+ * skip_layer (or -1): chain layer whose output columns 217.. are special: SOFTPLUS / DBWD replace them by side[:, 0..38]
+ *   (side [P][40], row stride ld_side; out2 gets 0); DSP stores the raw products (no sp' factor, no aux2) there.
+ * ---------------------------------------------------------------------------------------- */
+enum hold_chain_mode { HOLD_CHAIN_SOFTPLUS = 0, HOLD_CHAIN_DSP = 1, HOLD_CHAIN_DBWD = 2 };
+typedef struct {
+  int64_t P;
+  int32_t mode, n_layers, first_chunks, skip_layer;
+  const float* in;
+  int32_t ld_in;
+  const float* side;
+  int32_t ld_side;
+  const float* wpack;
+  int32_t ld;
+  const float* bias[8];
+  const float* aux1[8];
+  const float* aux2[8];
+  float* out[8];
+  float* out2[8];
+} hold_chain_desc;
+int64_t hold_chain_pack_floats(int32_t first_chunks, int32_t n_layers);
+int hold_chain(const hold_chain_desc* d, hold_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Pose-refinement inner loop (hold_amd/csrc/silhouette.hip).
  * Soft silhouette = pytorch3d MeshRenderer(MeshRasterizer(blur_radius, faces_per_pixel=100), SoftSilhouetteShader)
  * as configured by code/src/fitting/utils.py:101-158 and called at code/src/fitting/model.py:136-138:

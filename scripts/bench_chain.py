@@ -1,0 +1,40 @@
+"""time hold_chain per mode against the equivalent hold_gemm_nt sequences (P = 16384 rays x 98 samples)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from hold_amd import kernels as K, gemm as G
+dev = "cuda:0"; P = int(sys.argv[1]) if len(sys.argv) > 1 else 16384 * 98
+def pack(mats):
+    return torch.cat([m.reshape(8, 32, m.shape[1] // 8, 2, 4).permute(2, 0, 3, 1, 4).reshape(-1) for m in mats]).contiguous()
+g = torch.Generator().manual_seed(0)
+W = [torch.randn(256, 40, generator=g).to(dev) / 6] + [torch.randn(256, 256, generator=g).to(dev) / 16 for _ in range(7)]
+b = [torch.randn(256, generator=g).to(dev) * 0.05 for _ in range(8)]
+x0 = torch.randn(P, 40, device=dev)
+bufs = lambda n: [torch.empty(P, 256, device=dev) for _ in range(n)]
+h, t, a2, o1 = bufs(8), bufs(8), bufs(8), bufs(8)
+for x in h: x.uniform_(0, 0.05)
+for x in t + a2: x.normal_()
+wf, wb = pack(W), pack(W[1:])
+def timeit(name, fn, flops):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3): fn()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    print(f"{name:28s} {ms:8.3f} ms  {flops / ms / 1e9:6.1f} TFLOP/s", flush=True)
+f8 = 2.0 * P * 256 * (40 + 7 * 256); f7 = 2.0 * P * 256 * 7 * 256
+timeit("chain SOFTPLUS (8 layers)", lambda: K.chain(K.CHAIN_SOFTPLUS, P, x0, wf, 8, 5, skip_layer=3, side=x0, bias=b, out=o1), f8)
+timeit("chain SOFTPLUS no stores", lambda: K.chain(K.CHAIN_SOFTPLUS, P, x0, wf, 8, 5, skip_layer=3, side=x0, bias=b, out=None), f8)
+timeit("chain DSP (7 layers)", lambda: K.chain(K.CHAIN_DSP, P, t[7], wb, 7, 32, skip_layer=3, aux1=h[:7], out=o1[:7]), f7)
+timeit("chain DSP+a2 (7 layers)", lambda: K.chain(K.CHAIN_DSP, P, t[7], wb, 7, 32, skip_layer=3, aux1=h[:7], aux2=a2[:7], out=o1[:7]), f7)
+timeit("chain DBWD (8 layers)", lambda: K.chain(K.CHAIN_DBWD, P, x0, wf, 8, 5, skip_layer=3, side=x0, aux1=h, aux2=t, out=o1, out2=a2), f8)
+def layered_sp():
+    G.gemm_nt(x0, W[0], o1[0], bias=b[0], epi=G.EPI_SOFTPLUS, K=40)
+    for l in range(1, 8): G.gemm_nt(o1[l - 1], W[l], o1[l], bias=b[l], epi=G.EPI_SOFTPLUS)
+def layered_dsp():
+    cur = t[7]
+    for l in range(7): G.gemm_nt(cur, W[l + 1], o1[l], epi=G.EPI_MUL_DSP, aux1=h[l], aux2=a2[l]); cur = o1[l]
+timeit("gemm_nt x8 SOFTPLUS", layered_sp, f8)
+timeit("gemm_nt x7 DSP+a2", layered_dsp, f7)
