@@ -17,7 +17,7 @@ if f:
         k = m.group(1) if m else r["Kernel_Name"][:40]
         agg[k][0] += 1
         agg[k][1] += float(r["Counter_Value"])
-out = {k: {"launches": v[0], "sum": v[1], "avg_per_launch": v[1] / v[0]} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]}
+out = {k: {"launches": v[0], "sum": v[1], "avg_per_launch": v[1] / v[0]} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]}
 json.dump(out, open("/root/repo/gpurun_out/pmc/$c.json", "w"), indent=1)
 print("$c", json.dumps(list(out.items())[:3]))
 PY
