@@ -127,6 +127,24 @@ def test_chain_second_order_dbwd(P):
         cur = o1[l].double()
 
 
+def test_chain_row_split_matches_single_call(monkeypatch):
+    """batches beyond the kernel's 32-bit offset range are split by rows in hold_amd/kernels.py:chain"""
+    from hold_amd import kernels as K
+    dev = _dev()
+    P = 1000
+    g = torch.Generator().manual_seed(11)
+    v7 = torch.randn(P, 256, generator=g).to(dev)
+    Ms = [(torch.randn(256, 256, generator=g) / 16).to(dev) for _ in range(7)]
+    hs = [_sp(torch.randn(P, 256, generator=g) * 0.03).to(dev) for _ in range(7)]
+    ref = [torch.empty(P, 256, device=dev) for _ in range(7)]
+    K.chain(K.CHAIN_DSP, P, v7, _pack(Ms), 7, 32, skip_layer=3, aux1=hs, out=ref)
+    monkeypatch.setattr(K, "_CHAIN_MAX_ROWS", 384)
+    out = [torch.empty(P, 256, device=dev) for _ in range(7)]
+    K.chain(K.CHAIN_DSP, P, v7, _pack(Ms), 7, 32, skip_layer=3, aux1=hs, out=out)
+    for a, b in zip(ref, out):
+        assert torch.equal(a, b)
+
+
 def test_chain_rejects_bad_arguments():
     import ctypes as C
     from hold_amd import _lib
