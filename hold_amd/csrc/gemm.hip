@@ -196,16 +196,28 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(hold_gemm_desc d, int t
       if (kt + 1 < nk && !(stagger & 256)) stage(m0, n0, kt + 1, buf ^ 1);
       const float* pa = sA + buf * (BM * BKc) + rowa0 * BKc;
       const float* pw = sW + buf * (BNc * BKc) + roww0 * BKc;
-#pragma unroll
-      for (int q = 0; q < QN; ++q) {
+      // fragments of the next 16-byte k group are requested before this group's MFMAs (pinned with sched barriers:
+      // left alone the scheduler issues them a couple of MFMAs before their use)
+      f32x4 avn[2], bvn[NT];
+      auto frag = [&](int q) {
         const int c = hh * QN + q;
-        f32x4 av[2], bv[NT];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
-          av[a] = *reinterpret_cast<const f32x4*>(pa + a * 32 * BKc + ((c ^ key(rowa0 + 32 * a)) << 2));
+          avn[a] = *reinterpret_cast<const f32x4*>(pa + a * 32 * BKc + ((c ^ key(rowa0 + 32 * a)) << 2));
 #pragma unroll
         for (int b = 0; b < NT; ++b)
-          bv[b] = *reinterpret_cast<const f32x4*>(pw + b * 32 * BKc + ((c ^ key(roww0 + 32 * b)) << 2));
+          bvn[b] = *reinterpret_cast<const f32x4*>(pw + b * 32 * BKc + ((c ^ key(roww0 + 32 * b)) << 2));
+      };
+      frag(0);
+#pragma unroll
+      for (int q = 0; q < QN; ++q) {
+        f32x4 av[2], bv[NT];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) av[a] = avn[a];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) bv[b] = bvn[b];
+        if (q + 1 < QN) frag(q + 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
@@ -213,6 +225,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(hold_gemm_desc d, int t
 #pragma unroll
             for (int b = 0; b < NT; ++b)
               acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][cc], bv[b][cc], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
       if (!(stagger & 512)) stage_wait();
     }
@@ -481,13 +494,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restri
     if (c + 1 < c_end) stage(c + 1, buf ^ 1);
     const float* pr = sR + buf * PC * 128 + (hh * STEPS) * 128 + wn * 64 + li;
     const float* px = sX + buf * PC * BKW + (hh * STEPS) * BKW + wk * (32 * KT) + li;
+    // fragments one step ahead, pinned: left alone the scheduler issues them ~2 MFMAs before their use
+    float avn[2], bvn[KT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) avn[a] = pr[a * 32];
+#pragma unroll
+    for (int b = 0; b < KT; ++b) bvn[b] = px[b * 32];
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
       float av[2], bv[KT];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) av[a] = pr[st * 128 + a * 32];
+      for (int a = 0; a < 2; ++a) av[a] = avn[a];
 #pragma unroll
-      for (int b = 0; b < KT; ++b) bv[b] = px[st * BKW + b * 32];
+      for (int b = 0; b < KT; ++b) bv[b] = bvn[b];
+      if (st + 1 < STEPS) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) avn[a] = pr[(st + 1) * 128 + a * 32];
+#pragma unroll
+        for (int b = 0; b < KT; ++b) bvn[b] = px[(st + 1) * BKW + b * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -495,6 +521,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restri
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
       bsum[0] += av[0];
       bsum[1] += av[1];
+      __builtin_amdgcn_sched_barrier(0);
     }
     stage_wait();
   }
