@@ -117,6 +117,7 @@ SIGNATURES = {
     "hold_diag_mfma_lds": [_P, _P, _I, _I, _I, _P],
     "hold_fused_sdf": [_P, _I, _L, _P, _P, _P, _F, _P, _P, _I, _P],
     "hold_chain": [C.POINTER(ChainDesc), _P],
+    "hold_fused_sdf_x6": [_P, _I, _L, _P, _P, _P, _F, _P, _P, _I, _P],
     "hold_mano_lbs_fwd": [C.POINTER(ManoModel), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "hold_mano_lbs_bwd": [C.POINTER(ManoModel), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
 }
@@ -127,6 +128,7 @@ def _declare(L):
     L.hold_wgrad_workspace_floats.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     L.hold_wgrad_workspace_floats.restype = C.c_int64
     L.hold_fused_sdf_pack_floats.restype = C.c_int64
+    L.hold_fused_sdf_x6_pack_bytes.restype = C.c_int64
     L.hold_chain_pack_floats.argtypes = [C.c_int32, C.c_int32]
     L.hold_chain_pack_floats.restype = C.c_int64
     L.hold_silhouette_workspace_floats.argtypes = [C.c_int32, C.c_int32]

@@ -354,6 +354,187 @@ __global__ __launch_bounds__(512, 2) void fused_sdf_pipe_kernel(FusedArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// EXPERIMENTAL (opt-in, HOLD_FUSED_SDF_X6=1; not validated on hardware yet): split-precision variant.  Every fp32
+// operand is the exact sum of three bf16 limbs (x = l1 + l2 + l3, each limb the bf16 rounding of the remaining
+// residual); the six partial products with limb-index sum <= 4 run on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA
+// rate) with fp32 accumulation, the three dropped ones are <= 2^-24 relative.  scripts/split_precision_study.py
+// (exact CPU emulation) measures this scheme at the accuracy of plain fp32 on the whole trunk incl. second-order
+// gradients.  Activations stay fp32 in LDS (3 bf16 planes of 128 x 256 would not fit in 160 KiB) and are split on the
+// fly when a wave loads its fragments; the weights arrive pre-split (6 B per weight, MFMA-fragment order, L2-resident).
+// Un-pipelined layer structure of fused_sdf_kernel<4,1> (each weight fragment feeds all 4 point tiles; the two-half
+// pipeline would stream the 2.8 MiB weight pack twice per layer).  Within a layer the work is 2 x STEPS "pair tiles"
+// (one 16-wide k step x 64 points): region q issues the LDS reads of pair q+2, runs the 12 MFMAs of pair q and splits
+// pair q+1's activations under them.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int X6_L0_STEPS = 3, X6_LK_STEPS = 16;   // K = 48 (40 zero-padded) and 256, in steps of 16
+constexpr int X6_STEP_UNITS = 3 * 512;              // 16-byte units per step: [3 limbs][8 n-tiles][64 lanes]
+
+struct Limbs3 { bf16x8 l[3]; };
+
+__device__ __forceinline__ Limbs3 split8(const f32x4& x0, const f32x4& x1) {
+  Limbs3 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = e < 4 ? x0[e] : x1[e - 4];
+    const __bf16 h1 = (__bf16)x;
+    const float r1 = x - (float)h1;
+    const __bf16 h2 = (__bf16)r1;
+    const float r2 = r1 - (float)h2;
+    o.l[0][e] = h1;
+    o.l[1][e] = h2;
+    o.l[2][e] = (__bf16)r2;
+  }
+  return o;
+}
+
+// MFMA phase of one layer.  wq: this wave-lane's pointer to the layer's first step in the limb pack; nxt: the step that
+// follows the layer's last one (next layer, or the pack's start for the next 128 points).  bn holds the limbs of the
+// step about to run (requested one step = 24 MFMAs per wave earlier).
+template <int STEPS>
+__device__ __forceinline__ void x6_layer(const bf16x8* __restrict__ wq, const bf16x8* __restrict__ nxt,
+                                         const float* __restrict__ arow, f32x16 (&acc)[4], bf16x8 (&bn)[3]) {
+  constexpr int Q = 2 * STEPS;
+  auto rd = [&](int q, f32x4 (&x)[4]) {  // fp32 fragments of pair q: m = 2 (q & 1) + {0, 1}, k = 16 (q >> 1) + 8 hh ..
+    const float* p = arow + (q >> 1) * 16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      x[2 * j] = *reinterpret_cast<const f32x4*>(p + (2 * (q & 1) + j) * 32 * ASTR);
+      x[2 * j + 1] = *reinterpret_cast<const f32x4*>(p + (2 * (q & 1) + j) * 32 * ASTR + 4);
+    }
+  };
+  f32x4 xn[4];
+  Limbs3 la[2], lb[2];
+  bf16x8 b[3];
+  rd(0, xn);
+  la[0] = split8(xn[0], xn[1]);
+  la[1] = split8(xn[2], xn[3]);
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int s = q >> 1, m0 = 2 * (q & 1);
+    // ---- issue: the next pair's fp32 fragments, the next step's weight limbs ----
+    if (q + 1 < Q) rd(q + 1, xn);
+    if ((q & 1) == 0) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        b[t] = bn[t];
+        bn[t] = (s + 1 < STEPS) ? wq[(s + 1) * X6_STEP_UNITS + t * 512] : nxt[t * 512];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- first half of the limb products (w limb, a limb): 00 01 10 ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[m0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], la[j].l[0], acc[m0 + j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[m0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], la[j].l[1], acc[m0 + j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[m0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1], la[j].l[0], acc[m0 + j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 11 02 20, with the next pair's split (its LDS data has had 6 MFMAs to arrive) interleaved ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[m0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1], la[j].l[1], acc[m0 + j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[m0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], la[j].l[2], acc[m0 + j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[m0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[2], la[j].l[0], acc[m0 + j], 0, 0, 0);
+    if (q + 1 < Q) {
+      lb[0] = split8(xn[0], xn[1]);
+      lb[1] = split8(xn[2], xn[3]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    la[0] = lb[0];
+    la[1] = lb[1];
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void fused_sdf_x6_kernel(FusedArgs a, const bf16x8* __restrict__ wx6) {
+  constexpr int PTS = 128, NTHR = 512;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* act = smem;                   // [128][260] fp32
+  float* emb = smem + PTS * ASTR;      // [128][40]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, li = lane & 31;
+  const bf16x8* w0 = wx6 + wave * 64 + lane;
+
+  for (long blk = blockIdx.x; blk * PTS < a.P; blk += gridDim.x) {
+    const long p0 = blk * PTS;
+    bf16x8 bn[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) bn[t] = w0[t * 512];
+    for (int e = tid; e < PTS * 48; e += NTHR) {   // embedding, zero-padded to K = 48
+      const int p = e / 48, j = e % 48;
+      float v = 0.f;
+      const long gp = p0 + p;
+      if (j < NE && gp < a.P) {
+        if (j < 3) {
+          v = a.xc[gp * a.ldx + j];
+        } else {
+          const int q = (j - 3) / 3, dim = (j - 3) % 3, k = q >> 1;
+          const float arg = a.xc[gp * a.ldx + dim] * (float)(1 << k);
+          v = (q & 1) ? cosf(arg) : sinf(arg);
+        }
+        if (a.barf) v *= a.barf[j];
+      }
+      if (j < ESTR) emb[p * ESTR + j] = v;
+      act[p * ASTR + j] = v;
+    }
+    __syncthreads();
+
+    const float* arow = act + li * ASTR + hh * 8;
+    const bf16x8* wl = w0;
+    for (int layer = 0; layer < 8; ++layer) {
+      f32x16 acc[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+      if (layer == 0) {
+        x6_layer<X6_L0_STEPS>(wl, wl + X6_L0_STEPS * X6_STEP_UNITS, arow, acc, bn);
+        wl += X6_L0_STEPS * X6_STEP_UNITS;
+      } else {
+        x6_layer<X6_LK_STEPS>(wl, layer < 7 ? wl + X6_LK_STEPS * X6_STEP_UNITS : w0, arow, acc, bn);
+        wl += X6_LK_STEPS * X6_STEP_UNITS;
+      }
+      __syncthreads();  // every wave has finished READING this layer's input
+      const int nb = wave * 32 + 4 * hh;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n4 = nb + 8 * g;
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + layer * 256 + n4);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int p = m * 32 + li;
+          f32x4 v;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = softplus100(acc[m][4 * g + c] + bias[c]);
+          if (layer == 3 && n4 + 3 >= SKIP_OUT) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (n4 + c >= SKIP_OUT) v[c] = emb[p * ESTR + (n4 + c - SKIP_OUT)];
+          }
+          *reinterpret_cast<f32x4*>(act + p * ASTR + n4) = v;
+        }
+      }
+      __syncthreads();
+    }
+    {
+      const int p = tid >> 2, q = tid & 3;
+      const f32x4* hrow = reinterpret_cast<const f32x4*>(act + p * ASTR + q * 64);
+      const f32x4* wrow = reinterpret_cast<const f32x4*>(a.w8 + q * 64);
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const f32x4 h = hrow[i], w = wrow[i];
+        s += h[0] * w[0] + h[1] * w[1] + h[2] * w[2] + h[3] * w[3];
+      }
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      if (q == 0 && p0 + p < a.P) a.sdf[(p0 + p) * a.lds] = s + a.b8;
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" int64_t hold_fused_sdf_pack_floats(void) {
@@ -406,5 +587,39 @@ extern "C" int hold_fused_sdf(const float* xc, int32_t ldx, int64_t P, const flo
                        (hipStream_t)st, a,
                        getenv("HOLD_FUSED_STAGGER") ? atoi(getenv("HOLD_FUSED_STAGGER")) : (blocks >= 4 * res ? 3 : 0));
   }
+  return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+}
+
+extern "C" int64_t hold_fused_sdf_x6_pack_bytes(void) {
+  return (int64_t)(X6_L0_STEPS + 7 * X6_LK_STEPS) * X6_STEP_UNITS * 16;
+}
+
+// EXPERIMENTAL split-precision (3 bf16 limbs, 6 products) variant of hold_fused_sdf; same contract, the weights as
+// wpack_x6 (hold_fused_sdf_x6_pack_bytes() bytes, layout in include/hold_hip.h).
+extern "C" int hold_fused_sdf_x6(const float* xc, int32_t ldx, int64_t P, const void* wpack_x6, const float* bias,
+                                 const float* w8, float b8, const float* barf_w, float* sdf, int32_t ld_sdf,
+                                 hold_stream_t st) {
+  if (!xc || !wpack_x6 || !bias || !w8 || !sdf || ldx < 3 || ld_sdf < 1 || P < 0) return HOLD_E_ARG;
+  if (((uintptr_t)wpack_x6 & 15) || ((uintptr_t)w8 & 15) || ((uintptr_t)bias & 15)) return HOLD_E_ARG;
+  if (P == 0) return HOLD_OK;
+  static int n_cu = 0;
+  static bool attr_set = false;
+  const size_t sh = (size_t)(128 * ASTR + 128 * ESTR) * sizeof(float);
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return HOLD_E_LAUNCH;
+    n_cu = prop.multiProcessorCount;
+  }
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)fused_sdf_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) !=
+        hipSuccess)
+      return HOLD_E_LAUNCH;
+    attr_set = true;
+  }
+  FusedArgs a = {xc, ldx, (long)P, nullptr, bias, w8, b8, barf_w, sdf, ld_sdf};
+  const long blocks = (P + 127) / 128;
+  hipLaunchKernelGGL(fused_sdf_x6_kernel, dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(512), sh, (hipStream_t)st,
+                     a, reinterpret_cast<const bf16x8*>(wpack_x6));
   return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
 }

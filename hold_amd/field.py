@@ -24,6 +24,8 @@ from . import kernels as K
 
 FEAT = 256
 FUSED_SDF = os.environ.get("HOLD_FUSED_SDF", "1") != "0"  # sampler queries through the fused LDS-resident kernel
+# EXPERIMENTAL: sampler queries through the split-precision (bf16 x 6) fused kernel -- opt-in until hardware-validated
+FUSED_SDF_X6 = os.environ.get("HOLD_FUSED_SDF_X6", "0") == "1"
 # training-path sweeps as LDS-resident layer chains (hold_chain) instead of one hold_gemm_nt per layer
 USE_CHAIN = os.environ.get("HOLD_CHAIN", "1") != "0"
 RIN_X, RIN_N, RIN_POSE, RIN_FEAT = 0, 3, 6, 14
@@ -68,6 +70,29 @@ class FieldSpec:
         self.n_bones = 1 if kind == "object" else 16
 
 
+def split_limbs(w, n=3):
+    """exact bf16 limb decomposition w = sum_t limb_t (limb_t = bf16 rounding of the residual), as fp32 values"""
+    out, r = [], w.float()
+    for _ in range(n):
+        l = r.to(torch.bfloat16)
+        out.append(l)
+        r = r - l.float()
+    return out
+
+
+def pack_x6(W8):
+    """limb pack of hold_fused_sdf_x6 (include/hold_hip.h) from the 8 trunk matrices W8[l] ([<=256, K_l], layer 0 with
+    K = 40): bf16 tensor, [K_l/16 steps][3 limbs][8 n-tiles][2 h][32 i][8 e] per layer."""
+    parts = []
+    for l, wl in enumerate(W8):
+        K = 48 if l == 0 else 256
+        m = torch.zeros(256, K, device=wl.device)
+        m[:wl.shape[0], :wl.shape[1]] = wl
+        limbs = torch.stack(split_limbs(m))  # [3, 256, K] bf16
+        parts.append(limbs.reshape(3, 8, 32, K // 16, 2, 8).permute(3, 0, 1, 4, 2, 5).reshape(-1))
+    return torch.cat(parts).contiguous()
+
+
 def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
     """iw/ib: 9 effective ImplicitNet weights/biases ([out,in] as nn.Linear); rw/rb: 5 RenderingNet ones.
     Returns the re-laid-out (and, for sweeps that contract over the output index, transposed) copies the
@@ -108,6 +133,8 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
     for l in range(8):
         bias8[l, :pk["b"][l].shape[0]] = pk["b"][l]
     pk["fused"] = (torch.cat(parts).contiguous(), bias8.contiguous())
+    if FUSED_SDF_X6:
+        pk["fused_x6"] = pack_x6(W[:8])
     # descending sweeps (hold_chain DSP): layer j contracts over the outputs of trunk layer l = 7 - j, M_j = W_l^T
     parts = []
     for l in range(7, 0, -1):
@@ -197,6 +224,9 @@ class NodeField:
     def sdf_only(self, pk, x, P, ppf, dfm, barf_w, out_sdf):
         """no-grad SDF query of the sampler (sdf_func_with_deformer, volsdf_utils.py:150-169).  out_sdf [P,1]."""
         xc, _ = self._deform(x, P, ppf, dfm, want_w=False)
+        if FUSED_SDF and FUSED_SDF_X6:
+            K.fused_sdf_x6(xc, P, pk["fused_x6"], pk["fused"][1], pk["w8_sdf"], float(pk["b8_sdf"]), barf_w, out_sdf)
+            return
         if FUSED_SDF:
             wpack, bias8 = pk["fused"]
             K.fused_sdf(xc, P, wpack, bias8, pk["w8_sdf"], float(pk["b8_sdf"]), barf_w, out_sdf)

@@ -93,6 +93,16 @@ def fused_sdf(xc, P, wpack, bias8, w8, b8, barf_w, out_sdf):
     _g._prof_end(e0, 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256), "fused_sdf_kernel")
 
 
+def fused_sdf_x6(xc, P, wpack_x6, bias8, w8, b8, barf_w, out_sdf):
+    """EXPERIMENTAL split-precision (3 bf16 limbs x 6 products) variant of fused_sdf; wpack_x6 from field.pack_x6."""
+    assert wpack_x6.numel() * wpack_x6.element_size() == _lib.lib().hold_fused_sdf_x6_pack_bytes()
+    from . import gemm as _g
+    e0 = _g._prof_begin()
+    call("hold_fused_sdf_x6", ptr(xc), _ld(xc), P, ptr(wpack_x6), ptr(bias8), ptr(w8), float(b8), ptr(barf_w),
+         ptr(out_sdf), _ld(out_sdf))
+    _g._prof_end(e0, 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256), "fused_sdf_kernel")
+
+
 CHAIN_SOFTPLUS, CHAIN_DSP, CHAIN_DBWD = 0, 1, 2
 
 

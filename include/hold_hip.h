@@ -250,6 +250,17 @@ int64_t hold_fused_sdf_pack_floats(void);
 int hold_fused_sdf(const float* xc, int32_t ldx, int64_t P, const float* wpack, const float* bias, const float* w8,
                    float b8, const float* barf_w, float* sdf, int32_t ld_sdf, hold_stream_t stream);
 
+/* EXPERIMENTAL (opt-in via HOLD_FUSED_SDF_X6=1 in hold_amd/field.py; not hardware-validated in round 1): the same
+ * contract as hold_fused_sdf with split-precision arithmetic -- every fp32 operand is the exact sum of three bf16 limbs
+ * (limb t = bf16 rounding of what limbs < t left over), six of the nine limb products on v_mfma_f32_32x32x16_bf16 with
+ * fp32 accumulation (dropped terms <= 2^-24 relative; scripts/split_precision_study.py).
+ * wpack_x6: hold_fused_sdf_x6_pack_bytes() bytes of bf16:
+ *   for layer l (K_l = 48 for l = 0 (40 zero-padded), else 256; rows/scaling as for hold_fused_sdf):
+ *   [K_l/16 steps][3 limbs t][8 n-tiles][2 halves h][32 rows i][8] = limb_t(W_l)[32*nt + i][16*step + 8*h + e] */
+int64_t hold_fused_sdf_x6_pack_bytes(void);
+int hold_fused_sdf_x6(const float* xc, int32_t ldx, int64_t P, const void* wpack_x6, const float* bias, const float* w8,
+                      float b8, const float* barf_w, float* sdf, int32_t ld_sdf, hold_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * LDS-resident layer chains of the ImplicitNet for the TRAINING path (hold_amd/csrc/chain.hip): up to 8 consecutive
  * 256-wide layers of one sweep in one launch; the running activation stays in LDS, per-layer side inputs are read

@@ -122,3 +122,35 @@ def test_fused_sdf_matches_layered_path():
         K.fused_sdf(xc, P, wpack, bias8, pk["w8_sdf"], float(pk["b8_sdf"]), barf, out)
         err = float((out - ref).abs().max())
         assert err < 2e-5 * max(1.0, float(ref.abs().max())), (kind, err)
+
+
+@pytest.mark.skipif(__import__("os").environ.get("HOLD_TEST_EXPERIMENTAL") != "1",
+                    reason="hold_fused_sdf_x6 is opt-in until validated on hardware (HOLD_TEST_EXPERIMENTAL=1)")
+def test_fused_sdf_x6_matches_fp32_fused():
+    """split-precision (3 bf16 limbs x 6 products) sampler trunk against the fp32-MFMA fused kernel"""
+    from hold_amd import field as F, kernels as K, synthetic as syn
+    dev = _dev()
+    sc = syn.make_scene(2)
+    sd = {k: torch.as_tensor(v).to(dev) for k, v in syn.make_state_dict(sc, perturb=0.05).items()}
+    for kind, node in (("hand", "right"), ("object", "object")):
+        spec = F.FieldSpec(kind)
+        pre = f"nodes.{node}."
+        eff = lambda p: sd[p + ".weight_v"] * (sd[p + ".weight_g"] / sd[p + ".weight_v"].norm(dim=1, keepdim=True))
+        iw = [eff(pre + f"implicit_network.lin{l}") for l in range(9)]
+        ib = [sd[pre + f"implicit_network.lin{l}.bias"] for l in range(9)]
+        rw = [eff(pre + f"rendering_network.lin{l}") for l in range(5)]
+        rb = [sd[pre + f"rendering_network.lin{l}.bias"] for l in range(5)]
+        pk = F.pack_weights(spec, iw, ib, rw, rb, need_bwd=False)
+        x6 = F.pack_x6(pk["W"][:8])
+        P = 1000
+        g = torch.Generator().manual_seed(1)
+        xc = torch.zeros(P, 4, device=dev)
+        xc[:, :3] = (torch.rand(P, 3, generator=g) * 1.6 - 0.8).to(dev)
+        barf = (torch.rand(39, generator=g).to(dev) if kind == "object" else None)
+        wpack, bias8 = pk["fused"]
+        ref = torch.empty(P, 1, device=dev)
+        K.fused_sdf(xc, P, wpack, bias8, pk["w8_sdf"], float(pk["b8_sdf"]), barf, ref)
+        out = torch.full((P, 1), 7.0, device=dev)
+        K.fused_sdf_x6(xc, P, x6, bias8, pk["w8_sdf"], float(pk["b8_sdf"]), barf, out)
+        err = float((out - ref).abs().max())
+        assert err < 5e-6 * max(1.0, float(ref.abs().max())), (kind, err)

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert declared - {"hold_abi_version", "hold_wgrad_workspace_floats", "hold_fused_sdf_pack_floats", "hold_chain_pack_floats",
+    assert declared - {"hold_abi_version", "hold_wgrad_workspace_floats", "hold_fused_sdf_pack_floats", "hold_chain_pack_floats", "hold_fused_sdf_x6_pack_bytes",
                        "hold_silhouette_workspace_floats"} == set(_lib.SIGNATURES)
     assert L.hold_abi_version() == 1
 
@@ -65,3 +65,42 @@ def test_synthetic_inputs_are_deterministic():
     assert all(np.array_equal(s1[k], s2[k]) for k in s1)
     w = a["weights"]
     assert np.allclose(w.sum(1), 1.0) and a["v_template"].shape == (778, 3)
+
+
+def test_x6_limb_pack_layout_and_arithmetic():
+    """hold_fused_sdf_x6's weight pack (field.pack_x6) read back with the KERNEL's index arithmetic
+    (csrc/fused_sdf.hip: unit = step*1536 + limb*512 + wave*64 + lane, lane = 32*h + i, 8 bf16 per unit) and combined
+    with on-the-fly activation limbs through the six limb products reproduces W @ x to fp32 accuracy."""
+    import torch
+    from hold_amd import field as F
+
+    g = torch.Generator().manual_seed(0)
+    W8 = [torch.randn(256, 40, generator=g) / 6] + [torch.randn(256, 256, generator=g) / 16 for _ in range(7)]
+    W8[3] = W8[3][:217]
+    pack = F.pack_x6(W8)
+    assert pack.dtype == torch.bfloat16 and pack.numel() * 2 == (3 + 7 * 16) * 1536 * 16
+    units = pack.float().reshape(-1, 8)  # 16-byte units
+    step0 = 0
+    for l, wl in enumerate(W8):
+        K = 48 if l == 0 else 256
+        steps = K // 16
+        x = torch.zeros(32, K)
+        x[:, :wl.shape[1]] = torch.randn(32, wl.shape[1], generator=g)  # 32 points = one MFMA tile
+        xl = [t.float() for t in F.split_limbs(x)]
+        assert torch.equal(xl[0] + xl[1] + xl[2], x)  # three bf16 limbs hold an fp32 exactly
+        for wave in (0, 3, 6, 7):
+            acc = torch.zeros(32, 32)  # D[i = feature][j = point]
+            for s in range(steps):
+                for wlimb, alimb in ((0, 0), (0, 1), (1, 0), (1, 1), (0, 2), (2, 0)):
+                    A = torch.zeros(32, 16)  # A[i][k]: lane (h, i) supplies k = 8h + e
+                    for h in range(2):
+                        lanes = torch.arange(32) + 32 * h
+                        A[:, 8 * h:8 * h + 8] = units[(step0 + s) * 1536 + wlimb * 512 + wave * 64 + lanes]
+                    B = xl[alimb][:, 16 * s:16 * s + 16]  # B[k][j] = act[j][16 s + k]
+                    acc += A @ B.t()
+            ref = torch.zeros(256, K, dtype=torch.float64)
+            ref[:wl.shape[0], :wl.shape[1]] = wl.double()
+            ref = ref[32 * wave:32 * wave + 32] @ x.double().t()
+            err = (acc.double() - ref).abs().max().item()
+            assert err < 2e-6 * max(1.0, ref.abs().max().item()), (l, wave, err)
+        step0 += steps
