@@ -154,7 +154,7 @@ def stream_ptr():
 def ptr(t):
     if t is None:
         return None
-    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.int64, torch.uint8), (t.device, t.dtype)
+    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.int64, torch.uint8, torch.bfloat16), (t.device, t.dtype)
     return C.c_void_p(t.data_ptr())
 
 
