@@ -535,6 +535,167 @@ __global__ __launch_bounds__(512, 2) void fused_sdf_x6_kernel(FusedArgs a, const
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// EXPERIMENTAL, NOT YET RUN ON HARDWARE (HOLD_FUSED_X6_VARIANT=1): the split-precision trunk with the limb split done
+// ONCE per activation, in the producing epilogue.  The on-the-fly variant above reaches only 36 % of its bf16-MFMA floor
+// because all 8 waves split the same activations (~110 VALU instructions per 12 MFMAs).  Here LDS holds the three bf16
+// limb planes of the activations instead of fp32 ([3][64 points][264] bf16 = 99 KiB; 128 points would need 198 KiB), the
+// MFMA loop is pure ds_read_b128 + MFMA, and a workgroup owns 64 points: wave w = features [32w, 32w+32) x 2 point
+// tiles, every weight fragment feeds 2 MFMAs per limb product (the 2.8 MiB limb pack streams once per 64 points).
+// Row stride 264 bf16 = 528 B = 16 (mod 256): ds_read_b128 of 16 consecutive rows hit 16 distinct 16-byte bank groups.
+constexpr int XP_PTS = 64, XP_ROW = 264, XP_PLANE = XP_PTS * XP_ROW;   // bf16 elements
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int STEPS>
+__device__ __forceinline__ void xp_layer(const bf16x8* __restrict__ wq, const bf16x8* __restrict__ nxt,
+                                         const __bf16* __restrict__ prow, f32x16 (&acc)[2], bf16x8 (&bn)[3]) {
+  // prow: plane 0, row of point li, column 8 hh; tile m adds 32 rows, limb t adds a plane, step s adds 16 columns
+  auto rd = [&](int s, bf16x8 (&al)[2][3]) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        al[m][t] = *reinterpret_cast<const bf16x8*>(prow + t * XP_PLANE + m * 32 * XP_ROW + s * 16);
+  };
+  bf16x8 an[2][3], b[3];
+  rd(0, an);
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    bf16x8 a[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) a[m][t] = an[m][t];
+    if (s + 1 < STEPS) rd(s + 1, an);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      b[t] = bn[t];
+      bn[t] = (s + 1 < STEPS) ? wq[(s + 1) * X6_STEP_UNITS + t * 512] : nxt[t * 512];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int pr = 0; pr < 6; ++pr) {
+      const int wl = (pr == 2 || pr == 3) ? 1 : (pr == 5 ? 2 : 0);   // (w limb, a limb): 00 01 10 11 02 20
+      const int al = (pr == 1 || pr == 3) ? 1 : (pr == 4 ? 2 : 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[wl], a[m][al], acc[m], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void fused_sdf_x6p_kernel(FusedArgs a, const bf16x8* __restrict__ wx6) {
+  constexpr int NTHR = 512;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16* planes = reinterpret_cast<__bf16*>(smem);                       // [3][64][264] bf16
+  float* emb = smem + 3 * XP_PLANE / 2;                                   // [64][40] fp32
+  float* red = emb + XP_PTS * ESTR;                                       // [8 waves][64] partial sdf
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, li = lane & 31;
+  const int nb = wave * 32 + 4 * hh;
+  const bf16x8* w0 = wx6 + wave * 64 + lane;
+
+  for (long blk = blockIdx.x; blk * XP_PTS < a.P; blk += gridDim.x) {
+    const long p0 = blk * XP_PTS;
+    bf16x8 bn[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) bn[t] = w0[t * 512];
+    for (int e = tid; e < XP_PTS * 48; e += NTHR) {   // embedding, zero-padded to K = 48, split into limbs
+      const int p = e / 48, j = e % 48;
+      float v = 0.f;
+      const long gp = p0 + p;
+      if (j < NE && gp < a.P) {
+        if (j < 3) {
+          v = a.xc[gp * a.ldx + j];
+        } else {
+          const int q = (j - 3) / 3, dim = (j - 3) % 3, k = q >> 1;
+          const float arg = a.xc[gp * a.ldx + dim] * (float)(1 << k);
+          v = (q & 1) ? cosf(arg) : sinf(arg);
+        }
+        if (a.barf) v *= a.barf[j];
+      }
+      if (j < ESTR) emb[p * ESTR + j] = v;
+      const __bf16 h1 = (__bf16)v;
+      const float r1 = v - (float)h1;
+      const __bf16 h2 = (__bf16)r1;
+      planes[p * XP_ROW + j] = h1;
+      planes[XP_PLANE + p * XP_ROW + j] = h2;
+      planes[2 * XP_PLANE + p * XP_ROW + j] = (__bf16)(r1 - (float)h2);
+    }
+    __syncthreads();
+
+    const __bf16* prow = planes + li * XP_ROW + hh * 8;
+    const bf16x8* wl = w0;
+    float part[2] = {0.f, 0.f};
+    for (int layer = 0; layer < 8; ++layer) {
+      f32x16 acc[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+      if (layer == 0) {
+        xp_layer<X6_L0_STEPS>(wl, wl + X6_L0_STEPS * X6_STEP_UNITS, prow, acc, bn);
+        wl += X6_L0_STEPS * X6_STEP_UNITS;
+      } else {
+        xp_layer<X6_LK_STEPS>(wl, layer < 7 ? wl + X6_LK_STEPS * X6_STEP_UNITS : w0, prow, acc, bn);
+        wl += X6_LK_STEPS * X6_STEP_UNITS;
+      }
+      __syncthreads();  // every wave has finished READING this layer's input
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n4 = nb + 8 * g;
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + layer * 256 + n4);
+        const f32x4 w8v = *reinterpret_cast<const f32x4*>(a.w8 + n4);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int p = m * 32 + li;
+          f32x4 v;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = softplus100(acc[m][4 * g + c] + bias[c]);
+          if (layer == 3 && n4 + 3 >= SKIP_OUT) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (n4 + c >= SKIP_OUT) v[c] = emb[p * ESTR + (n4 + c - SKIP_OUT)];
+          }
+          if (layer == 7) {  // sdf row of the last layer straight from the registers
+            part[m] += v[0] * w8v[0] + v[1] * w8v[1] + v[2] * w8v[2] + v[3] * w8v[3];
+          } else {
+            bf16x4 l1, l2, l3;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const __bf16 h1 = (__bf16)v[c];
+              const float r1 = v[c] - (float)h1;
+              const __bf16 h2 = (__bf16)r1;
+              l1[c] = h1;
+              l2[c] = h2;
+              l3[c] = (__bf16)(r1 - (float)h2);
+            }
+            __bf16* dst = planes + p * XP_ROW + n4;
+            *reinterpret_cast<bf16x4*>(dst) = l1;
+            *reinterpret_cast<bf16x4*>(dst + XP_PLANE) = l2;
+            *reinterpret_cast<bf16x4*>(dst + 2 * XP_PLANE) = l3;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // ---- sdf = w8 . h7 + b8: lanes hh = 0 / 1 hold complementary features of the same points ----
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const float s = part[m] + __shfl_xor(part[m], 32);
+      if (hh == 0) red[wave * XP_PTS + m * 32 + li] = s;
+    }
+    __syncthreads();
+    if (tid < XP_PTS) {
+      float s = a.b8;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) s += red[w * XP_PTS + tid];
+      if (p0 + tid < a.P) a.sdf[(p0 + tid) * a.lds] = s;
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" int64_t hold_fused_sdf_pack_floats(void) {
@@ -618,6 +779,21 @@ extern "C" int hold_fused_sdf_x6(const float* xc, int32_t ldx, int64_t P, const 
     attr_set = true;
   }
   FusedArgs a = {xc, ldx, (long)P, nullptr, bias, w8, b8, barf_w, sdf, ld_sdf};
+  const char* var = getenv("HOLD_FUSED_X6_VARIANT");
+  if (var && atoi(var) == 1) {  // limb planes in LDS, 64-point blocks (not yet run on hardware)
+    const size_t shp = (size_t)3 * XP_PLANE * 2 + (size_t)(XP_PTS * ESTR + 8 * XP_PTS) * sizeof(float);
+    static bool attr_p = false;
+    if (!attr_p) {
+      if (hipFuncSetAttribute((const void*)fused_sdf_x6p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)shp) != hipSuccess)
+        return HOLD_E_LAUNCH;
+      attr_p = true;
+    }
+    const long blocks = (P + XP_PTS - 1) / XP_PTS;
+    hipLaunchKernelGGL(fused_sdf_x6p_kernel, dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(512), shp,
+                       (hipStream_t)st, a, reinterpret_cast<const bf16x8*>(wpack_x6));
+    return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+  }
   const long blocks = (P + 127) / 128;
   hipLaunchKernelGGL(fused_sdf_x6_kernel, dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(512), sh, (hipStream_t)st,
                      a, reinterpret_cast<const bf16x8*>(wpack_x6));

@@ -126,9 +126,12 @@ def test_fused_sdf_matches_layered_path():
 
 @pytest.mark.skipif(__import__("os").environ.get("HOLD_TEST_EXPERIMENTAL") != "1",
                     reason="hold_fused_sdf_x6 is opt-in until validated on hardware (HOLD_TEST_EXPERIMENTAL=1)")
-def test_fused_sdf_x6_matches_fp32_fused():
-    """split-precision (3 bf16 limbs x 6 products) sampler trunk against the fp32-MFMA fused kernel"""
+@pytest.mark.parametrize("variant", ["0", "1"])
+def test_fused_sdf_x6_matches_fp32_fused(variant, monkeypatch):
+    """split-precision (3 bf16 limbs x 6 products) sampler trunk against the fp32-MFMA fused kernel
+    (variant 0: fp32 activations split on the fly; 1: limb planes in LDS, 64-point blocks)"""
     from hold_amd import field as F, kernels as K, synthetic as syn
+    monkeypatch.setenv("HOLD_FUSED_X6_VARIANT", variant)
     dev = _dev()
     sc = syn.make_scene(2)
     sd = {k: torch.as_tensor(v).to(dev) for k, v in syn.make_state_dict(sc, perturb=0.05).items()}
@@ -142,7 +145,7 @@ def test_fused_sdf_x6_matches_fp32_fused():
         rb = [sd[pre + f"rendering_network.lin{l}.bias"] for l in range(5)]
         pk = F.pack_weights(spec, iw, ib, rw, rb, need_bwd=False)
         x6 = F.pack_x6(pk["W"][:8])
-        P = 1000
+        P = 128 * 300 + 37
         g = torch.Generator().manual_seed(1)
         xc = torch.zeros(P, 4, device=dev)
         xc[:, :3] = (torch.rand(P, 3, generator=g) * 1.6 - 0.8).to(dev)
