@@ -107,6 +107,36 @@ def loss_fn_h(out, targets, flag, contact_idx):
     return d
 
 
+def project2d(K, pts_cam):
+    """project2d_batch (common/transforms.py:339-352): pixel coordinates of camera-space points; K [3,3] or [B,3,3]."""
+    Kb = K if K.dim() == 3 else K[None].expand(pts_cam.shape[0], -1, -1)
+    h = torch.bmm(Kb, pts_cam.permute(0, 2, 1)).permute(0, 2, 1)
+    return h[..., :2] / h[..., 2:3]
+
+
+def loss_fn_ih(out, targets, contact_idx, dist_thres=2.0 ** 2):
+    """two-hand loss, code/src/fitting/loss.py:120-165: object mask L1 on pixels covered by neither hand (x1000), per-frame
+    mean fingertip-zone -> object squared distance kept only above dist_thres (x0.05, each hand), and an MSE that pins the
+    projected hand vertices to their first-iteration positions (x1; the targets are cached in `targets` on first use)."""
+    vp = (1 - targets["right"]) * (1 - targets["left"])
+    lo = ((out["object.mask"] - targets["object"]).abs() * vp).sum() / vp.sum()
+    vo = out["object.v3d_c"]
+    contact = {}
+    for fl in ("right", "left"):
+        c = knn1_sqdist(out[f"{fl}.v3d_c"][:, contact_idx], vo).mean(dim=1)
+        contact[fl] = torch.where(c < dist_thres, torch.zeros_like(c), c).mean()
+    j2d = {fl: project2d(out["K"], out[f"{fl}.v3d_c"]) for fl in ("right", "left")}
+    if "j2d_r_target" not in targets:
+        targets["j2d_r_target"] = j2d["right"].detach().clone()
+        targets["j2d_l_target"] = j2d["left"].detach().clone()
+    d = {"mask_o": lo * 1000,
+         "v2d_r": torch.nn.functional.mse_loss(j2d["right"], targets["j2d_r_target"]),
+         "v2d_l": torch.nn.functional.mse_loss(j2d["left"], targets["j2d_l_target"]),
+         "contact_ro": contact["right"] * 0.05, "contact_lo": contact["left"] * 0.05}
+    d["loss"] = sum(d.values())
+    return d
+
+
 class FittingModel(torch.nn.Module):
     """Model of code/src/fitting/model.py:30-200 for one hand + object (the HO3D / in-the-wild case):
     free parameters = hand translation, object rotation + translation (fitting.py:57-67); everything else frozen."""
@@ -164,3 +194,45 @@ class FittingModel(torch.nn.Module):
             if opt.param_groups[0]["lr"] < tol_lr:
                 break
         return hist
+
+
+class FittingModelIH(torch.nn.Module):
+    """two-hand + object variant of Model (model.py:64-78 picks loss_fn_ih when both hands are present): free parameters =
+    both hand translations, object rotation + translation.  The reference also rasterises the two hand masks every
+    iteration (model.py:121-140) although loss_fn_ih never reads them; they are skipped here (no effect on the loss or
+    its gradients)."""
+
+    def __init__(self, hand_servers, obj_server, obj_faces, params, w2c, K, imsize, targets, contact_idx):
+        super().__init__()
+        self.hand_servers, self.obj_server, self.obj_faces = hand_servers, obj_server, obj_faces
+        self.w2c, self.K, self.imsize = w2c, K, imsize
+        self.targets, self.contact_idx = targets, contact_idx
+        free = ("right.transl", "left.transl", "object.global_orient", "object.transl")
+        self.frozen = {k: v for k, v in params.items() if k not in free}
+        self.r_transl = torch.nn.Parameter(params["right.transl"].clone())
+        self.l_transl = torch.nn.Parameter(params["left.transl"].clone())
+        self.o_rot = torch.nn.Parameter(params["object.global_orient"].clone())
+        self.o_transl = torch.nn.Parameter(params["object.transl"].clone())
+
+    def fwd_params(self):
+        f = self.frozen
+        B = self.r_transl.shape[0]
+        H, W = self.imsize
+        fx, fy, cx, cy = (float(self.K[0, 0]), float(self.K[1, 1]), float(self.K[0, 2]), float(self.K[1, 2]))
+        scale = f["scene_scale"].view(-1).expand(B).contiguous()
+        R, T = self.w2c[:, :3, :3], self.w2c[:, :3, 3:]
+        out = {"K": self.K}
+        for fl, tr in (("right", self.r_transl), ("left", self.l_transl)):
+            full_pose = torch.cat((f[f"{fl}.global_orient"], f[f"{fl}.pose"]), 1)
+            ho = self.hand_servers[fl](scale, tr, full_pose, f[f"{fl}.betas"].expand(B, -1).contiguous())
+            out[f"{fl}.v3d_c"] = rigid_tf(ho["verts"], R, T)
+        oo = self.obj_server(scale, self.o_transl, self.o_rot)
+        vo = rigid_tf(oo["verts"], R, T)
+        out["object.v3d_c"] = vo
+        out["object.mask"] = soft_silhouette(vo, self.obj_faces, fx, fy, cx, cy, H, W)
+        return out
+
+    def forward(self):
+        return loss_fn_ih(self.fwd_params(), self.targets, self.contact_idx)
+
+    fit = FittingModel.fit

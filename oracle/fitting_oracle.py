@@ -104,3 +104,35 @@ def loss_fn_h(out, targets, flag, contact_idx):
     vp = 1 - targets["object"]
     lh = ((out[f"{flag}.mask"] - targets[flag]).abs() * vp).sum() / vp.sum()
     return {"mask_o": lo * 1000, "mask_h": lh * 1000, "fine_ho": fine * 100.0, "loss": lo * 1000 + lh * 1000 + fine * 100.0}
+
+
+def project2d(K, pts_cam):
+    """project2d_batch, common/transforms.py:339-352."""
+    Kb = K if K.dim() == 3 else K[None].expand(pts_cam.shape[0], -1, -1)
+    h = torch.bmm(Kb, pts_cam.permute(0, 2, 1)).permute(0, 2, 1)
+    return h[..., :2] / h[..., 2:3]
+
+
+def loss_fn_ih(out, targets, contact_idx):
+    """code/src/fitting/loss.py:120-165 (statement by statement, incl. the in-place thresholding)."""
+    valid_pix = (1 - targets["right"]) * (1 - targets["left"])
+    err = (out["object.mask"] - targets["object"]).abs() * valid_pix
+    loss_mask_o = err.sum() / valid_pix.sum()
+    dist_thres = 2.0 ** 2
+    c_ro = knn1_mean(out["right.v3d_c"][:, contact_idx], out["object.v3d_c"]).mean(dim=1)
+    c_lo = knn1_mean(out["left.v3d_c"][:, contact_idx], out["object.v3d_c"]).mean(dim=1)
+    c_ro = c_ro.clone()
+    c_lo = c_lo.clone()
+    c_ro[c_ro < dist_thres] = 0
+    c_lo[c_lo < dist_thres] = 0
+    j2d_r = project2d(out["K"], out["right.v3d_c"])
+    j2d_l = project2d(out["K"], out["left.v3d_c"])
+    if "j2d_r_target" not in targets:
+        targets["j2d_r_target"] = j2d_r.detach().clone()
+        targets["j2d_l_target"] = j2d_l.detach().clone()
+    d = {"mask_o": loss_mask_o * 1000,
+         "v2d_r": torch.nn.functional.mse_loss(j2d_r, targets["j2d_r_target"]),
+         "v2d_l": torch.nn.functional.mse_loss(j2d_l, targets["j2d_l_target"]),
+         "contact_ro": c_ro.mean() * 0.05, "contact_lo": c_lo.mean() * 0.05}
+    d["loss"] = sum(d.values())
+    return d

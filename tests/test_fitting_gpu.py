@@ -123,3 +123,14 @@ def test_fitting_loop_reduces_loss():
     hist = m.fit(num_iterations=40)
     assert hist[-1] < 0.7 * hist[0], (hist[0], hist[-1])
     assert all(np.isfinite(hist))
+
+
+def test_fitting_losses_match_reference_golden():
+    """hold_amd.fitting.loss_fn_h / loss_fn_ih (HIP K=1 neighbour search + its backward inside) on the golden inputs
+    against the REFERENCE's outputs and gradients (tests/golden/fitting_losses.npz)."""
+    import os
+    from fitting_loss_cases import run_single_hand, run_two_hand
+    from hold_amd import fitting as ft
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fitting_losses.npz"))
+    assert run_two_hand(g, ft.loss_fn_ih, "cuda") < 2e-5
+    assert run_single_hand(g, ft.loss_fn_h, "cuda") < 2e-5

@@ -82,3 +82,12 @@ def test_train_forward_backward_matches_reference(gold_dir):
                  "background.bg_implicit_network.lin5.weight"]:
         gn = float(sdg[name].grad.norm())
         assert abs(gn - float(g["gradnorm." + name])) / float(g["gradnorm." + name]) < 5e-3, name
+
+
+def test_fitting_losses_match_reference(gold_dir):
+    """oracle/fitting_oracle.py:loss_fn_h / loss_fn_ih against the reference's own code/src/fitting/loss.py outputs"""
+    from fitting_loss_cases import run_single_hand, run_two_hand
+    from oracle import fitting_oracle as fo
+    g = _load(gold_dir, "fitting_losses.npz")
+    assert run_two_hand(g, fo.loss_fn_ih, "cpu") < 1e-6
+    assert run_single_hand(g, fo.loss_fn_h, "cpu") < 1e-6
