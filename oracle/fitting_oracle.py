@@ -11,6 +11,10 @@ follows pytorch3d's documented behaviour:
     distance (negative inside, distance to the nearest edge segment) is < blur_radius, in front of the camera.
     (the K = 100 cap only binds when more than 100 faces overlap a pixel; not modelled)
   * sigmoid_alpha_blend: alpha = 1 - prod_f (1 - sigmoid(-d_f / sigma)).
+
+The LOSS functions (loss_fn_h, loss_fn_ih: knn_points K=1, l1, project2d) ARE pinned: scripts/make_golden_fitting.py
+imports the reference's own code/src/fitting/loss.py under the shim and records its outputs and gradients in
+tests/golden/fitting_losses.npz; tests/test_oracle_golden.py checks this restatement against them (identical).
 """
 from __future__ import annotations
 
