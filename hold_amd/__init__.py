@@ -1,5 +1,5 @@
 """hold_amd -- MI355X-native volumetric hand-object rendering path for HOLD."""
-__all__ = ["build_from_scene"]
+__all__ = ["build_from_scene", "reference_holdnet", "install"]
 
 
 def build_from_scene(scene, state_dict=None, device="cuda", **kw):
@@ -21,3 +21,43 @@ def build_from_scene(scene, state_dict=None, device="cuda", **kw):
         bad = [m for m in missing if "human_layer" not in m and "object_model" not in m and "alpha_max_iter" not in m]
         assert not bad, bad
     return net.to(device)
+
+
+def reference_holdnet(opt, betas_r, betas_l, num_frames, args):
+    """HOLDNet with the REFERENCE's constructor signature (code/src/hold/hold_net.py:23-51; called at
+    code/src/hold/hold.py:41-47): the file-backed inputs are read from the places the reference reads them --
+    ./body_models/MANO_{RIGHT,LEFT}.pkl (mano/server.py:121-128) and ./data/<args.case>/build/data.npy
+    (object_model.py:15-27 via hold.py:33-34)."""
+    import os
+    import pickle
+
+    import numpy as np
+
+    from .hold_net import DEFAULT_SAMPLER, HOLDNet
+
+    entities = np.load(os.path.join("./data", args.case, "build/data.npy"), allow_pickle=True).item()["entities"]
+    mano = {}
+    for side, b in (("right", betas_r), ("left", betas_l)):
+        if b is not None:
+            with open(f"./body_models/MANO_{side.upper()}.pkl", "rb") as f:
+                mano[side] = pickle.load(f, encoding="latin1")
+    g = lambda o, k, d: getattr(o, k, d) if not isinstance(o, dict) else o.get(k, d)
+    return HOLDNet(g(opt, "scene_bounding_sphere", 6.0), betas_r, betas_l, num_frames, entities, mano,
+                   sampler_opt={**DEFAULT_SAMPLER, **dict(g(opt, "ray_sampler", None) or {})}, barf_s=g(args, "barf_s", 1000),
+                   barf_e=g(args, "barf_e", 10000), no_barf=g(args, "no_barf", False))
+
+
+def install():
+    """One-line drop-in for the reference tree: ``import hold_amd; hold_amd.install()`` before
+    ``HOLD(opt, args)`` is constructed rebinds the name ``HOLDNet`` that code/src/hold/hold.py:12 imported, so
+    hold.py:41-47 builds the MI355X model; everything else in the reference (Lightning loop, Loss, datasets) is untouched.
+    Raises ImportError if the reference's ``src`` package is not importable."""
+    import importlib
+
+    hold_mod = importlib.import_module("src.hold.hold")
+    hold_mod.HOLDNet = reference_holdnet
+    try:
+        importlib.import_module("src.hold.hold_net").HOLDNet = reference_holdnet
+    except ImportError:
+        pass
+    return reference_holdnet

@@ -104,3 +104,40 @@ def test_x6_limb_pack_layout_and_arithmetic():
             err = (acc.double() - ref).abs().max().item()
             assert err < 2e-6 * max(1.0, ref.abs().max().item()), (l, wave, err)
         step0 += steps
+
+
+def test_reference_signature_drop_in(tmp_path, monkeypatch):
+    """hold_amd.install() rebinds the HOLDNet name code/src/hold/hold.py:12 imported; the replacement takes the
+    reference's constructor arguments and reads MANO pickles / data.npy from the reference's relative paths."""
+    import pickle
+    import sys
+    import types
+
+    import numpy as np
+
+    import hold_amd
+
+    sc = syn.make_scene(3)
+    (tmp_path / "body_models").mkdir()
+    (tmp_path / "data" / "synth" / "build").mkdir(parents=True)
+    for side, r in (("RIGHT", True), ("LEFT", False)):
+        pickle.dump(syn.make_mano_model(r), open(tmp_path / "body_models" / f"MANO_{side}.pkl", "wb"))
+    np.save(tmp_path / "data" / "synth" / "build" / "data.npy", {"entities": sc["entities"]}, allow_pickle=True)
+    monkeypatch.chdir(tmp_path)
+    # stand-ins for the reference's modules (the real ones need Lightning etc.)
+    for name in ("src", "src.hold", "src.hold.hold", "src.hold.hold_net"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        monkeypatch.setitem(sys.modules, name, m)
+    sys.modules["src.hold.hold"].HOLDNet = object
+    sys.modules["src.hold.hold_net"].HOLDNet = object
+    ctor = hold_amd.install()
+    assert sys.modules["src.hold.hold"].HOLDNet is ctor and sys.modules["src.hold.hold_net"].HOLDNet is ctor
+    opt = types.SimpleNamespace(scene_bounding_sphere=sc["scene_bounding_sphere"],
+                                ray_sampler=dict(near=0.0, N_samples=64, N_samples_eval=128, N_samples_extra=32, eps=0.1,
+                                                 beta_iters=10, max_total_iters=5))
+    args = types.SimpleNamespace(case="synth", barf_s=1000, barf_e=10000, no_barf=False)
+    net = ctor(opt, sc["entities"]["right"]["mean_shape"], None, sc["n_frames"], args)
+    assert sorted(net.nodes.keys()) == ["object", "right"]
+    names = set(net.state_dict().keys())
+    assert "nodes.right.implicit_network.lin0.weight_v" in names and "background.bg_implicit_network.lin0.weight" in names
