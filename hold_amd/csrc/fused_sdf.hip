@@ -14,6 +14,7 @@
 // (one coalesced 1 KiB global load per 8 k-values per wave, prefetched two chunks ahead).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "../../include/hold_hip.h"
@@ -739,8 +740,15 @@ extern "C" int hold_fused_sdf(const float* xc, int32_t ldx, int64_t P, const flo
                        (hipStream_t)st, a);
   } else if (variant == 128) {
     const long blocks = (P + 127) / 128;
+    int dbg = 0;
+    if (const char* e = getenv("HOLD_FUSED_DEBUG")) {  // timing ablations only: parts of the kernel are skipped
+      static bool warned = false;
+      if (!warned) fprintf(stderr, "libholdhip: HOLD_FUSED_DEBUG=%s -- timing ablation, hold_fused_sdf results are WRONG\n", e);
+      warned = true;
+      dbg = atoi(e);
+    }
     hipLaunchKernelGGL((fused_sdf_kernel<4, 1>), dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(512), sh128,
-                       (hipStream_t)st, a, getenv("HOLD_FUSED_DEBUG") ? atoi(getenv("HOLD_FUSED_DEBUG")) : 0);
+                       (hipStream_t)st, a, dbg);
   } else {
     const long blocks = (P + 63) / 64;
     const long res = 2L * n_cu;

@@ -16,6 +16,7 @@
 // LDS row stride 36 floats makes the b128 fragment reads and the b128 staging writes conflict-free.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "../../include/hold_hip.h"
@@ -584,7 +585,12 @@ static int launch_gemm(const hold_gemm_desc& d, hipStream_t s) {
   // stagger the second half of a full persistent grid by ~half a tile (s_sleep(127) = 8128 cycles each)
   const int nkk = (d.K + BKc - 1) / BKc;
   int stagger = (tiles >= 2 * resident) ? (nkk * BKc >= 192 ? 2 : 1) : 0;
-  if (const char* dbg = getenv("HOLD_GEMM_DEBUG")) stagger |= atoi(dbg);  // timing ablations only (wrong results)
+  if (const char* dbg = getenv("HOLD_GEMM_DEBUG")) {  // timing ablations only: parts of the kernel are skipped
+    static bool warned = false;
+    if (!warned) fprintf(stderr, "libholdhip: HOLD_GEMM_DEBUG=%s -- timing ablation, hold_gemm_nt results are WRONG\n", dbg);
+    warned = true;
+    stagger |= atoi(dbg);
+  }
   switch (d.epilogue) {
 #define HOLD_CASE(E) \
   case E: hipLaunchKernelGGL((gemm_nt_kernel<E, NT>), grid, block, 0, s, d, tiles, stagger); break;
