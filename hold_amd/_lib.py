@@ -117,6 +117,7 @@ SIGNATURES = {
     "hold_diag_mfma_lds": [_P, _P, _I, _I, _I, _P],
     "hold_fused_sdf": [_P, _I, _L, _P, _P, _P, _F, _P, _P, _I, _P],
     "hold_chain": [C.POINTER(ChainDesc), _P],
+    "hold_mesh_sdf": [_P, _I, _L, _P, _I, _I, _P, _I, _F, _P, _P, _P],
     "hold_fused_sdf_x6": [_P, _I, _L, _P, _P, _P, _F, _P, _P, _I, _P],
     "hold_mano_lbs_fwd": [C.POINTER(ManoModel), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "hold_mano_lbs_bwd": [C.POINTER(ManoModel), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],

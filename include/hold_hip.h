@@ -297,6 +297,18 @@ int64_t hold_chain_pack_floats(int32_t first_chunks, int32_t n_layers);
 int hold_chain(const hold_chain_desc* d, hold_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training loss-target geometry without kaolin (hold_amd/csrc/geometry.hip):
+ * signed distance (negative inside) of pts [B][P][3] to a closed triangle mesh, replacing
+ * kaolin.metrics.trianglemesh.point_to_mesh_distance + kaolin.ops.mesh.check_sign of compute_mano_cano_sdf /
+ * check_off_in_surface_points_cano_mesh (code/src/engine/volsdf_utils.py:172-217).
+ * verts [B][V][3] (or [V][3] with verts_shared = 1), faces [F][3] int32.  cull_dist > 0 with aabb [B][6]
+ * (min xyz, max xyz of the frame's vertices): points farther than cull_dist from the box skip the face loop and get
+ * that (lower-bound, positive) distance -- enough for the reference's off-surface test (min distance > threshold).
+ * ---------------------------------------------------------------------------------------- */
+int hold_mesh_sdf(const float* pts, int32_t B, int64_t P, const float* verts, int32_t verts_shared, int32_t V,
+                  const int32_t* faces, int32_t F, float cull_dist, const float* aabb, float* sd, hold_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Pose-refinement inner loop (hold_amd/csrc/silhouette.hip).
  * Soft silhouette = pytorch3d MeshRenderer(MeshRasterizer(blur_radius, faces_per_pixel=100), SoftSilhouetteShader)
  * as configured by code/src/fitting/utils.py:101-158 and called at code/src/fitting/model.py:136-138:

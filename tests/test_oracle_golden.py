@@ -91,3 +91,26 @@ def test_fitting_losses_match_reference(gold_dir):
     g = _load(gold_dir, "fitting_losses.npz")
     assert run_two_hand(g, fo.loss_fn_ih, "cpu") < 1e-6
     assert run_single_hand(g, fo.loss_fn_h, "cpu") < 1e-6
+
+
+def test_geometry_oracle_matches_closed_form_sdf():
+    """oracle/geometry_oracle.py (point->mesh distance + winding-number sign, the kaolin replacement of SURVEY 8(f-2))
+    against the closed-form signed distance of a box and the half-space inside test of a tetrahedron."""
+    from oracle import geometry_oracle as go
+    g = torch.Generator().manual_seed(0)
+    h = (0.3, 0.2, 0.5)
+    v, f = go.box_mesh(h)
+    p = (torch.rand(4000, 3, generator=g, dtype=torch.float64) * 2 - 1) * 0.8
+    ref = go.box_sdf(p, h)
+    assert float((go.mesh_sdf(p, v, f) - ref).abs().max()) < 1e-12
+    assert float((go.mesh_sdf(p.float(), v.float(), f).double() - ref).abs().max()) < 1e-6
+    tv = torch.tensor([[0., 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], dtype=torch.float64)
+    tf = torch.tensor([[0, 2, 1], [0, 1, 3], [0, 3, 2], [1, 2, 3]])
+    pt = torch.rand(2000, 3, generator=g, dtype=torch.float64) * 1.4 - 0.2
+    inside = (pt.min(1).values > 0) & (pt.sum(1) < 1)
+    assert torch.equal(go.mesh_sdf(pt, tv, tf) < 0, inside)
+    # per-ray masks of check_off_in_surface_points_cano_mesh (volsdf_utils.py:189-217): 10 rays x 8 samples
+    x = p[:80].reshape(1, 80, 3)
+    off, ins = go.check_off_in_surface_points_cano_mesh(v[None], f, x, 10, threshold=0.05)
+    m = ref[:80].reshape(10, 8).min(1).values
+    assert torch.equal(off, m > 0.05) and torch.equal(ins, m <= 0.0)
