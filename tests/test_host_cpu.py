@@ -141,3 +141,47 @@ def test_reference_signature_drop_in(tmp_path, monkeypatch):
     assert sorted(net.nodes.keys()) == ["object", "right"]
     names = set(net.state_dict().keys())
     assert "nodes.right.implicit_network.lin0.weight_v" in names and "background.bg_implicit_network.lin0.weight" in names
+
+
+def test_chain_weight_packs_follow_the_header_layout():
+    """field.pack_weights: pk["fused"] (forward-type sweeps) and pk["chain_bwd"] (descending sweeps, M_j = W_l^T with
+    l = 7 - j, zero padded) are in the fragment order include/hold_hip.h documents for hold_chain / hold_fused_sdf:
+    [K/8 chunks][8 n-tiles][2 halves h][32 rows i][4] = M[32*nt + i][8*chunk + 4*h + c]."""
+    import torch
+    from hold_amd import field as F
+
+    g = torch.Generator().manual_seed(0)
+    spec = F.FieldSpec("object")
+    iw = [torch.randn(256, 39, generator=g)] + [torch.randn(256, 256, generator=g) for _ in range(2)] + \
+         [torch.randn(217, 256, generator=g)] + [torch.randn(256, 256, generator=g) for _ in range(4)] + \
+         [torch.randn(257, 256, generator=g)]
+    ib = [torch.randn(w.shape[0], generator=g) for w in iw]
+    rw = [torch.randn(256, spec.rin_dim, generator=g)] + [torch.randn(256, 256, generator=g) for _ in range(3)] + \
+         [torch.randn(3, 256, generator=g)]
+    rb = [torch.randn(w.shape[0], generator=g) for w in rw]
+    pk = F.pack_weights(spec, iw, ib, rw, rb, need_bwd=True)
+
+    def unpack(flat, K):
+        return flat.reshape(K // 8, 8, 2, 32, 4).permute(1, 3, 0, 2, 4).reshape(256, K)
+
+    wpack, bias8 = pk["fused"]
+    off = 0
+    for l in range(8):
+        K = 40 if l == 0 else 256
+        m = unpack(wpack[off:off + 256 * K], K)
+        off += 256 * K
+        ref = torch.zeros(256, K)
+        ref[:pk["W"][l].shape[0], :pk["W"][l].shape[1]] = pk["W"][l]
+        assert torch.equal(m, ref), l
+        assert torch.equal(bias8[l, :pk["b"][l].shape[0]], pk["b"][l])
+    assert off == wpack.numel()
+    cb = pk["chain_bwd"]
+    assert cb.numel() == 7 * 65536
+    for j in range(7):
+        l = 7 - j
+        m = unpack(cb[j * 65536:(j + 1) * 65536], 256)
+        ref = torch.zeros(256, 256)
+        ref[:pk["W"][l].shape[1], :pk["W"][l].shape[0]] = pk["W"][l].t()
+        assert torch.equal(m, ref), j
+    # the skip folding: layer 4 carries the 1/sqrt(2) of cat([x, input]) / sqrt(2)  (shape_net.py:122-123)
+    assert torch.allclose(pk["W"][4], iw[4] / 2 ** 0.5)
