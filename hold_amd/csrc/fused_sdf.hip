@@ -558,6 +558,16 @@ __device__ __forceinline__ void xp_layer(const bf16x8* __restrict__ wq, const bf
       for (int t = 0; t < 3; ++t)
         al[m][t] = *reinterpret_cast<const bf16x8*>(prow + t * XP_PLANE + m * 32 * XP_ROW + s * 16);
   };
+  // four independent accumulation chains (2 point tiles x even / odd limb products): consecutive MFMAs on one
+  // accumulator are 4 issues apart whatever the dependent-accumulator latency of the bf16 MFMA is
+  f32x16 part[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      part[m][0][r] = 0.f;
+      part[m][1][r] = 0.f;
+    }
   bf16x8 an[2][3], b[3];
   rd(0, an);
 #pragma unroll
@@ -579,10 +589,15 @@ __device__ __forceinline__ void xp_layer(const bf16x8* __restrict__ wq, const bf
       const int wl = (pr == 2 || pr == 3) ? 1 : (pr == 5 ? 2 : 0);   // (w limb, a limb): 00 01 10 11 02 20
       const int al = (pr == 1 || pr == 3) ? 1 : (pr == 4 ? 2 : 0);
 #pragma unroll
-      for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[wl], a[m][al], acc[m], 0, 0, 0);
+      for (int m = 0; m < 2; ++m)
+        part[m][pr & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[wl], a[m][al], part[m][pr & 1], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = part[m][0][r] + part[m][1][r];
 }
 
 __global__ __launch_bounds__(512, 2) void fused_sdf_x6p_kernel(FusedArgs a, const bf16x8* __restrict__ wx6) {
