@@ -28,6 +28,23 @@ namespace {
 
 constexpr int BM = 128;
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct Limbs3 { bf16x8 l[3]; };
+// exact three-limb bf16 decomposition of 8 fp32 values (x = l0 + l1 + l2, each limb the bf16 rounding of the residual)
+__device__ __forceinline__ Limbs3 split8s(const float (&x)[8]) {
+  Limbs3 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 h1 = (__bf16)x[e];
+    const float r1 = x[e] - (float)h1;
+    const __bf16 h2 = (__bf16)r1;
+    o.l[0][e] = h1;
+    o.l[1][e] = h2;
+    o.l[2][e] = (__bf16)(r1 - (float)h2);
+  }
+  return o;
+}
+
 // softplus(y, beta=100, threshold=20) = y for 100y > 20, else (max(z,0) + log1p(exp(-|z|))) / 100, z = 100y.
 // exp/log run on the hardware transcendental units (v_exp_f32 / v_log_f32); log1p switches to its series
 // for small arguments, so the absolute error stays ~1e-9 (x 1/100), the class of fp32 GEMM reordering noise.
@@ -405,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
 // version is bound by the CU's texture-address path (64 VMEM instructions per 64 MFMAs per wave).  Fragments are
 // column reads of the row-major LDS image (ds_read_b32, consecutive lanes = consecutive banks, conflict-free).
 // KT = 32-wide k tiles per wave: 2 -> block tile 128 n x 128 k (32 rows per stage), 4 -> 128 n x 256 k (16 rows).
-template <int KT>
+template <int KT, bool X6 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restrict__ R, int ldr,
                                                            const float* __restrict__ X, int ldx, int P, int N, int K,
                                                            int splits, float* __restrict__ part,
@@ -495,34 +512,71 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restri
     if (c + 1 < c_end) stage(c + 1, buf ^ 1);
     const float* pr = sR + buf * PC * 128 + (hh * STEPS) * 128 + wn * 64 + li;
     const float* px = sX + buf * PC * BKW + (hh * STEPS) * BKW + wk * (32 * KT) + li;
-    // fragments one step ahead, pinned: left alone the scheduler issues them ~2 MFMAs before their use
-    float avn[2], bvn[KT];
+    if constexpr (X6) {
+      // EXPERIMENTAL split precision (opt-in HOLD_WGRAD_X6=1, not yet run on hardware): both operands are split into
+      // three bf16 limbs as they leave LDS, six limb products per 16 reduction rows on v_mfma_f32_32x32x16_bf16.
+      // Lane (hh, li) supplies rows 16 step + 8 hh .. + 7 of column li of its n / k tile to both operands.
+      const float* pr6 = sR + buf * PC * 128 + (hh * 8) * 128 + wn * 64 + li;
+      const float* px6 = sX + buf * PC * BKW + (hh * 8) * BKW + wk * (32 * KT) + li;
 #pragma unroll
-    for (int a = 0; a < 2; ++a) avn[a] = pr[a * 32];
+      for (int st = 0; st < PC / 16; ++st) {
+        Limbs3 la[2], lb[KT];
 #pragma unroll
-    for (int b = 0; b < KT; ++b) bvn[b] = px[b * 32];
+        for (int a = 0; a < 2; ++a) {
+          float x[8];
 #pragma unroll
-    for (int st = 0; st < STEPS; ++st) {
-      float av[2], bv[KT];
+          for (int e = 0; e < 8; ++e) x[e] = pr6[(st * 16 + e) * 128 + a * 32];
+          bsum[a] += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+          la[a] = split8s(x);
+        }
 #pragma unroll
-      for (int a = 0; a < 2; ++a) av[a] = avn[a];
+        for (int b = 0; b < KT; ++b) {
+          float x[8];
 #pragma unroll
-      for (int b = 0; b < KT; ++b) bv[b] = bvn[b];
-      if (st + 1 < STEPS) {
+          for (int e = 0; e < 8; ++e) x[e] = px6[(st * 16 + e) * BKW + b * 32];
+          lb[b] = split8s(x);
+        }
 #pragma unroll
-        for (int a = 0; a < 2; ++a) avn[a] = pr[(st + 1) * 128 + a * 32];
+        for (int pr = 0; pr < 6; ++pr) {
+          const int il = (pr == 2 || pr == 3) ? 1 : (pr == 5 ? 2 : 0);   // (R limb, X limb): 00 01 10 11 02 20
+          const int jl = (pr == 1 || pr == 3) ? 1 : (pr == 4 ? 2 : 0);
 #pragma unroll
-        for (int b = 0; b < KT; ++b) bvn[b] = px[(st + 1) * BKW + b * 32];
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < KT; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la[a].l[il], lb[b].l[jl], acc[a][b], 0, 0, 0);
+        }
       }
-      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      // fragments one step ahead, pinned: left alone the scheduler issues them ~2 MFMAs before their use
+      float avn[2], bvn[KT];
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < 2; ++a) avn[a] = pr[a * 32];
 #pragma unroll
-        for (int b = 0; b < KT; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
-      bsum[0] += av[0];
-      bsum[1] += av[1];
-      __builtin_amdgcn_sched_barrier(0);
+      for (int b = 0; b < KT; ++b) bvn[b] = px[b * 32];
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        float av[2], bv[KT];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) av[a] = avn[a];
+#pragma unroll
+        for (int b = 0; b < KT; ++b) bv[b] = bvn[b];
+        if (st + 1 < STEPS) {
+#pragma unroll
+          for (int a = 0; a < 2; ++a) avn[a] = pr[(st + 1) * 128 + a * 32];
+#pragma unroll
+          for (int b = 0; b < KT; ++b) bvn[b] = px[(st + 1) * BKW + b * 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < KT; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        bsum[0] += av[0];
+        bsum[1] += av[1];
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     stage_wait();
   }
@@ -641,7 +695,11 @@ extern "C" int hold_wgrad(const float* R, int32_t ldr, const float* X, int32_t l
   float* part_b = db ? workspace + (long)splits * N * K : nullptr;
   const bool lds_ok = !(ldr & 3) && !(ldx & 3) && !((uintptr_t)R & 15) && !((uintptr_t)X & 15) && ldr >= 4 && ldx >= 4 &&
                       !getenv("HOLD_WGRAD_DIRECT");
-  if (lds_ok && K > 128) {
+  if (lds_ok && getenv("HOLD_WGRAD_X6")) {  // EXPERIMENTAL split-precision path (128 x 128 tiles)
+    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+    hipLaunchKernelGGL((wgrad_lds_kernel<2, true>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits,
+                       part, part_b);
+  } else if (lds_ok && K > 128) {
     const int tiles = ((N + 127) / 128) * ((K + 255) / 256);
     const long ch = ((long)P + 15) / 16;
     if (splits > ch) splits = (int)(ch > 0 ? ch : 1);

@@ -157,3 +157,22 @@ def test_fused_sdf_x6_matches_fp32_fused(variant, monkeypatch):
         K.fused_sdf_x6(xc, P, x6, bias8, pk["w8_sdf"], float(pk["b8_sdf"]), barf, out)
         err = float((out - ref).abs().max())
         assert err < 5e-6 * max(1.0, float(ref.abs().max())), (kind, err)
+
+
+@pytest.mark.skipif(__import__("os").environ.get("HOLD_TEST_EXPERIMENTAL") != "1",
+                    reason="split-precision wgrad (HOLD_WGRAD_X6=1) has not run on hardware yet: HOLD_TEST_EXPERIMENTAL=1")
+@pytest.mark.parametrize("P,N,K", [(4096, 256, 256), (5000, 217, 256), (777, 256, 40), (130, 3, 256)])
+def test_wgrad_x6_matches_fp64(P, N, K, monkeypatch):
+    from hold_amd import gemm
+    dev = _dev()
+    g = torch.Generator().manual_seed(P + N + K)
+    R = torch.randn(P, N, generator=g).to(dev)
+    X = torch.randn(P, K, generator=g).to(dev)
+    ref = R.double().t() @ X.double()
+    refb = R.double().sum(0)
+    monkeypatch.setenv("HOLD_WGRAD_X6", "1")
+    dW = torch.zeros(N, K, device=dev)
+    db = torch.zeros(N, device=dev)
+    gemm.wgrad(R, X, dW, db)
+    assert float((dW.double() - ref).abs().max()) < 3e-5 * max(1.0, float(ref.abs().max()))
+    assert float((db.double() - refb).abs().max()) < 3e-5 * max(1.0, float(refb.abs().max()))
