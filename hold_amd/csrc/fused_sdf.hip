@@ -389,10 +389,39 @@ __device__ __forceinline__ Limbs3 split8(const f32x4& x0, const f32x4& x1) {
   return o;
 }
 
+// The same decomposition by TRUNCATION, integer / full-rate ops only (no v_cvt_pk_bf16_f32; HOLD_X6_SPLIT=trunc):
+// limb 1 = the top 16 bits of x, limb 2 = the top 16 bits of the exact residual, limb 3 = the second residual, which has
+// at most 8 significant bits left and is a bf16 already.  x = l1 + l2 + l3 still holds exactly; the limbs are at most
+// twice as large as the rounded ones, so the dropped limb products stay below 2^-23 relative.
+__device__ __forceinline__ Limbs3 split8_trunc(const f32x4& x0, const f32x4& x1) {
+  uint32_t h1[8], h2[8], h3[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = e < 4 ? x0[e] : x1[e - 4];
+    h1[e] = __builtin_bit_cast(uint32_t, x) & 0xffff0000u;
+    const float r1 = x - __builtin_bit_cast(float, h1[e]);
+    h2[e] = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
+    h3[e] = __builtin_bit_cast(uint32_t, r1 - __builtin_bit_cast(float, h2[e]));
+  }
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  Limbs3 o;
+  u32x4 p1, p2, p3;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {  // dword j = bf16 elements 2j (low half) and 2j + 1 (high half): v_perm_b32
+    p1[j] = __builtin_amdgcn_perm(h1[2 * j + 1], h1[2 * j], 0x07060302u);
+    p2[j] = __builtin_amdgcn_perm(h2[2 * j + 1], h2[2 * j], 0x07060302u);
+    p3[j] = __builtin_amdgcn_perm(h3[2 * j + 1], h3[2 * j], 0x07060302u);
+  }
+  o.l[0] = __builtin_bit_cast(bf16x8, p1);
+  o.l[1] = __builtin_bit_cast(bf16x8, p2);
+  o.l[2] = __builtin_bit_cast(bf16x8, p3);
+  return o;
+}
+
 // MFMA phase of one layer.  wq: this wave-lane's pointer to the layer's first step in the limb pack; nxt: the step that
 // follows the layer's last one (next layer, or the pack's start for the next 128 points).  bn holds the limbs of the
 // step about to run (requested one step = 24 MFMAs per wave earlier).
-template <int STEPS>
+template <int STEPS, bool TRUNC>
 __device__ __forceinline__ void x6_layer(const bf16x8* __restrict__ wq, const bf16x8* __restrict__ nxt,
                                          const float* __restrict__ arow, f32x16 (&acc)[4], bf16x8 (&bn)[3]) {
   constexpr int Q = 2 * STEPS;
@@ -408,8 +437,8 @@ __device__ __forceinline__ void x6_layer(const bf16x8* __restrict__ wq, const bf
   Limbs3 la[2], lb[2];
   bf16x8 b[3];
   rd(0, xn);
-  la[0] = split8(xn[0], xn[1]);
-  la[1] = split8(xn[2], xn[3]);
+  la[0] = (TRUNC ? split8_trunc(xn[0], xn[1]) : split8(xn[0], xn[1]));
+  la[1] = (TRUNC ? split8_trunc(xn[2], xn[3]) : split8(xn[2], xn[3]));
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
     const int s = q >> 1, m0 = 2 * (q & 1);
@@ -439,8 +468,8 @@ __device__ __forceinline__ void x6_layer(const bf16x8* __restrict__ wq, const bf
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[m0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[2], la[j].l[0], acc[m0 + j], 0, 0, 0);
     if (q + 1 < Q) {
-      lb[0] = split8(xn[0], xn[1]);
-      lb[1] = split8(xn[2], xn[3]);
+      lb[0] = (TRUNC ? split8_trunc(xn[0], xn[1]) : split8(xn[0], xn[1]));
+      lb[1] = (TRUNC ? split8_trunc(xn[2], xn[3]) : split8(xn[2], xn[3]));
     }
     __builtin_amdgcn_sched_barrier(0);
     la[0] = lb[0];
@@ -448,6 +477,7 @@ __device__ __forceinline__ void x6_layer(const bf16x8* __restrict__ wq, const bf
   }
 }
 
+template <bool TRUNC>
 __global__ __launch_bounds__(512, 2) void fused_sdf_x6_kernel(FusedArgs a, const bf16x8* __restrict__ wx6) {
   constexpr int PTS = 128, NTHR = 512;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -490,10 +520,10 @@ __global__ __launch_bounds__(512, 2) void fused_sdf_x6_kernel(FusedArgs a, const
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
       if (layer == 0) {
-        x6_layer<X6_L0_STEPS>(wl, wl + X6_L0_STEPS * X6_STEP_UNITS, arow, acc, bn);
+        x6_layer<X6_L0_STEPS, TRUNC>(wl, wl + X6_L0_STEPS * X6_STEP_UNITS, arow, acc, bn);
         wl += X6_L0_STEPS * X6_STEP_UNITS;
       } else {
-        x6_layer<X6_LK_STEPS>(wl, layer < 7 ? wl + X6_LK_STEPS * X6_STEP_UNITS : w0, arow, acc, bn);
+        x6_layer<X6_LK_STEPS, TRUNC>(wl, layer < 7 ? wl + X6_LK_STEPS * X6_STEP_UNITS : w0, arow, acc, bn);
         wl += X6_LK_STEPS * X6_STEP_UNITS;
       }
       __syncthreads();  // every wave has finished READING this layer's input
@@ -796,8 +826,10 @@ extern "C" int hold_fused_sdf_x6(const float* xc, int32_t ldx, int64_t P, const 
     n_cu = prop.multiProcessorCount;
   }
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)fused_sdf_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) !=
-        hipSuccess)
+    if (hipFuncSetAttribute((const void*)fused_sdf_x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sh) != hipSuccess ||
+        hipFuncSetAttribute((const void*)fused_sdf_x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sh) != hipSuccess)
       return HOLD_E_LAUNCH;
     attr_set = true;
   }
@@ -818,7 +850,12 @@ extern "C" int hold_fused_sdf_x6(const float* xc, int32_t ldx, int64_t P, const 
     return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
   }
   const long blocks = (P + 127) / 128;
-  hipLaunchKernelGGL(fused_sdf_x6_kernel, dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(512), sh, (hipStream_t)st,
-                     a, reinterpret_cast<const bf16x8*>(wpack_x6));
+  const char* sp = getenv("HOLD_X6_SPLIT");
+  if (sp && sp[0] == 't')
+    hipLaunchKernelGGL(fused_sdf_x6_kernel<true>, dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(512), sh,
+                       (hipStream_t)st, a, reinterpret_cast<const bf16x8*>(wpack_x6));
+  else
+    hipLaunchKernelGGL(fused_sdf_x6_kernel<false>, dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(512), sh,
+                       (hipStream_t)st, a, reinterpret_cast<const bf16x8*>(wpack_x6));
   return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
 }

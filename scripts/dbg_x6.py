@@ -12,8 +12,10 @@ rw = [eff(pre + f"rendering_network.lin{l}") for l in range(5)]; rb = [sd[pre + 
 pk = F.pack_weights(spec, iw, ib, rw, rb, need_bwd=False)
 x6 = F.pack_x6(pk["W"][:8])
 wpack, bias8 = pk["fused"]
-for P, var in ((1000, "0"), (128 * 4096, "0"), (1000, "1"), (128 * 4096, "1")):
+for P, var, split in ((1000, "0", "rne"), (128 * 4096, "0", "rne"), (1000, "0", "trunc"), (128 * 4096, "0", "trunc"),
+                      (1000, "1", "rne"), (128 * 4096, "1", "rne")):
     os.environ["HOLD_FUSED_X6_VARIANT"] = var
+    os.environ["HOLD_X6_SPLIT"] = split
     xc = torch.zeros(P, 4, device=dev); xc[:, :3] = torch.rand(P, 3, device=dev) * 1.6 - 0.8
     ref = torch.empty(P, 1, device=dev); out = torch.full((P, 1), 7.0, device=dev)
     try:
@@ -21,7 +23,7 @@ for P, var in ((1000, "0"), (128 * 4096, "0"), (1000, "1"), (128 * 4096, "1")):
         K.fused_sdf_x6(xc, P, x6, bias8, pk["w8_sdf"], float(pk["b8_sdf"]), None, out)
         torch.cuda.synchronize()
         d = (out - ref).abs()
-        print("variant", var, "P", P, "maxerr", float(d.max()), "mean", float(d.mean()), "refmax", float(ref.abs().max()), "n7", int((out == 7).sum()),
+        print("variant", var, "split", split, "P", P, "maxerr", float(d.max()), "mean", float(d.mean()), "refmax", float(ref.abs().max()), "n7", int((out == 7).sum()),
               "nan", int(torch.isnan(out).sum()), "first", out[:4, 0].tolist(), ref[:4, 0].tolist(), flush=True)
         if P > 1000:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

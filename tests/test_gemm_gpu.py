@@ -126,12 +126,13 @@ def test_fused_sdf_matches_layered_path():
 
 @pytest.mark.skipif(__import__("os").environ.get("HOLD_TEST_EXPERIMENTAL") != "1",
                     reason="hold_fused_sdf_x6 is opt-in until validated on hardware (HOLD_TEST_EXPERIMENTAL=1)")
-@pytest.mark.parametrize("variant", ["0", "1"])
-def test_fused_sdf_x6_matches_fp32_fused(variant, monkeypatch):
+@pytest.mark.parametrize("variant,split", [("0", "rne"), ("0", "trunc"), ("1", "rne")])
+def test_fused_sdf_x6_matches_fp32_fused(variant, split, monkeypatch):
     """split-precision (3 bf16 limbs x 6 products) sampler trunk against the fp32-MFMA fused kernel
     (variant 0: fp32 activations split on the fly; 1: limb planes in LDS, 64-point blocks)"""
     from hold_amd import field as F, kernels as K, synthetic as syn
     monkeypatch.setenv("HOLD_FUSED_X6_VARIANT", variant)
+    monkeypatch.setenv("HOLD_X6_SPLIT", split)
     dev = _dev()
     sc = syn.make_scene(2)
     sd = {k: torch.as_tensor(v).to(dev) for k, v in syn.make_state_dict(sc, perturb=0.05).items()}
