@@ -44,6 +44,30 @@ __device__ __forceinline__ Limbs3 split8s(const float (&x)[8]) {
   }
   return o;
 }
+// the same by truncation (v_and / v_sub / v_perm only), see fused_sdf.hip:split8_trunc
+__device__ __forceinline__ Limbs3 split8s_trunc(const float (&x)[8]) {
+  uint32_t h1[8], h2[8], h3[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    h1[e] = __builtin_bit_cast(uint32_t, x[e]) & 0xffff0000u;
+    const float r1 = x[e] - __builtin_bit_cast(float, h1[e]);
+    h2[e] = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
+    h3[e] = __builtin_bit_cast(uint32_t, r1 - __builtin_bit_cast(float, h2[e]));
+  }
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 p1, p2, p3;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    p1[j] = __builtin_amdgcn_perm(h1[2 * j + 1], h1[2 * j], 0x07060302u);
+    p2[j] = __builtin_amdgcn_perm(h2[2 * j + 1], h2[2 * j], 0x07060302u);
+    p3[j] = __builtin_amdgcn_perm(h3[2 * j + 1], h3[2 * j], 0x07060302u);
+  }
+  Limbs3 o;
+  o.l[0] = __builtin_bit_cast(bf16x8, p1);
+  o.l[1] = __builtin_bit_cast(bf16x8, p2);
+  o.l[2] = __builtin_bit_cast(bf16x8, p3);
+  return o;
+}
 
 // softplus(y, beta=100, threshold=20) = y for 100y > 20, else (max(z,0) + log1p(exp(-|z|))) / 100, z = 100y.
 // exp/log run on the hardware transcendental units (v_exp_f32 / v_log_f32); log1p switches to its series
@@ -422,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
 // version is bound by the CU's texture-address path (64 VMEM instructions per 64 MFMAs per wave).  Fragments are
 // column reads of the row-major LDS image (ds_read_b32, consecutive lanes = consecutive banks, conflict-free).
 // KT = 32-wide k tiles per wave: 2 -> block tile 128 n x 128 k (32 rows per stage), 4 -> 128 n x 256 k (16 rows).
-template <int KT, bool X6 = false>
+template <int KT, int X6 = 0>  // X6: 0 fp32 MFMA, 1 bf16 x 6 limb products (rounded limbs), 2 (truncated limbs)
 __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restrict__ R, int ldr,
                                                            const float* __restrict__ X, int ldx, int P, int N, int K,
                                                            int splits, float* __restrict__ part,
@@ -512,7 +536,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restri
     if (c + 1 < c_end) stage(c + 1, buf ^ 1);
     const float* pr = sR + buf * PC * 128 + (hh * STEPS) * 128 + wn * 64 + li;
     const float* px = sX + buf * PC * BKW + (hh * STEPS) * BKW + wk * (32 * KT) + li;
-    if constexpr (X6) {
+    if constexpr (X6 != 0) {
       // EXPERIMENTAL split precision (opt-in HOLD_WGRAD_X6=1, not yet run on hardware): both operands are split into
       // three bf16 limbs as they leave LDS, six limb products per 16 reduction rows on v_mfma_f32_32x32x16_bf16.
       // Lane (hh, li) supplies rows 16 step + 8 hh .. + 7 of column li of its n / k tile to both operands.
@@ -527,14 +551,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restri
 #pragma unroll
           for (int e = 0; e < 8; ++e) x[e] = pr6[(st * 16 + e) * 128 + a * 32];
           bsum[a] += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
-          la[a] = split8s(x);
+          la[a] = (X6 == 2) ? split8s_trunc(x) : split8s(x);
         }
 #pragma unroll
         for (int b = 0; b < KT; ++b) {
           float x[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) x[e] = px6[(st * 16 + e) * BKW + b * 32];
-          lb[b] = split8s(x);
+          lb[b] = (X6 == 2) ? split8s_trunc(x) : split8s(x);
         }
 #pragma unroll
         for (int pr = 0; pr < 6; ++pr) {
@@ -697,8 +721,13 @@ extern "C" int hold_wgrad(const float* R, int32_t ldr, const float* X, int32_t l
                       !getenv("HOLD_WGRAD_DIRECT");
   if (lds_ok && getenv("HOLD_WGRAD_X6")) {  // EXPERIMENTAL split-precision path (128 x 128 tiles)
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-    hipLaunchKernelGGL((wgrad_lds_kernel<2, true>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits,
-                       part, part_b);
+    const char* sp = getenv("HOLD_X6_SPLIT");
+    if (sp && sp[0] == 't')
+      hipLaunchKernelGGL((wgrad_lds_kernel<2, 2>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits,
+                         part, part_b);
+    else
+      hipLaunchKernelGGL((wgrad_lds_kernel<2, 1>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits,
+                         part, part_b);
   } else if (lds_ok && K > 128) {
     const int tiles = ((N + 127) / 128) * ((K + 255) / 256);
     const long ch = ((long)P + 15) / 16;
