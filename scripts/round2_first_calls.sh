@@ -19,5 +19,7 @@ done
 echo "== split-precision wgrad (HOLD_WGRAD_X6=1): micro + end to end"
 timeout 100 python scripts/bench_gemm.py 2>&1 | grep wgrad
 HOLD_WGRAD_X6=1 timeout 100 python scripts/bench_gemm.py 2>&1 | grep wgrad
+HOLD_WGRAD_X6=1 HOLD_X6_SPLIT=trunc timeout 100 python scripts/bench_gemm.py 2>&1 | grep wgrad
+HOLD_TEST_EXPERIMENTAL=1 HOLD_X6_SPLIT=trunc timeout 100 python -m pytest tests/test_gemm_gpu.py -q -m gpu -k wgrad_x6 2>&1 | tail -2
 HOLD_WGRAD_X6=1 timeout 300 python -m pytest tests/test_path_gpu.py tests/test_chain_gpu.py -q -m gpu 2>&1 | tail -3
 HOLD_WGRAD_X6=1 timeout 200 python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('wgrad x6', d['value'], d['ms_per_step'], d['roofline']['kernels'].get('wgrad_kernel'))"
