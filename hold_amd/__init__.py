@@ -1,5 +1,5 @@
 """hold_amd -- MI355X-native volumetric hand-object rendering path for HOLD."""
-__all__ = ["build_from_scene", "reference_holdnet", "install"]
+__all__ = ["build_from_scene", "reference_holdnet", "install", "xdict"]
 
 
 def build_from_scene(scene, state_dict=None, device="cuda", **kw):
@@ -23,41 +23,77 @@ def build_from_scene(scene, state_dict=None, device="cuda", **kw):
     return net.to(device)
 
 
-def reference_holdnet(opt, betas_r, betas_l, num_frames, args):
-    """HOLDNet with the REFERENCE's constructor signature (code/src/hold/hold_net.py:23-51; called at
-    code/src/hold/hold.py:41-47): the file-backed inputs are read from the places the reference reads them --
-    ./body_models/MANO_{RIGHT,LEFT}.pkl (mano/server.py:121-128) and ./data/<args.case>/build/data.npy
-    (object_model.py:15-27 via hold.py:33-34)."""
-    import os
-    import pickle
+def _get(o, k, d=None):
+    if o is None:
+        return d
+    return o.get(k, d) if isinstance(o, dict) else getattr(o, k, d)
 
-    import numpy as np
 
+def _reference_class():
+    """class factory (hold_net imports torch; keep ``import hold_amd`` light)."""
     from .hold_net import DEFAULT_SAMPLER, HOLDNet
 
-    entities = np.load(os.path.join("./data", args.case, "build/data.npy"), allow_pickle=True).item()["entities"]
-    mano = {}
-    for side, b in (("right", betas_r), ("left", betas_l)):
-        if b is not None:
-            with open(f"./body_models/MANO_{side.upper()}.pkl", "rb") as f:
-                mano[side] = pickle.load(f, encoding="latin1")
-    g = lambda o, k, d: getattr(o, k, d) if not isinstance(o, dict) else o.get(k, d)
-    return HOLDNet(g(opt, "scene_bounding_sphere", 6.0), betas_r, betas_l, num_frames, entities, mano,
-                   sampler_opt={**DEFAULT_SAMPLER, **dict(g(opt, "ray_sampler", None) or {})}, barf_s=g(args, "barf_s", 1000),
-                   barf_e=g(args, "barf_e", 10000), no_barf=g(args, "no_barf", False))
+    class ReferenceHOLDNet(HOLDNet):
+        """HOLDNet with the REFERENCE's constructor ``HOLDNet(opt, betas_r, betas_l, num_frames, args)``
+        (code/src/hold/hold_net.py:23-51; built at code/src/hold/hold.py:41-47).  File-backed inputs are read from
+        where the reference reads them: ./body_models/MANO_{RIGHT,LEFT}.pkl (mano/server.py:121-128) and
+        ./data/<args.case>/build/data.npy (object_model.py:15-27, mano/params.py:20-23, obj/params.py:15-17), the
+        per-frame pose tables are loaded from it (``params.load_params(args.case)``), the SDF nets get the
+        ``init: geometry`` scheme of the config, and ``init_network()`` honours ``args.shape_init``."""
+
+        def __init__(self, opt, betas_r, betas_l, num_frames, args):
+            import os
+            import pickle
+
+            import numpy as np
+
+            ents = np.load(os.path.join("./data", args.case, "build/data.npy"), allow_pickle=True).item()["entities"]
+            mano = {}
+            for side, b in (("right", betas_r), ("left", betas_l)):
+                if b is not None:
+                    with open(f"./body_models/MANO_{side.upper()}.pkl", "rb") as f:
+                        mano[side] = pickle.load(f, encoding="latin1")
+            inet = _get(opt, "implicit_network")
+            super().__init__(_get(opt, "scene_bounding_sphere", 6.0), betas_r, betas_l, num_frames, ents, mano,
+                             sampler_opt={**DEFAULT_SAMPLER, **dict(_get(opt, "ray_sampler") or {})},
+                             barf_s=_get(args, "barf_s", 1000), barf_e=_get(args, "barf_e", 10000),
+                             no_barf=_get(args, "no_barf", False), init=_get(inet, "init", "geometry"),
+                             init_bias=_get(inet, "bias", 0.6))
+            self.args, self.opt = args, opt
+            self.init_network(_get(args, "shape_init", "") or "")
+
+    return ReferenceHOLDNet
+
+
+_REF_CLS = None
+
+
+def reference_holdnet(opt, betas_r, betas_l, num_frames, args):
+    """construct ``ReferenceHOLDNet`` (kept as a function for callers that rebind a constructor name)."""
+    global _REF_CLS
+    if _REF_CLS is None:
+        _REF_CLS = _reference_class()
+    return _REF_CLS(opt, betas_r, betas_l, num_frames, args)
 
 
 def install():
     """One-line drop-in for the reference tree: ``import hold_amd; hold_amd.install()`` before
     ``HOLD(opt, args)`` is constructed rebinds the name ``HOLDNet`` that code/src/hold/hold.py:12 imported, so
-    hold.py:41-47 builds the MI355X model; everything else in the reference (Lightning loop, Loss, datasets) is untouched.
+    hold.py:41-47 builds the MI355X model; the reference's Lightning module, ``Loss`` and datasets stay as they are and
+    receive ``common.xdict.xdict`` outputs (hold_amd.xdict.output_class).
     Raises ImportError if the reference's ``src`` package is not importable."""
     import importlib
 
+    global _REF_CLS
+    from . import xdict as xd
+
     hold_mod = importlib.import_module("src.hold.hold")
-    hold_mod.HOLDNet = reference_holdnet
+    xd._OUT_CLS = None  # re-resolve: the reference's common.xdict is importable now
+    if _REF_CLS is None:
+        _REF_CLS = _reference_class()
+    hold_mod.HOLDNet = _REF_CLS
     try:
-        importlib.import_module("src.hold.hold_net").HOLDNet = reference_holdnet
+        importlib.import_module("src.hold.hold_net").HOLDNet = _REF_CLS
     except ImportError:
         pass
-    return reference_holdnet
+    return _REF_CLS

@@ -75,6 +75,10 @@ class CompositeDesc(C.Structure):
     ]
 
 
+class LossNodes(C.Structure):
+    _fields_ = [("mask_prob", C.c_void_p * 3), ("off", C.c_void_p * 3), ("d_mask", C.c_void_p * 3)]
+
+
 class ManoModel(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("v_template", "shapedirs", "posedirs", "J_regressor", "parents",
                                           "lbs_weights", "pose_mean", "tfs_c_inv")]
@@ -91,6 +95,8 @@ SIGNATURES = {
     "hold_embed_bwd2": [_P, _I, _I, _P, _L, _P, _I, _P, _I, _P, _I, _P, _I, _P],
     "hold_knn_invlbs_fwd": [_P, _I, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _P],
     "hold_invskin_fwd": [_P, _I, _L, _L, _P, _P, _I, _P, _I, _P],
+    "hold_raygen": [_P, _P, _P, _I, _L, _L, _P, _P, _P],
+    "hold_skin_fwd": [_P, _I, _L, _L, _P, _P, _I, _P, _I, _P],
     "hold_invskin_bwd": [_P, _I, _P, _P, _I, _L, _L, _P, _I, _P, _P],
     "hold_normal_fwd": [_P, _I, _P, _P, _I, _L, _L, _P, _I, _P],
     "hold_normal_bwd": [_P, _I, _P, _P, _I, _L, _L, _P, _I, _P, _I, _P, _P],
@@ -118,6 +124,13 @@ SIGNATURES = {
     "hold_fused_sdf": [_P, _I, _L, _P, _P, _P, _F, _P, _P, _I, _P],
     "hold_chain": [C.POINTER(ChainDesc), _P],
     "hold_mesh_sdf": [_P, _I, _L, _P, _I, _I, _P, _I, _F, _P, _P, _P],
+    "hold_pixel_loss_fwd": [_P, _P, _P, _P, _L, _I, C.POINTER(LossNodes), _P, _P, _P],
+    "hold_pixel_loss_bwd": [_P, _P, _P, _P, _L, _I, C.POINTER(LossNodes), _P, _P, _P, _P],
+    "hold_sumsq": [_P, _L, _P, _I, _P, _P],
+    "hold_adam_step": [_P, _P, _P, _P, _L, _L, _F, _F, _F, _F, _F, _I, _F, _F, _P, _P],
+    "hold_mt_classify": [_P, _I, _F, _P, _P, _P, _P, _P],
+    "hold_mt_vertices": [_P, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P],
+    "hold_mt_triangles": [_P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P],
     "hold_fused_sdf_x6": [_P, _I, _L, _P, _P, _P, _F, _P, _P, _I, _P],
     "hold_mano_lbs_fwd": [C.POINTER(ManoModel), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "hold_mano_lbs_bwd": [C.POINTER(ManoModel), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
@@ -128,6 +141,7 @@ def _declare(L):
     L.hold_abi_version.restype = C.c_int
     L.hold_wgrad_workspace_floats.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     L.hold_wgrad_workspace_floats.restype = C.c_int64
+    L.hold_reduce_workspace_floats.restype = C.c_int64
     L.hold_fused_sdf_pack_floats.restype = C.c_int64
     L.hold_fused_sdf_x6_pack_bytes.restype = C.c_int64
     L.hold_chain_pack_floats.argtypes = [C.c_int32, C.c_int32]
@@ -155,7 +169,7 @@ def stream_ptr():
 def ptr(t):
     if t is None:
         return None
-    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.int64, torch.uint8, torch.bfloat16), (t.device, t.dtype)
+    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.int64, torch.uint8, torch.int8, torch.bool, torch.bfloat16), (t.device, t.dtype)
     return C.c_void_p(t.data_ptr())
 
 

@@ -263,6 +263,55 @@ __global__ void invskin_kernel(const float* __restrict__ x, int ldx, long P, lon
   o[2] = Ai[6] * bx + Ai[7] * by + Ai[8] * bz;
 }
 
+// ray generation: get_camera_params + lift of code/src/datasets/utils.py:230-282 for the pose-matrix
+// branch, with the per-ray broadcast of the camera centre (mano_node.py:90-92) fused in: one thread per ray.
+__global__ void raygen_kernel(const float* __restrict__ uv, const float* __restrict__ pose, const float* __restrict__ intr,
+                              int ld_intr, long n_rays, long rays_per_frame, float* __restrict__ dirs,
+                              float* __restrict__ cam) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rays) return;
+  const long b = r / rays_per_frame;
+  const float* K = intr + b * ld_intr * ld_intr;
+  const float* P = pose + b * 16;
+  const float fx = K[0], sk = K[1], cx = K[2], fy = K[ld_intr + 1], cy = K[ld_intr + 2];
+  const float x = uv[r * 2], y = uv[r * 2 + 1];
+  const float xl = (x - cx + cy * sk / fy - sk * y / fy) / fx;
+  const float yl = (y - cy) / fy;
+  // world = P [xl, yl, 1, 1]^T ; direction = world - camera centre (P[:3,3])
+  const float wx = P[0] * xl + P[1] * yl + P[2] + P[3], wy = P[4] * xl + P[5] * yl + P[6] + P[7],
+              wz = P[8] * xl + P[9] * yl + P[10] + P[11];
+  const float dx = wx - P[3], dy = wy - P[7], dz = wz - P[11];
+  const float inv = 1.0f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);  // F.normalize eps
+  dirs[r * 3] = dx * inv;
+  dirs[r * 3 + 1] = dy * inv;
+  dirs[r * 3 + 2] = dz * inv;
+  cam[r * 3] = P[3];
+  cam[r * 3 + 1] = P[7];
+  cam[r * 3 + 2] = P[11];
+}
+
+// forward LBS of query points (cano -> deformed): x' = (sum_j w_j T_j) [x;1]   (mano/deformer.py:168-169)
+__global__ void skin_fwd_kernel(const float* __restrict__ x, int ldx, long P, long ppf, const float* __restrict__ w,
+                                const float* __restrict__ tfs, int nb, float* __restrict__ xd, int ldxd) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const float* T = tfs + (p / ppf) * nb * 16;
+  float wl[NB];
+  if (w) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) wl[j] = w[p * NB + j];
+  } else {
+    wl[0] = 1.f;
+  }
+  float M[12], s;
+  blend_tf(wl, T, nb, M, s);
+  const float a = x[p * ldx], b = x[p * ldx + 1], c = x[p * ldx + 2];
+  float* o = xd + p * ldxd;
+  o[0] = M[0] * a + M[1] * b + M[2] * c + M[3];
+  o[1] = M[4] * a + M[5] * b + M[6] * c + M[7];
+  o[2] = M[8] * a + M[9] * b + M[10] * c + M[11];
+}
+
 // ---------------------------------------------------------------------------------------------
 // canonical normal: n = normalize(g . J^-1), J = sum_j w_j T_j[:3,:3]   (volsdf_utils.py:68-81,100-102)
 // ---------------------------------------------------------------------------------------------
@@ -526,6 +575,26 @@ extern "C" int hold_invskin_fwd(const float* x, int32_t ldx, int64_t P, int64_t 
   if (P == 0) return HOLD_OK;
   hipLaunchKernelGGL(invskin_kernel, dim3(nblk(P)), dim3(256), 0, (hipStream_t)st, x, ldx, (long)P, (long)pts_per_frame,
                      n_bones == 1 ? nullptr : w, tfs, n_bones, xc, ldxc);
+  return ok();
+}
+
+extern "C" int hold_raygen(const float* uv, const float* pose, const float* intrinsics, int32_t ld_intr, int64_t n_rays,
+                           int64_t rays_per_frame, float* ray_dirs, float* cam_loc, hold_stream_t st) {
+  if (!uv || !pose || !intrinsics || !ray_dirs || !cam_loc || (ld_intr != 3 && ld_intr != 4) || rays_per_frame <= 0)
+    return HOLD_E_ARG;
+  if (n_rays == 0) return HOLD_OK;
+  hipLaunchKernelGGL(raygen_kernel, dim3(nblk(n_rays)), dim3(256), 0, (hipStream_t)st, uv, pose, intrinsics, ld_intr,
+                     (long)n_rays, (long)rays_per_frame, ray_dirs, cam_loc);
+  return ok();
+}
+
+extern "C" int hold_skin_fwd(const float* x, int32_t ldx, int64_t P, int64_t pts_per_frame, const float* w,
+                             const float* tfs, int32_t n_bones, float* xd, int32_t ldxd, hold_stream_t st) {
+  if (!x || !tfs || !xd || (n_bones != 1 && n_bones != NB) || (n_bones == NB && !w) || pts_per_frame <= 0)
+    return HOLD_E_ARG;
+  if (P == 0) return HOLD_OK;
+  hipLaunchKernelGGL(skin_fwd_kernel, dim3(nblk(P)), dim3(256), 0, (hipStream_t)st, x, ldx, (long)P, (long)pts_per_frame,
+                     n_bones == 1 ? nullptr : w, tfs, n_bones, xd, ldxd);
   return ok();
 }
 

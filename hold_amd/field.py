@@ -94,7 +94,7 @@ def pack_x6(W8):
 
 
 def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
-    """iw/ib: 9 effective ImplicitNet weights/biases ([out,in] as nn.Linear); rw/rb: 5 RenderingNet ones.
+    """iw/ib: 9 effective ImplicitNet weights/biases ([out,in] as nn.Linear); rw/rb: 5 RenderingNet ones (or None).
     Returns the re-laid-out (and, for sweeps that contract over the output index, transposed) copies the
     kernels read.  Tiny (<= 256x304) device ops once per step."""
     dev = iw[0].device
@@ -142,6 +142,8 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
         m[:W[l].shape[1], :W[l].shape[0]] = W[l].t()
         parts.append(m.reshape(8, 32, 32, 2, 4).permute(2, 0, 3, 1, 4).reshape(-1))
     pk["chain_bwd"] = torch.cat(parts).contiguous()
+    if rw is None:  # implicit net only (ImplicitNet.forward / gradient)
+        return pk
     r0 = torch.zeros(256, spec.Kr, device=dev)
     r0[:, :spec.rin_dim] = rw[0]
     R = [r0, rw[1].contiguous(), rw[2].contiguous(), rw[3].contiguous(), rw[4].contiguous()]
@@ -165,6 +167,7 @@ class NodeField:
         self.spec = spec
         self.pool = Pool(device)
         self.device = device
+        self.gen = 0  # bumped by every call that overwrites the saved activations (checked by the autograd glue)
 
     # ------------------------------------------------------------------ deformation
     def _deform(self, x, P, ppf, dfm, want_w):
@@ -223,6 +226,7 @@ class NodeField:
 
     def sdf_only(self, pk, x, P, ppf, dfm, barf_w, out_sdf):
         """no-grad SDF query of the sampler (sdf_func_with_deformer, volsdf_utils.py:150-169).  out_sdf [P,1]."""
+        self.gen += 1  # overwrites the pooled canonical points a pending backward would read
         xc, _ = self._deform(x, P, ppf, dfm, want_w=False)
         if FUSED_SDF and FUSED_SDF_X6:
             K.fused_sdf_x6(xc, P, pk["fused_x6"], pk["fused"][1], pk["w8_sdf"], float(pk["b8_sdf"]), barf_w, out_sdf)
@@ -239,6 +243,7 @@ class NodeField:
     def forward(self, pk, x, P, ppf, dfm, barf_w, pose_embed, time_code, training):
         """-> dict(sdf [P,1], rgb [P,4], normal = rin[:,3:6], xc, feat = rin[:,14:270])."""
         sp, pool = self.spec, self.pool
+        self.gen += 1
         xc, w_def = self._deform(x, P, ppf, dfm, want_w=training)
         in0, h = self._trunk(pk, xc, P, barf_w, keep_all=True)
         rin = pool.get("rin", P, sp.Kr)
@@ -322,7 +327,8 @@ class NodeField:
         if USE_CHAIN:
             r = [pool.get(f"rbc{l}", P, 256) for l in range(7)] + [r7]
             K.chain(K.CHAIN_DSP, P, r7, pk["chain_bwd"], 7, 32, skip_layer=3, aux1=[h[l - 1] for l in range(7, 0, -1)],
-                    aux2=[a2[l - 1] for l in range(7, 0, -1)], out=[r[l - 1] for l in range(7, 0, -1)])
+                    aux2=None if a2 is None else [a2[l - 1] for l in range(7, 0, -1)],
+                    out=[r[l - 1] for l in range(7, 0, -1)])
             if ebar is not None:
                 K.copy_cols(r[3][:, sp.skip_out:], ebar, sp.E, P)
             for l in range(7, 0, -1):
@@ -333,32 +339,69 @@ class NodeField:
             return r[0]
         rb_ = [pool.get(f"rb{i}", P, 256) for i in range(2)]
         cur = r7
+        A2 = lambda i: None if a2 is None else a2[i]
         for l in range(7, 0, -1):
             nxt = rb_[1] if cur is rb_[0] else rb_[0]
             if l == 4:
                 G.wgrad(cur, h[3], dW[4], dWb[4], accumulate=True)
                 if ebar is not None:
-                    G.gemm_nt(cur, WT[4], nxt[:, :sp.skip_out], epi=G.EPI_MUL_DSP, aux1=h[3], aux2=a2[3], N=256,
+                    G.gemm_nt(cur, WT[4], nxt[:, :sp.skip_out], epi=G.EPI_MUL_DSP, aux1=h[3], aux2=A2(3), N=256,
                               n_split=sp.skip_out, out_raw=ebar)
                 else:
-                    G.gemm_nt(cur, WT[4], nxt[:, :sp.skip_out], epi=G.EPI_MUL_DSP, aux1=h[3], aux2=a2[3],
+                    G.gemm_nt(cur, WT[4], nxt[:, :sp.skip_out], epi=G.EPI_MUL_DSP, aux1=h[3], aux2=A2(3),
                               N=sp.skip_out)
                 # keep K-padding columns of r_3 (217..219) zero for the next GEMM
                 nxt[:, sp.skip_out:sp.skip_pad].zero_()
             elif l == 3:
                 G.wgrad(cur, h[2], dW[3], dWb[3], N=sp.skip_out, accumulate=True)
-                G.gemm_nt(cur, WT[3], nxt, epi=G.EPI_MUL_DSP, aux1=h[2], aux2=a2[2], K=sp.skip_pad)
+                G.gemm_nt(cur, WT[3], nxt, epi=G.EPI_MUL_DSP, aux1=h[2], aux2=A2(2), K=sp.skip_pad)
             else:
                 G.wgrad(cur, h[l - 1], dW[l], dWb[l], accumulate=True)
-                G.gemm_nt(cur, WT[l], nxt, epi=G.EPI_MUL_DSP, aux1=h[l - 1], aux2=a2[l - 1])
+                G.gemm_nt(cur, WT[l], nxt, epi=G.EPI_MUL_DSP, aux1=h[l - 1], aux2=A2(l - 1))
             cur = nxt
         return cur
+
+    # ------------------------------------------------------------------ ImplicitNet.forward (shape_net.py:84-130)
+    def sdf_feat_forward(self, pk, xc, P, barf_w):
+        """canonical points xc [P,4] -> out [P,260] = (256 features | sdf | pad); keeps h for sdf_feat_backward."""
+        sp, pool = self.spec, self.pool
+        self.gen += 1
+        in0, h = self._trunk(pk, xc, P, barf_w, keep_all=True)
+        out = pool.get("oc_out", P, 260)
+        G.gemm_nt(h[7], pk["W"][8], out, bias=pk["b"][8], N=257)
+        self.saved = dict(P=P, xc=xc, in0=in0, h=h, barf_w=barf_w, pk=pk)
+        return out
+
+    def sdf_feat_backward(self, ob):
+        """first-order backward of sdf_feat_forward: ob [P,260] = d/d(features | sdf | 0) -> (g_iw[9], g_ib[9], d_x [P,4])."""
+        sp, pool, sv = self.spec, self.pool, self.saved
+        P, pk, h, xc = sv["P"], sv["pk"], sv["h"], sv["xc"]
+        dev = self.device
+        W, WT = pk["W"], pk["WT"]
+        dW = [torch.zeros_like(m) for m in W]
+        dWb = [torch.zeros_like(b) for b in pk["b"]]
+        G.wgrad(ob, h[7], dW[8], dWb[8], N=257, accumulate=True)
+        r7 = pool.get("r7", P, 256)
+        G.gemm_nt(ob, WT[8], r7, epi=G.EPI_MUL_DSP, aux1=h[7], K=260)
+        ebar = pool.get("ebar", P, sp.K0)
+        cur = self._first_order_sweep(pk, h, None, r7, sv["in0"], dW, dWb, ebar, P)
+        G.wgrad(cur, sv["in0"], dW[0], dWb[0], K=sp.K0, accumulate=True)
+        G.gemm_nt(cur, WT[0], ebar, N=sp.K0, accumulate=True)
+        xbar = pool.get("xbar", P, 4)
+        K.embed_bwd(xc, sp.L, P, ebar, xbar, barf_w=sv["barf_w"])
+        d0 = torch.zeros(256, pk["iw0_cols"], device=dev)
+        d0[:, :sp.E] = dW[0][:, :sp.E]
+        g_iw = [d0, dW[1], dW[2], dW[3], dW[4] / math.sqrt(2), dW[5], dW[6], dW[7],
+                torch.cat([dW[8][256:257], dW[8][:256]], 0)]
+        g_ib = dWb[:8] + [torch.cat([dWb[8][256:257], dWb[8][:256]])]
+        return g_iw, g_ib, xbar
 
     # ------------------------------------------------------------------ eikonal samples (a13)
     def grad_points_forward(self, pk, xc, P, barf_w):
         """d sdf / d x at free canonical points (compute_gradient_samples, volsdf_utils.py:19-48): trunk forward +
         reverse sweep only (no deformer, no colour net).  Keeps h / t / ge for grad_points_backward."""
         sp, pool = self.spec, self.pool
+        self.gen += 1
         in0, h = self._trunk(pk, xc, P, barf_w, keep_all=True)
         WT = pk["WT"]
         t = [pool.get(f"t{l}", P, 256) for l in range(8)]

@@ -68,3 +68,46 @@ class PointInSpace:
         local = pc_input + torch.randn_like(pc_input) * (self.local_sigma if local_sigma is None else local_sigma)
         glob = torch.rand(B, int(N * global_ratio), D, device=pc_input.device) * (gs * 2) - gs
         return torch.cat([local, glob], dim=1)
+
+
+def subdivide_loop(verts, faces):
+    """One iteration of Loop subdivision of a triangle mesh (what ``trimesh.remesh.subdivide_loop(v, f, iterations=1)``
+    does for hold_utils.subdivide_cano, code/src/hold/hold_utils.py:137-146): every triangle -> 4; edge ("odd")
+    vertices at 3/8 (a+b) + 1/8 (c+d) for interior edges, midpoints on boundary edges; original ("even") vertices
+    relaxed with Loop's beta(k).  verts [V,3] float, faces [F,3] int64 -> ([V+E,3], [4F,3]); new vertex order =
+    even vertices then one vertex per unique edge.  Runs on the tensors' device (a once-per-200-steps host-side op).
+    trimesh is not available in this image: the scheme is restated from Loop's rules, parity with trimesh unpinned."""
+    V, dev = verts.shape[0], verts.device
+    f = faces.long()
+    e = torch.stack([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], 1).reshape(-1, 2)  # 3 half-edges per face
+    opp = torch.stack([f[:, 2], f[:, 0], f[:, 1]], 1).reshape(-1)  # vertex opposite each half-edge
+    lo, hi = e.min(1).values, e.max(1).values
+    key = lo * V + hi
+    uniq, inverse, counts = torch.unique(key, return_inverse=True, return_counts=True)
+    E = uniq.shape[0]
+    a, b = uniq // V, uniq % V
+    opp_sum = torch.zeros(E, 3, device=dev, dtype=verts.dtype).index_add_(0, inverse, verts[opp])
+    interior = (counts == 2)[:, None]
+    odd = torch.where(interior, 0.375 * (verts[a] + verts[b]) + 0.125 * opp_sum, 0.5 * (verts[a] + verts[b]))
+    # even vertices: neighbours through unique edges
+    nsum = torch.zeros(V, 3, device=dev, dtype=verts.dtype)
+    nsum.index_add_(0, a, verts[b]).index_add_(0, b, verts[a])
+    k = torch.zeros(V, device=dev, dtype=verts.dtype)
+    one = torch.ones(E, device=dev, dtype=verts.dtype)
+    k.index_add_(0, a, one).index_add_(0, b, one)
+    kk = k.clamp(min=1)
+    beta = (40.0 - (2.0 * torch.cos(2 * torch.pi / kk) + 3) ** 2) / (64 * kk)
+    even = beta[:, None] * nsum + (1 - kk * beta)[:, None] * verts
+    # boundary vertices: 1/8 (sum of the two boundary neighbours) + 3/4 v
+    bmask = counts == 1
+    if bool(bmask.any()):
+        bs = torch.zeros(V, 3, device=dev, dtype=verts.dtype)
+        bs.index_add_(0, a[bmask], verts[b[bmask]]).index_add_(0, b[bmask], verts[a[bmask]])
+        on_b = torch.zeros(V, dtype=torch.bool, device=dev)
+        on_b[a[bmask]] = True
+        on_b[b[bmask]] = True
+        even = torch.where(on_b[:, None], 0.125 * bs + 0.75 * verts, even)
+    oi = inverse.reshape(-1, 3) + V  # odd vertex on edges (01, 12, 20) of each face
+    nf = torch.stack([f[:, 0], oi[:, 0], oi[:, 2], oi[:, 0], f[:, 1], oi[:, 1], oi[:, 2], oi[:, 1], f[:, 2],
+                      oi[:, 0], oi[:, 1], oi[:, 2]], 1).reshape(-1, 3)
+    return torch.cat([even, odd], 0), nf

@@ -20,8 +20,12 @@ import torch.nn.functional as F
 from . import gemm as G
 from . import kernels as K
 from .field import FEAT, FieldSpec, NodeField, Pool, pack_weights, pad4
+from .fitting import seal_mano_mesh
+from .geometry import (PointInSpace, check_off_in_surface_points_cano_mesh, compute_mano_cano_sdf,
+                       sample_on_barycentric_mesh, subdivide_loop)
 from .mano import MANOServer, ObjectServer
 from .sampler import ErrorBoundSampler, UniformSampler
+from .xdict import output_class
 
 CLASS_ID = {"object": 1, "right": 2, "left": 3}
 
@@ -94,10 +98,15 @@ def _eff(lin):
 
 
 class ImplicitNet(nn.Module):
-    """parameter container with the reference's names/shapes (shape_net.py:9-82)."""
+    """ImplicitNet of code/src/networks/shape_net.py:8-144: the reference's parameter names / shapes and its
+    ``init: geometry`` scheme (:50-70, drawn in the same order from torch's global generator), with
+    ``forward(input, cond)`` / ``gradient(x, cond)`` running on the HIP kernels (first- and second-order backward
+    to the weights through ``NodeField``).  ``cond`` is accepted for signature parity: the 45 MANO pose columns are
+    multiplied by zero in the reference (:104-106) and the object net has none, so it never changes the result;
+    the background net (cond = frame latent, d_in 4) is evaluated through ``Background`` only."""
 
     def __init__(self, d_in, multires, cond_dim, weight_norm, embedding="fourier", barf_s=1000, barf_e=10000,
-                 no_barf=False):
+                 no_barf=False, init="none", bias=0.6, skip_in=(4,)):
         super().__init__()
         if embedding == "barf":
             self.embedder_obj = BarfEmbedder(d_in, multires, barf_s, barf_e, no_barf)
@@ -107,14 +116,76 @@ class ImplicitNet(nn.Module):
         self.d_in, self.multires, self.cond_dim, self.E = d_in, multires, cond_dim, e
         dims = [e] + [256] * 8 + [1 + FEAT]
         self.num_layers = len(dims)
-        for l in range(9):
-            out = dims[l + 1] - dims[0] if (l + 1) == 4 else dims[l + 1]
-            inn = dims[l] + (cond_dim if l == 0 else 0)
-            setattr(self, f"lin{l}", _lin(inn, out, weight_norm))
+        self.skip_in = tuple(skip_in)
+        for l in range(self.num_layers - 1):
+            out = dims[l + 1] - dims[0] if (l + 1) in self.skip_in else dims[l + 1]
+            lin = nn.Linear(dims[l] + (cond_dim if l == 0 else 0), out)
+            if init == "geometry":
+                if l == self.num_layers - 2:
+                    nn.init.normal_(lin.weight, mean=np.sqrt(np.pi) / np.sqrt(dims[l]), std=0.0001)
+                    nn.init.constant_(lin.bias, -bias)
+                elif multires > 0 and l == 0:
+                    nn.init.constant_(lin.bias, 0.0)
+                    nn.init.constant_(lin.weight[:, 3:], 0.0)
+                    nn.init.normal_(lin.weight[:, :3], 0.0, np.sqrt(2) / np.sqrt(out))
+                elif multires > 0 and l in self.skip_in:
+                    nn.init.constant_(lin.bias, 0.0)
+                    nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(out))
+                    nn.init.constant_(lin.weight[:, -(dims[0] - 3):], 0.0)
+                else:
+                    nn.init.constant_(lin.bias, 0.0)
+                    nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(out))
+            elif init == "zero" and l == self.num_layers - 2:
+                nn.init.constant_(lin.bias, 0.0)
+                nn.init.uniform_(lin.weight, -1e-5, 1e-5)
+            setattr(self, f"lin{l}", nn.utils.weight_norm(lin) if weight_norm else lin)
+        self._fields = {}
 
     def effective(self):
         lins = [getattr(self, f"lin{l}") for l in range(9)]
         return [_eff(l) for l in lins], [l.bias for l in lins]
+
+    # ---- kernel-backed call surface (shape_net.py:84-144) ----
+    def _field(self, device, tag):
+        assert self.d_in == 3, "the background ImplicitNet (d_in 4, frame cond) is evaluated by Background.render"
+        key = (str(device), tag)
+        if key not in self._fields:
+            self._fields[key] = NodeField(FieldSpec("hand" if self.cond_dim else "object"), device)
+        return self._fields[key]
+
+    def forward(self, input, cond=None, current_epoch=None):
+        """input [B,P,3] | [P,3] -> [B,P,257] (sdf | 256 features), differentiable w.r.t. the weights and input."""
+        if input.dim() == 2:
+            input = input.unsqueeze(0)
+        B, P, _ = input.shape
+        if B * P == 0:
+            return input
+        iw, ib = self.effective()
+        out = _ImplicitFn.apply(self, input.reshape(B * P, 3), self.embedder_obj.weights(input.device), *iw, *ib)
+        return out.view(B, P, 1 + FEAT)
+
+    @torch.no_grad()
+    def sdf(self, x):
+        """no-grad canonical SDF at x [P,3] -> [P] through the fused LDS-resident trunk (hold_fused_sdf): the query of
+        the canonical meshing grid (hold_utils.query_oc under generate_mesh, code/src/utils/meshing.py:35-41)."""
+        P = x.shape[0]
+        fld = self._field(x.device, "oc")
+        iw, ib = self.effective()
+        pk = pack_weights(fld.spec, iw, ib, None, None, need_bwd=False)
+        xc = torch.zeros(P, 4, device=x.device)
+        xc[:, :3] = x
+        out = torch.empty(P, 1, device=x.device)
+        wpack, bias8 = pk["fused"]
+        K.fused_sdf(xc, P, wpack, bias8, pk["w8_sdf"], float(pk["b8_sdf"]), self.embedder_obj.weights(x.device), out)
+        return out.view(P)
+
+    def gradient(self, x, cond=None):
+        """d sdf / d x with a differentiable (second-order) graph to the weights (shape_net.py:132-144): [P,1,3]."""
+        iw, ib = self.effective()
+        xc = torch.zeros(x.shape[0], 4, device=x.device)
+        xc[:, :3] = x.detach()
+        g = _EikonalFn.apply(self, xc, self.embedder_obj.weights(x.device), *iw, *ib)
+        return g.unsqueeze(1)
 
 
 class RenderingNet(nn.Module):
@@ -146,7 +217,7 @@ class LaplaceDensity(nn.Module):
 
 
 class GenericParams(nn.Module):
-    """per-frame pose tables (code/src/model/generic/params.py:6-62)."""
+    """per-frame pose tables (code/src/model/generic/params.py:6-62, mano/params.py:5-46, obj/params.py:4-30)."""
 
     def __init__(self, num_frames, params_dim, node_id):
         super().__init__()
@@ -158,8 +229,34 @@ class GenericParams(nn.Module):
             emb.weight.requires_grad = False
             setattr(self, name, emb)
 
+    def init_parameters(self, param_name, data, requires_grad=False):
+        w = getattr(self, param_name).weight
+        w.data = data[..., :self.params_dim[param_name]].to(device=w.device, dtype=w.dtype)
+        w.requires_grad = requires_grad
+
+    def set_requires_grad(self, param_name, requires_grad=True):
+        getattr(self, param_name).weight.requires_grad = requires_grad
+
+    def load_entity(self, data):
+        """fill the tables from one ``entities[node_id]`` record of data.npy (docs/data_doc.md:70-87)."""
+        t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
+        if "pose" in self.param_names:  # MANOParams.load_params (mano/params.py:15-46)
+            poses = np.asarray(data["hand_poses"])
+            vals = {"betas": t(np.asarray(data["mean_shape"])[None]), "global_orient": t(poses[:, :3]),
+                    "pose": t(poses[:, 3:]), "transl": t(data["hand_trans"])}
+        else:  # ObjectParams.load_params (obj/params.py:9-30)
+            op = np.asarray(data["object_poses"])
+            vals = {"global_orient": t(op[:, :3]), "transl": t(op[:, 3:])}
+        for name, v in vals.items():
+            self.init_parameters(name, v, requires_grad=False)
+
+    def load_params(self, case):
+        import os
+        ents = np.load(os.path.join("./data", case, "build/data.npy"), allow_pickle=True).item()["entities"]
+        self.load_entity(ents[self.node_id])
+
     def forward(self, frame_ids):
-        out = {}
+        out = output_class()()
         for name in self.param_names:
             ids = torch.zeros_like(frame_ids) if name == "betas" else frame_ids
             out[f"{self.node_id}.{name}"] = getattr(self, name)(ids)
@@ -170,11 +267,11 @@ class GenericParams(nn.Module):
 
     def defrost(self, keys=None):
         for n in (keys or self.param_names):
-            getattr(self, n).weight.requires_grad = True
+            self.set_requires_grad(n, True)
 
     def freeze(self, keys=None):
         for n in (keys or self.param_names):
-            getattr(self, n).weight.requires_grad = False
+            self.set_requires_grad(n, False)
 
 
 # ------------------------------------------------------------------------------------------ autograd glue
@@ -191,7 +288,7 @@ class _FieldFn(torch.autograd.Function):
         dfm["tfs"] = tfs.detach().reshape(-1, nb, 16).contiguous()
         out = node.field.forward(pk, x, P, ppf, dfm, barf_w, pose_embed.detach().contiguous(),
                                  None if time_code is None else time_code.detach().contiguous(), training=training)
-        ctx.node = node
+        ctx.node, ctx.gen = node, node.field.gen
         ctx.B = tfs.shape[0]
         ctx.tfs_shape = tfs.shape
         ctx.has_time = time_code is not None
@@ -205,6 +302,7 @@ class _FieldFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_sdf, d_rgb, d_normal, d_xc_unused):
         node = ctx.node
+        _check_gen(node.field, ctx.gen, f"HOLDNet node '{node.node_id}'")
         P = node.field.saved["P"]
         dev = node.field.device
         d_sdf = torch.zeros(P, device=dev) if d_sdf is None else d_sdf.contiguous()
@@ -217,24 +315,59 @@ class _FieldFn(torch.autograd.Function):
                 *g["iw"], *g["ib"], *g["rw"], *g["rb"])
 
 
+def _check_gen(field, gen, what):
+    if field.gen != gen:
+        raise RuntimeError(
+            f"hold_amd: {what}.backward() after the node's activation buffers were overwritten by a later forward "
+            "(activations live in a per-node pool, not in the autograd graph): call backward() before the next "
+            "forward of the same node, or use a separate HOLDNet instance for the interleaved evaluation")
+
+
 class _EikonalFn(torch.autograd.Function):
     """g = d sdf / d x at free canonical points with a differentiable (second-order) backward to the weights:
     compute_gradient_samples + compute_gradient(create_graph=True), code/src/engine/volsdf_utils.py:6-48."""
 
     @staticmethod
-    def forward(ctx, node, xc, barf_w, *weights):
+    def forward(ctx, inet, xc, barf_w, *weights):
         iw, ib = weights[0:9], weights[9:18]
-        rw, rb = weights[18:23], weights[23:28]
-        pk = pack_weights(node.spec, iw, ib, rw, rb, need_bwd=True)
-        fld = node._eik_field(xc.device)
+        fld = inet._field(xc.device, "eik")
+        pk = pack_weights(fld.spec, iw, ib, None, None, need_bwd=True)
         g = fld.grad_points_forward(pk, xc, xc.shape[0], barf_w)
-        ctx.node = node
+        ctx.fld, ctx.gen = fld, fld.gen
         return g[:, :3].clone()
 
     @staticmethod
     def backward(ctx, gbar):
-        g_iw, g_ib = ctx.node._eik_field(gbar.device).grad_points_backward(gbar.contiguous())
-        return (None, None, None, *g_iw, *g_ib, *([None] * 10))
+        _check_gen(ctx.fld, ctx.gen, "ImplicitNet.gradient")
+        g_iw, g_ib = ctx.fld.grad_points_backward(gbar.contiguous())
+        return (None, None, None, *g_iw, *g_ib)
+
+
+class _ImplicitFn(torch.autograd.Function):
+    """ImplicitNet.forward at canonical points (shape_net.py:84-130) with its first-order backward."""
+
+    @staticmethod
+    def forward(ctx, inet, x, barf_w, *weights):
+        iw, ib = weights[0:9], weights[9:18]
+        fld = inet._field(x.device, "oc")
+        pk = pack_weights(fld.spec, iw, ib, None, None, need_bwd=True)
+        P = x.shape[0]
+        xc = fld.pool.get("xc_in", P, 4)
+        xc[:, :3] = x.detach()
+        o = fld.sdf_feat_forward(pk, xc, P, barf_w)
+        ctx.fld, ctx.gen, ctx.P = fld, fld.gen, P
+        return torch.cat([o[:, 256:257], o[:, :256]], 1)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        _check_gen(ctx.fld, ctx.gen, "ImplicitNet.forward")
+        fld, P = ctx.fld, ctx.P
+        ob = fld.pool.get("oc_bar", P, 260)
+        ob.zero_()
+        ob[:, :256] = d_out[:, 1:]
+        ob[:, 256] = d_out[:, 0]
+        g_iw, g_ib, xbar = fld.sdf_feat_backward(ob)
+        return (None, xbar[:, :3].clone(), None, *g_iw, *g_ib)
 
 
 class _CompositeFn(torch.autograd.Function):
@@ -299,18 +432,26 @@ class _BackgroundFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------ nodes
 class Node(nn.Module):
-    def __init__(self, node_id, kind, n_frames, sdf_bounding_sphere, sampler_opt, barf_s, barf_e, no_barf):
+    """Node of code/src/model/renderables/node.py:12-109: networks, sampler, density, deformer, server, pose tables."""
+
+    def __init__(self, node_id, kind, n_frames, sdf_bounding_sphere, sampler_opt, barf_s, barf_e, no_barf, params, server,
+                 init="geometry", init_bias=0.6):
         super().__init__()
         self.node_id, self.kind, self.class_id = node_id, kind, CLASS_ID[node_id]
         self.spec = FieldSpec(kind)
         self.sdf_bounding_sphere = sdf_bounding_sphere
         cond = 45 if kind == "hand" else 0
+        # `params` was constructed by the caller BEFORE the networks, as the reference does, so that the same torch
+        # seed gives the same initial parameters; sub-modules are registered in the reference's order (node.py:27-42)
         self.implicit_network = ImplicitNet(3, 6, cond, True, "fourier" if kind == "hand" else "barf", barf_s, barf_e,
-                                            no_barf)
+                                            no_barf, init=init, bias=init_bias)
         self.rendering_network = RenderingNet("pose", self.spec.rin_dim, [256] * 4, True, pose_dim=cond)
-        self.density = LaplaceDensity()
         self.ray_sampler = ErrorBoundSampler(sdf_bounding_sphere, inverse_sphere_bg=True, **sampler_opt)
+        self.density = LaplaceDensity()
+        self.server = server
+        self.params = params
         self.field = None
+        self._pk = None
 
     def _field(self, device):
         if self.field is None or self.field.device != device:
@@ -320,21 +461,26 @@ class Node(nn.Module):
     def step_embedding(self):
         self.implicit_network.embedder_obj.step()
 
-    def _eik_field(self, device):
-        f = getattr(self, "_eik", None)
-        if f is None or f.device != device:
-            f = self._eik = NodeField(self.spec, device)
-        return f
+    def meshing_cano(self, pose=None):  # node.py:44-45
+        return None
 
     def eikonal_grad(self, points):
         """grad_theta of the reference (volsdf_utils.compute_gradient_samples): d sdf / d x at canonical sample
         points [B, n, 3] -> [B, n, 3], differentiable w.r.t. the implicit network's parameters."""
         B, n, _ = points.shape
-        xc = torch.zeros(B * n, 4, device=points.device)
-        xc[:, :3] = points.reshape(-1, 3)
-        barf_w = self.implicit_network.embedder_obj.weights(points.device)
-        g = _EikonalFn.apply(self, xc, barf_w, *self._weights())
-        return g.view(B, n, 3)
+        return self.implicit_network.gradient(points.reshape(-1, 3)).view(B, n, 3)
+
+    def query_oc(self, x):
+        """hold_utils.query_oc (code/src/hold/hold_utils.py:61-65): canonical SDF at x [B,n,3] -> [B,n]."""
+        return self.implicit_network(x, None)[:, :, 0]
+
+    def _gradient_samples(self, sampler, centers, num, local_sigma, global_ratio):
+        """compute_gradient_samples (volsdf_utils.py:19-48): randperm(V)[:num] centres (CPU generator, as the
+        reference), one Gaussian copy each + global_ratio * num uniform box samples -> d sdf / d x with graph."""
+        idx = torch.randperm(centers.shape[1])[:num].to(centers.device)
+        sample = sampler.get_points(torch.index_select(centers, 1, idx), local_sigma=local_sigma,
+                                    global_ratio=global_ratio)
+        return sample, self.eikonal_grad(sample)
 
     def _weights(self):
         iw, ib = self.implicit_network.effective()
@@ -352,18 +498,20 @@ class Node(nn.Module):
         weights = self._weights()
         nb = self.spec.n_bones
         N = ray_dirs.shape[0]
+        with torch.no_grad():  # one re-layout of the (constant within the call) weights for sampler + field + backward
+            self._pk = pack_weights(self.spec, weights[0:9], weights[9:18], weights[18:23], weights[23:28], training)
         # ---- sampler (no grad; sampler toggles net.eval()/train() in the reference, a no-op for these nets) ----
         if z_override is None:
             with torch.no_grad():
-                pk = pack_weights(self.spec, weights[0:9], weights[9:18], weights[18:23], weights[23:28], False)
+                pk = self._pk
                 dfm = dict(dfm_const)
                 dfm["tfs"] = tfs.detach().reshape(-1, nb, 16).contiguous()
 
                 def sdf_query(x, P, out):
                     field.sdf_only(pk, x, P, P // tfs.shape[0], dfm, barf_w, out)
 
-                z_vals = self.ray_sampler.get_z_vals(sdf_query, ray_dirs, cam_loc, self.density.get_beta().item(),
-                                                     training, rng)
+                z_vals = self.ray_sampler.sample_z(sdf_query, ray_dirs, cam_loc, self.density.get_beta().item(),
+                                                   training, rng)
         else:
             z_vals = z_override.contiguous()
         S = z_vals.shape[1]
@@ -379,25 +527,70 @@ class Node(nn.Module):
 
 
 class MANONode(Node):
+    """code/src/model/renderables/mano_node.py:17-151."""
+
     def __init__(self, node_id, betas, n_frames, sdf_bounding_sphere, sampler_opt, mano_model, barf_s, barf_e,
-                 no_barf):
-        super().__init__(node_id, "hand", n_frames, sdf_bounding_sphere, sampler_opt, barf_s, barf_e, no_barf)
+                 no_barf, init="geometry", init_bias=0.6):
+        server = MANOServer(betas, node_id == "right", mano_model)
+        params = GenericParams(n_frames, {"betas": 10, "global_orient": 3, "transl": 3, "pose": 45}, node_id)
+        super().__init__(node_id, "hand", n_frames, sdf_bounding_sphere, sampler_opt, barf_s, barf_e, no_barf, params,
+                         server, init, init_bias)
         self.is_rhand = node_id == "right"
-        self.server = MANOServer(betas, self.is_rhand, mano_model)
-        self.params = GenericParams(n_frames, {"betas": 10, "global_orient": 3, "transl": 3, "pose": 45}, node_id)
-        # canonical vertices / skinning table of the KNN deformer (mano/deformer.py:20-32)
-        self.register_buffer("cano_verts", self.server.verts_c[0].clone(), persistent=False)
+        from .deformer import MANODeformer
+        self.deformer = MANODeformer(max_dist=0.1, K=15, betas=betas, is_rhand=self.is_rhand, server=self.server)
+        self.register_buffer("mesh_f_cano", torch.as_tensor(self.server.faces.astype(np.int64)), persistent=False)
+        # loss-target mesh: the sealed, once-subdivided canonical MANO, spawned every 200 steps (hold_net.py:161-166)
+        self.mesh_v_cano_div = None
+        self.mesh_f_cano_div = None
+        self.canonical_mesh = None
+        self.pt_sampler = PointInSpace(global_sigma_xyz=[0.15, 0.06, 0.12])  # hold_utils.py:58
+
+    # canonical vertices of the KNN deformer (mano/deformer.py:20-32) = the server's canonical pose output
+    cano_verts = property(lambda self: self.server.verts_c[0])
+    mesh_v_cano = property(lambda self: self.server.verts_c)
 
     def sample_eikonal_points(self, batch_size, num=256, local_sigma=0.008, global_ratio=0.20):
-        """PointInSpace(global_sigma_xyz=[0.15, 0.06, 0.12]).get_points around random canonical MANO vertices
-        (hold_utils.py:22-58,230-240; volsdf_utils.py:28-35): num local + num*ratio global samples."""
-        dev = self.cano_verts.device
-        idx = torch.randperm(self.cano_verts.shape[0])[:num].to(dev)
-        v = self.cano_verts[idx][None].expand(batch_size, -1, -1)
-        local = v + torch.randn_like(v) * local_sigma
-        gs = torch.tensor([0.15, 0.06, 0.12], device=dev)
-        glob = torch.rand(batch_size, int(num * global_ratio), 3, device=dev) * (gs * 2) - gs
-        return torch.cat([local, glob], dim=1)
+        """the sample points of compute_gradient_samples around random canonical MANO vertices."""
+        v = self.cano_verts[None].expand(batch_size, -1, -1)
+        idx = torch.randperm(v.shape[1])[:num].to(v.device)
+        return self.pt_sampler.get_points(torch.index_select(v, 1, idx), local_sigma=local_sigma,
+                                          global_ratio=global_ratio)
+
+    def spawn_cano_mano(self, sample_dict_h):
+        """mano_node.py:126-135: seal the pose-corrected canonical vertices (first frame of the batch) and Loop-
+        subdivide once -> 3 111 vertices / 6 216 faces."""
+        so = sample_dict_h.get("output", sample_dict_h)
+        v, f = seal_mano_mesh(so["v_posed"].detach(), self.mesh_f_cano, self.is_rhand)
+        self.mesh_v_cano_div, self.mesh_f_cano_div = subdivide_loop(v[0].float(), f)
+
+    def meshing_cano(self, pose=None):
+        """mano_node.py:137-151: canonical mesh of the learnt SDF inside MANO's canonical bounding box."""
+        from .meshing import generate_mesh
+        v_min_max = np.array([[-0.0814, -0.0280, -0.0742], [0.1171, 0.0349, 0.0971]])
+        dev = self.mesh_f_cano.device
+        return generate_mesh(lambda x: {"sdf": self.implicit_network.sdf(x)}, v_min_max, point_batch=10000, res_up=1,
+                             res_init=64, device=dev)
+
+    def loss_targets(self, out, fac, B, n_pix, frame_terms=True):
+        """prepare_loss_targets_hand (code/src/hold/hold_utils.py:186-240)."""
+        if self.mesh_v_cano_div is None:
+            return
+        nid = self.node_id
+        mesh_v = self.mesh_v_cano_div[None]
+        mesh_f = self.mesh_f_cano_div
+        cano_pts = fac["canonical_pts"].reshape(B, -1, 3)
+        if frame_terms:
+            samples = sample_on_barycentric_mesh(mesh_v.expand(B, -1, -1), mesh_f, num_samples=256)
+            samples = self.pt_sampler.get_points(samples, local_sigma=0.008, global_ratio=0.20)
+            out[f"{nid}.pts2mano_sdf_cano"] = compute_mano_cano_sdf(mesh_v[0], mesh_f, samples)
+            out[f"{nid}.pred_sdf"] = self.query_oc(samples)
+        off, _ = check_off_in_surface_points_cano_mesh(mesh_v[0], mesh_f, cano_pts, B * n_pix, threshold=0.01)
+        out[f"{nid}.index_off_surface"] = off
+        if frame_terms:
+            verts_c = self.cano_verts[None].expand(B, -1, -1)
+            esamp, g = self._gradient_samples(self.pt_sampler, verts_c, 256, 0.008, 0.20)
+            out[f"{nid}.grad_theta"] = g
+            self._last_targets = dict(mano_cano_samples=samples, eikonal_samples=esamp)
 
     def serve(self, input):
         nid = self.node_id
@@ -414,11 +607,55 @@ class MANONode(Node):
 
 
 class ObjectNode(Node):
-    def __init__(self, node_id, n_frames, sdf_bounding_sphere, sampler_opt, entity, barf_s, barf_e, no_barf):
-        super().__init__(node_id, "object", n_frames, sdf_bounding_sphere, sampler_opt, barf_s, barf_e, no_barf)
-        self.server = ObjectServer(entity)
-        self.params = GenericParams(n_frames, {"global_orient": 3, "transl": 3}, node_id)
+    """code/src/model/renderables/object_node.py:17-132."""
+
+    def __init__(self, node_id, n_frames, sdf_bounding_sphere, sampler_opt, entity, barf_s, barf_e, no_barf,
+                 init="geometry", init_bias=0.6):
+        params = GenericParams(n_frames, {"global_orient": 3, "transl": 3}, node_id)
+        server = ObjectServer(entity)
+        super().__init__(node_id, "object", n_frames, sdf_bounding_sphere, sampler_opt, barf_s, barf_e, no_barf, params,
+                         server, init, init_bias)
+        from .deformer import ObjectDeformer
+        self.deformer = ObjectDeformer()
         self.frame_latent_encoder = nn.Embedding(n_frames, 32)
+        self.is_test = False
+        self.mesh_o = None
+        self.mesh_vo_cano = None
+        self.mesh_fo_cano = None
+        v3d = np.asarray(entity["pts.cano"], dtype=np.float32)
+        self.v_min_max = np.array([v3d.min(axis=0), v3d.max(axis=0)]) * 2.0  # object_node.py:49-50
+
+    def meshing_cano(self, pose=None):
+        """object_node.py:112-121."""
+        from .meshing import generate_mesh
+        dev = self.frame_latent_encoder.weight.device
+        mesh = generate_mesh(lambda x: {"sdf": self.implicit_network.sdf(x)}, self.v_min_max, point_batch=10000,
+                             res_up=2, device=dev)
+        self.update_cano(mesh)
+        return mesh
+
+    def update_cano(self, mesh_canonical):
+        """object_node.py:123-132 (``mesh_o``, kaolin's face-vertex tensor, is kept as the face-gathered vertices)."""
+        dev = self.frame_latent_encoder.weight.device
+        self.mesh_vo_cano = torch.as_tensor(np.asarray(mesh_canonical.vertices)[None], device=dev).float()
+        self.mesh_fo_cano = torch.as_tensor(np.asarray(mesh_canonical.faces).astype(np.int64), device=dev)
+        self.mesh_o = self.mesh_vo_cano[:, self.mesh_fo_cano]
+
+    def loss_targets(self, out, fac, B, n_pix, frame_terms=True):
+        """prepare_loss_targets_object (code/src/hold/hold_utils.py:149-183)."""
+        if self.mesh_o is None:
+            return
+        nid = self.node_id
+        cano_pts = fac["canonical_pts"].reshape(B, -1, 3)
+        off, _ = check_off_in_surface_points_cano_mesh(self.mesh_vo_cano[0], self.mesh_fo_cano, cano_pts, B * n_pix,
+                                                       threshold=0.05)
+        out[f"{nid}.index_off_surface"] = off
+        if frame_terms:
+            xyz = self.mesh_vo_cano[0].abs().max(dim=0).values * 1.1
+            sampler = PointInSpace(global_sigma_xyz=xyz)
+            esamp, g = self._gradient_samples(sampler, self.mesh_vo_cano.expand(B, -1, -1), 256, 0.03, 0.20)
+            out[f"{nid}.grad_theta"] = g
+            self._last_targets = dict(eikonal_samples=esamp)
 
     def serve(self, input):
         nid = self.node_id
@@ -561,17 +798,10 @@ class Background(nn.Module):
 
 # ------------------------------------------------------------------------------------------ HOLDNet
 def get_camera_params(uv, pose, intrinsics):
-    """code/src/datasets/utils.py:230-282 (pose-matrix branch); per-pixel elementwise algebra on [B,P]."""
-    cam_loc = pose[:, :3, 3]
-    fx, fy = intrinsics[:, 0, 0, None], intrinsics[:, 1, 1, None]
-    cx, cy, sk = intrinsics[:, 0, 2, None], intrinsics[:, 1, 2, None], intrinsics[:, 0, 1, None]
-    x, y = uv[:, :, 0], uv[:, :, 1]
-    z = torch.ones_like(x)
-    xl = (x - cx + cy * sk / fy - sk * y / fy) / fx * z
-    yl = (y - cy) / fy * z
-    pc = torch.stack((xl, yl, z, torch.ones_like(z)), -1).permute(0, 2, 1)
-    world = torch.bmm(pose, pc).permute(0, 2, 1)[:, :, :3]
-    return F.normalize(world - cam_loc[:, None, :], dim=2), cam_loc
+    """code/src/datasets/utils.py:256-282 (pose-matrix branch) on hold_raygen: -> (ray_dirs [B,P,3], cam_loc [B,3])."""
+    B, Pn, _ = uv.shape
+    dirs, _ = K.raygen(uv, pose, intrinsics)
+    return dirs.view(B, Pn, 3), pose[:, :3, 3]
 
 
 DEFAULT_SAMPLER = dict(near=0.0, N_samples=64, N_samples_eval=128, N_samples_extra=32, eps=0.1, beta_iters=10,
@@ -579,11 +809,13 @@ DEFAULT_SAMPLER = dict(near=0.0, N_samples=64, N_samples_eval=128, N_samples_ext
 
 
 class HOLDNet(nn.Module):
-    """HOLDNet(opt, betas_r, betas_l, num_frames, args) of code/src/hold/hold_net.py:23-51, with the file-backed
-    inputs (MANO pickle, data.npy entities) passed explicitly."""
+    """HOLDNet of code/src/hold/hold_net.py:23-179 with the file-backed inputs (MANO pickles, data.npy entities) passed
+    explicitly; ``hold_amd.ReferenceHOLDNet`` wraps it in the reference's ``(opt, betas_r, betas_l, num_frames, args)``
+    constructor.  ``forward(input) -> xdict`` with the reference's keys, including the training-only loss targets
+    ``<node>.{index_off_surface, grad_theta, pts2mano_sdf_cano, pred_sdf}`` (prepare_loss_targets, :154-179)."""
 
     def __init__(self, scene_bounding_sphere, betas_r, betas_l, num_frames, entities, mano_models, sampler_opt=None,
-                 barf_s=1000, barf_e=10000, no_barf=False):
+                 barf_s=1000, barf_e=10000, no_barf=False, init="geometry", init_bias=0.6, load_pose_tables=True):
         super().__init__()
         self.sdf_bounding_sphere = float(scene_bounding_sphere)
         self.threshold = 0.05
@@ -591,29 +823,52 @@ class HOLDNet(nn.Module):
         nodes = {}
         if betas_r is not None:
             nodes["right"] = MANONode("right", betas_r, num_frames, self.sdf_bounding_sphere, so, mano_models["right"],
-                                      barf_s, barf_e, no_barf)
+                                      barf_s, barf_e, no_barf, init, init_bias)
         if betas_l is not None:
             nodes["left"] = MANONode("left", betas_l, num_frames, self.sdf_bounding_sphere, so, mano_models["left"],
-                                     barf_s, barf_e, no_barf)
+                                     barf_s, barf_e, no_barf, init, init_bias)
         nodes["object"] = ObjectNode("object", num_frames, self.sdf_bounding_sphere, so, entities["object"], barf_s,
-                                     barf_e, no_barf)
+                                     barf_e, no_barf, init, init_bias)
         self.nodes = nn.ModuleDict(nodes)
         self.background = Background(num_frames, self.sdf_bounding_sphere)
+        if load_pose_tables:  # params.load_params(args.case) of mano_node.py:46 / object_node.py:33
+            for nid, node in self.nodes.items():
+                ent = entities.get(nid, {})
+                if ("hand_poses" in ent) or ("object_poses" in ent):
+                    node.params.load_entity(ent)
+        self.auto_step_embedding = True  # train_step() steps the BARF counter once per optimiser step instead
+
+    def init_network(self, shape_init=""):
+        """hold_net.py:136-152: optionally start the hand / object SDF nets from a pre-trained checkpoint."""
+        if not shape_init:
+            return
+        sd = torch.load(f"./saved_models/{shape_init}/checkpoints/last.ckpt", map_location="cpu")["state_dict"]
+        sd = {k.replace("model.", ""): v for k, v in sd.items()
+              if "implicit_network" in k and "bg_implicit_network." not in k and ".embedder_obj." not in k}
+        self.load_state_dict(sd, strict=False)
 
     def step_embedding(self):
         for node in self.nodes.values():
             node.step_embedding()
         self.background.step_embedding()
 
+    def prepare_loss_targets(self, out, fac, step, B, n_pix, frame_terms=True):
+        """hold_net.py:154-179 + hold_utils.prepare_loss_targets_{hand,object}."""
+        if step % 200 == 0 and step > 0:
+            for nid, node in self.nodes.items():
+                if nid in ("right", "left"):
+                    node.spawn_cano_mano(fac[nid]["server"])
+        for nid, node in self.nodes.items():
+            node.loss_targets(out, fac[nid], B, n_pix, frame_terms)
+
     def forward(self, input, rng=None, z_override=None):
         if not torch.cuda.is_available():
             raise RuntimeError("hold_amd.HOLDNet needs an MI355X: the hot path has no CPU / eager fallback")
         training = self.training
+        XD = output_class()
         with torch.enable_grad() if training else torch.no_grad():
-            ray_dirs, cam = get_camera_params(input["uv"], input["extrinsics"], input["intrinsics"])
-            B, Pn, _ = ray_dirs.shape
-            cam_loc = cam.unsqueeze(1).repeat(1, Pn, 1).reshape(-1, 3).contiguous()
-            ray_dirs = ray_dirs.reshape(-1, 3).contiguous()
+            B, Pn, _ = input["uv"].shape
+            ray_dirs, cam_loc = K.raygen(input["uv"], input["extrinsics"], input["intrinsics"])  # [N,3] each
             N = B * Pn
             out = {}
             if training:
@@ -622,6 +877,8 @@ class HOLDNet(nn.Module):
             for nid, node in self.nodes.items():
                 fac[nid] = node.render(input, ray_dirs, cam_loc, Pn, None if rng is None else rng.get(nid),
                                        None if z_override is None else z_override[nid])
+            if training:
+                self.prepare_loss_targets(out, fac, int(out["step"]), B, Pn, input.get("hold_amd.frame_terms", True))
             ids = list(fac.keys())
             S = fac[ids[0]]["z_vals"].shape[1]
             args = ([fac[i]["z_vals"] for i in ids] + [fac[i]["sdf"] for i in ids] + [fac[i]["color"] for i in ids] +
@@ -660,6 +917,6 @@ class HOLDNet(nn.Module):
                 out["bg_rgb_only"] = bg_only
                 out["instance_map"] = torch.argmax(out["semantics"], dim=1)
             self._last_factors = fac
-            if training:
+            if training and self.auto_step_embedding:
                 self.step_embedding()
-        return out
+        return XD(out)

@@ -20,6 +20,17 @@ def _ld(t):
     return t.stride(0)
 
 
+def raygen(uv, pose, intrinsics):
+    """uv [B,Pn,2], pose [B,4,4], intrinsics [B,3|4,3|4] -> (ray_dirs [B*Pn,3], cam_loc [B*Pn,3])."""
+    B, Pn, _ = uv.shape
+    uv, pose, intr = uv.contiguous().float(), pose.contiguous().float(), intrinsics.contiguous().float()
+    assert pose.shape[1:] == (4, 4) and intr.shape[1] == intr.shape[2]
+    dirs = torch.empty(B * Pn, 3, device=uv.device)
+    cam = torch.empty(B * Pn, 3, device=uv.device)
+    call("hold_raygen", ptr(uv), ptr(pose), ptr(intr), intr.shape[1], B * Pn, Pn, ptr(dirs), ptr(cam))
+    return dirs, cam
+
+
 def ray_points(cam_loc, ray_dirs, z, S, out):
     call("hold_ray_points", ptr(cam_loc), ptr(ray_dirs), ptr(z), _ld(z), S, cam_loc.shape[0], ptr(out), _ld(out))
 
@@ -48,6 +59,10 @@ def knn_invlbs(x, P, pts_per_frame, verts, skin_w, tfs=None, w_out=None, xc_out=
 
 def invskin_fwd(x, P, pts_per_frame, w, tfs, n_bones, xc):
     call("hold_invskin_fwd", ptr(x), _ld(x), P, pts_per_frame, ptr(w), ptr(tfs), n_bones, ptr(xc), _ld(xc))
+
+
+def skin_fwd(x, P, pts_per_frame, w, tfs, n_bones, xd):
+    call("hold_skin_fwd", ptr(x), _ld(x), P, pts_per_frame, ptr(w), ptr(tfs), n_bones, ptr(xd), _ld(xd))
 
 
 def invskin_bwd(xc, w, tfs, n_bones, P, pts_per_frame, xcbar, dtfs):

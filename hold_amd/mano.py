@@ -7,15 +7,15 @@ code/src/model/obj/object_model.py:12-70, code/src/utils/external/lbs.py:139-251
 These run on B <= ~50 frames of 778 vertices -- about 1e-5 of the path's FLOPs.  On the GPU
 ``MANOServer.forward`` is ONE launch of the fused HIP kernel ``hold_mano_lbs_fwd`` (csrc/mano.hip) with a
 hand-derived backward ``hold_mano_lbs_bwd`` (pose / shape / translation gradients from d tfs and d verts).
-The torch expression ``mano_lbs`` below is used once, at construction time on the host, to derive the
-canonical-pose constants (verts_c, tfs_c_inv) exactly as the reference's constructor does.
+The canonical-pose constants (verts_c, joints_c, tfs_c_inv; server.py:46-60) come from the same kernel, evaluated
+lazily the first time they are needed on the module's device -- there is no torch / CPU implementation of the LBS in
+this package (the CPU restatement lives in oracle/hold_oracle.py).
 """
 from __future__ import annotations
 
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 TIP_IDS = (744, 320, 443, 554, 671)
 
@@ -54,43 +54,8 @@ class ManoLayer(nn.Module):
         self.vertex_joint_selector = VertexJointSelector()
         # member parameters the reference layer carries (unused by HOLD's forward, kept for checkpoints)
         for name, dim in [("betas", 10), ("global_orient", 3), ("body_pose", 3), ("transl", 3), ("hand_pose", 45)]:
-            self.register_parameter(name, nn.Parameter(torch.zeros(1, dim, dtype=dtype), requires_grad=False))
+            self.register_parameter(name, nn.Parameter(torch.zeros(1, dim, dtype=dtype), requires_grad=True))
         self._parent_list = [int(p) for p in parents.tolist()]
-
-
-def rodrigues(rot_vecs):
-    angle = torch.norm(rot_vecs + 1e-8, dim=1, keepdim=True)  # lbs.py:313 quirk kept
-    d = rot_vecs / angle
-    c, s = torch.cos(angle)[:, None], torch.sin(angle)[:, None]
-    rx, ry, rz = d[:, 0:1], d[:, 1:2], d[:, 2:3]
-    z = torch.zeros_like(rx)
-    Km = torch.cat([z, -rz, ry, rz, z, -rx, -ry, rx, z], 1).view(-1, 3, 3)
-    return torch.eye(3, dtype=rot_vecs.dtype, device=rot_vecs.device)[None] + s * Km + (1 - c) * torch.bmm(Km, Km)
-
-
-def mano_lbs(layer: ManoLayer, betas, full_pose):
-    """-> verts [B,778,3], joints [B,16,3], A [B,16,4,4] (relative bone transforms), v_posed [B,778,3]."""
-    B = full_pose.shape[0]
-    dt, dev = full_pose.dtype, full_pose.device
-    pose = full_pose + layer.pose_mean
-    v_shaped = layer.v_template + torch.einsum("bl,mkl->bmk", betas, layer.shapedirs)
-    J = torch.einsum("bik,ji->bjk", v_shaped, layer.J_regressor)
-    rot = rodrigues(pose.reshape(-1, 3)).view(B, 16, 3, 3)
-    pf = (rot[:, 1:] - torch.eye(3, dtype=dt, device=dev)).reshape(B, -1)
-    v_posed = v_shaped + torch.matmul(pf, layer.posedirs).view(B, -1, 3)
-    par = layer._parent_list
-    rel = torch.cat([J[:, :1], J[:, 1:] - J[:, par[1:]]], 1)
-    tm = torch.cat([F.pad(rot.reshape(-1, 3, 3), [0, 0, 0, 1]),
-                    F.pad(rel.reshape(-1, 3, 1), [0, 0, 0, 1], value=1.0)], 2).reshape(B, 16, 4, 4)
-    chain = [tm[:, 0]]
-    for i in range(1, 16):
-        chain.append(torch.matmul(chain[par[i]], tm[:, i]))
-    T = torch.stack(chain, 1)
-    Jh = F.pad(J.unsqueeze(-1), [0, 0, 0, 1])
-    A = T - F.pad(torch.matmul(T, Jh), [3, 0, 0, 0, 0, 0, 0, 0])
-    Tv = torch.matmul(layer.lbs_weights[None].expand(B, -1, -1), A.view(B, 16, 16)).view(B, -1, 4, 4)
-    verts = (Tv[:, :, :3, :3] @ v_posed.unsqueeze(-1)).squeeze(-1) + Tv[:, :, :3, 3]
-    return verts, T[:, :, :3, 3], A, v_posed
 
 
 class _ManoLbsFn(torch.autograd.Function):
@@ -112,7 +77,6 @@ class _ManoLbsFn(torch.autograd.Function):
                         ("pose_mean", hl.pose_mean)]:
             assert t.is_cuda and t.is_contiguous()
             setattr(mm, name, t.data_ptr())
-        assert server.tfs_c_inv.is_contiguous()
         mm.tfs_c_inv = None if absolute else server.tfs_c_inv.data_ptr()
         args = [a.detach().contiguous().float() for a in (betas, thetas, scene_scale.reshape(-1), transl)]
         verts = torch.empty(B, 778, 3, device=dev)
@@ -147,14 +111,20 @@ class _ManoLbsFn(torch.autograd.Function):
 
 
 class MANOServer(nn.Module):
-    """GenericServer/MANOServer of code/src/model/mano/server.py."""
+    """GenericServer/MANOServer of code/src/model/mano/server.py:20-133.  ``model`` is the un-pickled MANO dict; when
+    omitted it is read from ./body_models/MANO_{RIGHT,LEFT}.pkl as the reference does (server.py:121-128)."""
 
-    def __init__(self, betas, is_rhand, model: dict):
+    def __init__(self, betas, is_rhand, model: dict = None):
         super().__init__()
+        if model is None:
+            import pickle
+            with open(f"./body_models/MANO_{'RIGHT' if is_rhand else 'LEFT'}.pkl", "rb") as f:
+                model = pickle.load(f, encoding="latin1")
         self.human_layer = ManoLayer(model, is_rhand)
         self.faces = self.human_layer.faces
         self.bone_parents = self.human_layer.bone_parents.astype(int)
         self.bone_parents[0] = -1
+        self.bone_ids = [[int(self.bone_parents[i]), i] for i in range(16)]
         self.betas = None if betas is None else torch.as_tensor(np.asarray(betas), dtype=torch.float32)
         pc = torch.zeros(1, 62)
         pc[0, 0] = 1
@@ -163,36 +133,33 @@ class MANOServer(nn.Module):
             pc[0, -10:] = self.betas
         self.param_canonical = pc
         self.cano_params = torch.split(pc, [1, 3, 48, 10], dim=1)
-        with torch.no_grad():
-            out = self.forward(*self.cano_params, absolute=True)
-        self.register_buffer("verts_c", out["verts"], persistent=False)
-        self.register_buffer("joints_c", out["jnts"], persistent=False)
-        self.register_buffer("tfs_c_inv", out["tfs"].squeeze(0).inverse().contiguous(), persistent=False)
         self.register_buffer("_parents_i32", self.human_layer.parents.to(torch.int32), persistent=False)
+        self._cano = None
+
+    # ---- canonical pose constants (verts_c [1,778,3], joints_c [1,21,3], tfs_c_inv [16,4,4]) ----
+    def _canonical(self):
+        dev = self.human_layer.v_template.device
+        if self._cano is None or self._cano["verts_c"].device != dev:
+            if dev.type != "cuda":
+                raise RuntimeError("hold_amd.MANOServer: the MANO LBS runs in libholdhip.so only -- move the module "
+                                   "to the MI355X (.to('cuda')) before using its canonical vertices / transforms")
+            with torch.no_grad():
+                sc, tr, th, be = (a.to(dev) for a in self.cano_params)
+                verts, jnts, tfs, _ = _ManoLbsFn.apply(self, True, sc, tr, th, be)
+            self._cano = dict(verts_c=verts, joints_c=jnts, tfs_c_inv=tfs.squeeze(0).inverse().contiguous())
+        return self._cano
+
+    verts_c = property(lambda self: self._canonical()["verts_c"])
+    joints_c = property(lambda self: self._canonical()["joints_c"])
+    tfs_c_inv = property(lambda self: self._canonical()["tfs_c_inv"])
 
     def forward(self, scene_scale, transl, thetas, betas, absolute=False):
         hl = self.human_layer
         dev = hl.v_template.device
         scene_scale, transl, thetas, betas = (a.to(dev) for a in (scene_scale, transl, thetas, betas))
-        if dev.type == "cuda":  # run-time path: the fused HIP kernel (fwd + hand-derived bwd)
-            verts, jnts, tfs, v_posed = _ManoLbsFn.apply(self, bool(absolute), scene_scale, transl, thetas, betas)
-            return {"verts": verts, "jnts": jnts, "tfs": tfs, "v_posed": v_posed,
-                    "skin_weights": hl.lbs_weights[None].expand(verts.shape[0], -1, -1)}
-        # construction-time only (canonical pose on the host before the module is moved to the GPU)
-        verts, joints, A, v_posed = mano_lbs(hl, betas, thetas)
-        joints = torch.cat([joints, verts[:, list(TIP_IDS)]], 1)
-        s = scene_scale.view(-1, 1, 1)
-        t = transl.view(-1, 1, 3)
-        out = {"verts": verts * s + t * s, "jnts": joints * s + t * s}
-        top = A[:, :, :3, :] * s.view(-1, 1, 1, 1)
-        top = torch.cat([top[..., :3], top[..., 3:] + (t * s).view(-1, 1, 3, 1)], -1)
-        tf = torch.cat([top, A[:, :, 3:, :]], 2)
-        if not absolute:
-            tf = torch.einsum("bnij,njk->bnik", tf, self.tfs_c_inv)
-        out["tfs"] = tf
-        out["skin_weights"] = hl.lbs_weights[None].expand(verts.shape[0], -1, -1)
-        out["v_posed"] = v_posed
-        return out
+        verts, jnts, tfs, v_posed = _ManoLbsFn.apply(self, bool(absolute), scene_scale, transl, thetas, betas)
+        return {"verts": verts, "jnts": jnts, "tfs": tfs, "v_posed": v_posed,
+                "skin_weights": hl.lbs_weights[None].expand(verts.shape[0], -1, -1)}
 
     def forward_param(self, param_dict):
         get = lambda k: next(v for kk, v in param_dict.items() if k in kk)
@@ -217,9 +184,20 @@ def axis_angle_to_matrix(aa):
     return o.reshape(q.shape[:-1] + (3, 3))
 
 
+def _object_entity(entity_or_case):
+    """the ``entities["object"]`` record of data.npy, given either the record itself or the sequence name the
+    reference's ObjectModel / ObjectServer take (object_model.py:15-19)."""
+    if isinstance(entity_or_case, str):
+        return np.load(f"./data/{entity_or_case}/build/data.npy", allow_pickle=True).item()["entities"]["object"]
+    return entity_or_case
+
+
 class ObjectModel(nn.Module):
-    def __init__(self, entity: dict):
+    def __init__(self, entity, template=None):
         super().__init__()
+        entity = _object_entity(entity)
+        if template is not None:
+            entity = dict(entity, **{"pts.cano": np.asarray(template.vertices)})
         self.register_buffer("obj_scale", torch.tensor(np.array([entity["obj_scale"]]), dtype=torch.float32))
         self.register_buffer("v3d_cano", torch.as_tensor(entity["pts.cano"], dtype=torch.float32))
         nm = torch.as_tensor(entity["norm_mat"], dtype=torch.float32)
@@ -246,10 +224,13 @@ class ObjectModel(nn.Module):
 
 
 class ObjectServer(nn.Module):
-    def __init__(self, entity: dict):
+    """code/src/model/obj/server.py:19-56; ``entity`` = sequence name (reference signature) or the entity record."""
+
+    def __init__(self, entity, template=None):
         super().__init__()
-        self.object_model = ObjectModel(entity)
-        self.verts_c = self.object_model.v3d_cano[None]
+        self.object_model = ObjectModel(entity, template)
+
+    verts_c = property(lambda self: self.object_model.v3d_cano[None])
 
     def forward(self, scene_scale, transl, thetas, absolute=False):
         o = self.object_model(rot=thetas, trans=transl, scene_scale=scene_scale)

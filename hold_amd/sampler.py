@@ -63,7 +63,41 @@ class ErrorBoundSampler:
             return torch.rand(shape).to(dev)
         return torch.rand(shape, device=dev)
 
-    def get_z_vals(self, sdf_query, ray_dirs, cam_loc, beta0, is_training, rng=None):
+    def get_z_vals(self, sdf_fn, deformer, implicit_network, ray_dirs, cam_loc, density_fn, is_training, deform_info):
+        """The reference's call (code/src/engine/ray_sampler.py:128-138; mano_node.py:99-108, object_node.py:85-94):
+        ``sdf_fn(deformer, implicit_network, training, x [P,3], deform_info) -> (sdf [B,P/B,1], ...)``,
+        ``density_fn`` = the node's LaplaceDensity.  The algorithm (window, bound, beta search, inverse CDF) runs in
+        the sampler kernels; the SDF query is whatever callable is passed -- hold_amd.volsdf_utils.
+        sdf_func_with_deformer evaluates it with the fused HIP trunk."""
+        from . import volsdf_utils as VU
+        from .hold_net import ImplicitNet
+        tfs = deform_info["tfs"]
+        B = tfs.shape[0]
+        beta0 = density_fn.get_beta().item() if hasattr(density_fn, "get_beta") else float(density_fn)
+        if sdf_fn is VU.sdf_func_with_deformer and isinstance(implicit_network, ImplicitNet):
+            # fast path: KNN inverse LBS + the fused LDS-resident trunk, no [P,257] intermediate
+            from .field import pack_weights
+            fld = implicit_network._field(ray_dirs.device, "sampler")
+            nb = fld.spec.n_bones
+            with torch.no_grad():
+                iw, ib = implicit_network.effective()
+                pk = pack_weights(fld.spec, iw, ib, None, None, need_bwd=False)
+                dfm = dict(tfs=tfs.detach().reshape(B, nb, 16).contiguous().float())
+                if nb > 1:
+                    dfm["verts"] = deform_info["verts"].detach().contiguous().float()
+                    dfm["skin_w"] = deformer.server.human_layer.lbs_weights.contiguous()
+                barf_w = implicit_network.embedder_obj.weights(ray_dirs.device)
+            return self.sample_z(lambda x, P, out: fld.sdf_only(pk, x, P, P // B, dfm, barf_w, out), ray_dirs, cam_loc,
+                                 beta0, is_training)
+
+        def sdf_query(x, P, out):
+            with torch.no_grad():
+                res = sdf_fn(deformer, implicit_network, is_training, x[:, :3], deform_info)
+            out.copy_(res[0].reshape(P, 1))
+
+        return self.sample_z(sdf_query, ray_dirs, cam_loc, beta0, is_training)
+
+    def sample_z(self, sdf_query, ray_dirs, cam_loc, beta0, is_training, rng=None):
         """sdf_query(x [P,4], P, out [P,1]) evaluates the node's SDF at deformed-space points.
         Returns z_vals [N, N_samples + 2 + N_samples_extra], sorted, no grad."""
         dev = ray_dirs.device

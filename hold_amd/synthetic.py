@@ -20,6 +20,8 @@ NUM_FACES = 1538
 # fingertip vertex ids the reference appends as extra joints
 # (code/src/utils/external/vertex_ids.py:69-75, order thumb,index,middle,ring,pinky)
 MANO_TIP_IDS = np.array([744, 320, 443, 554, 671], dtype=np.int64)
+# wrist-loop vertex ids the reference seals with a fan (common/body_models.py:46-49)
+CIRCLE_V_ID = [108, 79, 78, 121, 214, 215, 279, 239, 234, 92, 38, 122, 118, 117, 119, 120]
 
 
 def make_mano_model(is_rhand: bool = True, seed: int = 7) -> dict:
@@ -50,27 +52,51 @@ def make_mano_model(is_rhand: bool = True, seed: int = 7) -> dict:
     if not is_rhand:
         joints[:, 2] *= -1.0
 
-    # --- vertices: points scattered around the bones (capsules) -----------------------
-    bones = [(int(MANO_PARENTS[j]), j) for j in range(1, NUM_JOINTS)]
-    tips = []
-    for f in range(5):
-        j2 = 3 + 3 * f
-        d = joints[j2] - joints[j2 - 1]
-        tips.append(joints[j2] + d / np.linalg.norm(d) * 0.02)
-    segs = [(joints[a], joints[b], 0.011) for a, b in bones]
-    segs += [(joints[3 + 3 * f], tips[f], 0.008) for f in range(5)]
-    verts = np.zeros((NUM_VERTS, 3), dtype=np.float64)
-    for v in range(NUM_VERTS):
-        s = segs[v % len(segs)]
-        t = rs.uniform(0.0, 1.0)
-        c = s[0] * (1 - t) + s[1] * t
-        n = rs.normal(size=3)
-        n /= np.linalg.norm(n) + 1e-12
-        verts[v] = c + n * s[2] * rs.uniform(0.6, 1.0)
-    # fingertip vertices sit at the tips
-    for f, vid in enumerate(MANO_TIP_IDS):
-        order = [4, 0, 1, 3, 2][f]  # thumb,index,middle,ring,pinky -> finger slot above
-        verts[vid] = tips[order]
+    # --- vertices: a closed, star-shaped "mitten" around the palm centre, open at the wrist ------------
+    # Topology as MANO's: 778 vertices / 1538 faces = a triangulated sphere minus the fan of one valence-16 vertex,
+    # whose ring is the wrist loop CIRCLE_V_ID that seal_mano_mesh closes again (common/body_models.py:46-73).
+    # Directions: a Fibonacci lattice outside a cap around the wrist pole (-x) plus 16 ring directions on the cap's
+    # inner circle; connectivity = convex hull of the directions (+ pole) with the pole's fan removed; positions =
+    # centre + r(direction) * direction, so the surface is an embedded radial graph (no self-intersections).
+    from scipy.spatial import ConvexHull
+    ring_ids = np.array(CIRCLE_V_ID, dtype=np.int64)
+    free_ids = np.array([i for i in range(NUM_VERTS) if i not in set(CIRCLE_V_ID)], dtype=np.int64)
+    alpha = 0.25  # angular radius of the wrist ring around the pole
+    m = len(free_ids)
+    t = -np.cos(1.8 * alpha) + (1.0 + np.cos(1.8 * alpha)) * (np.arange(m) + 0.5) / m  # cos(angle to +x), cap excluded
+    phi = np.arange(m) * np.pi * (3.0 - np.sqrt(5.0))
+    st = np.sqrt(1.0 - t * t)
+    dirs = np.zeros((NUM_VERTS + 1, 3))
+    dirs[free_ids] = np.stack([t, st * np.cos(phi), st * np.sin(phi)], 1)
+    az = 2.0 * np.pi * np.arange(16) / 16.0
+    dirs[ring_ids] = np.stack([-np.cos(alpha) * np.ones(16), np.sin(alpha) * np.cos(az), np.sin(alpha) * np.sin(az)], 1)
+    dirs[NUM_VERTS] = [-1.0, 0.0, 0.0]
+    hull = ConvexHull(dirs)
+    faces = hull.simplices.astype(np.int64)
+    assert faces.shape[0] == 2 * (NUM_VERTS + 1) - 4, faces.shape
+    tri = dirs[faces]
+    flip = np.einsum("fi,fi->f", np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), tri.mean(1)) < 0
+    faces[flip] = faces[flip][:, [0, 2, 1]]  # outward orientation
+    fan = (faces == NUM_VERTS).any(1)
+    assert fan.sum() == 16 and set(faces[fan].ravel()) - {NUM_VERTS} == set(CIRCLE_V_ID)
+    # the reference's seal faces are [ring[i-1], ring[i], 778]: the ring must run so that they face outward too
+    f0 = [f for f in faces[fan] if ring_ids[0] in f and ring_ids[1] in f][0].tolist()
+    k = f0.index(int(ring_ids[0]))
+    if f0[(k + 1) % 3] != int(ring_ids[1]):  # hull fan runs the other way round: mirror the ring's azimuth
+        dirs[ring_ids, 2] *= -1.0
+        dirs[free_ids, 2] *= -1.0
+        faces = faces[:, [0, 2, 1]]
+    faces = faces[~fan]
+    assert faces.shape[0] == NUM_FACES
+    ax = np.array([0.085, 0.022, 0.070])
+    d = dirs[:NUM_VERTS]
+    r = 1.0 / np.sqrt(((d / ax) ** 2).sum(1))
+    r *= 1.0 + 0.10 * np.sin(3.0 * np.arctan2(d[:, 2], d[:, 0])) * (1.0 - d[:, 1] ** 2)
+    verts = np.array([0.045, 0.0, 0.01]) + d * r[:, None]
+    if not is_rhand:  # mirrored hand: z -> -z flips the orientation, so swap two corners of every face
+        verts[:, 2] *= -1.0
+        faces = faces[:, [1, 0, 2]]
+    tips = [verts[vid] for vid in MANO_TIP_IDS]
 
     # --- skinning weights: soft assignment to nearest joints, rows sum to 1 ------------
     d2 = ((verts[:, None, :] - joints[None, :, :]) ** 2).sum(-1)
@@ -90,13 +116,6 @@ def make_mano_model(is_rhand: bool = True, seed: int = 7) -> dict:
     posedirs = rs.normal(scale=0.0004, size=(NUM_VERTS, 3, 135))
     hands_components = np.linalg.qr(rs.normal(size=(45, 45)))[0]
     hands_mean = rs.normal(scale=0.12, size=45)
-
-    # --- faces: any valid triangle list (only used by meshing / loss targets) ----------
-    order = np.argsort(verts[:, 0] + 0.3 * verts[:, 2])
-    faces = np.stack(
-        [order[np.arange(NUM_FACES) % NUM_VERTS], order[(np.arange(NUM_FACES) + 1) % NUM_VERTS],
-         order[(np.arange(NUM_FACES) + 7) % NUM_VERTS]], axis=1
-    ).astype(np.int64)
 
     kintree = np.stack([MANO_PARENTS.copy(), np.arange(NUM_JOINTS)], axis=0).astype(np.int64)
     kintree[0, 0] = 4294967295  # as in the MANO pickle; reference overwrites with -1

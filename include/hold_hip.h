@@ -117,6 +117,15 @@ int hold_knn_invlbs_fwd(const float* x, int32_t ldx, int64_t P, int64_t pts_per_
  * frame (n_bones = 1: ObjectDeformer.forward inverse, code/src/model/obj/deformer.py:10-41). */
 int hold_invskin_fwd(const float* x, int32_t ldx, int64_t P, int64_t pts_per_frame, const float* w, const float* tfs,
                      int32_t n_bones, float* xc, int32_t ldxc, hold_stream_t stream);
+/* ray generation: get_camera_params / lift, code/src/datasets/utils.py:230-282 (pose-matrix branch),
+ * plus the per-ray broadcast of the camera centre (mano_node.py:87-92).  uv [B][rays_per_frame][2] pixel coordinates,
+ * pose [B][4][4] camera-to-world, intrinsics [B][ld][ld] (ld = 3 or 4) -> ray_dirs [n_rays][3] unit, cam_loc [n_rays][3]. */
+int hold_raygen(const float* uv, const float* pose, const float* intrinsics, int32_t ld_intr, int64_t n_rays,
+                int64_t rays_per_frame, float* ray_dirs, float* cam_loc, hold_stream_t stream);
+/* forward LBS of query points, cano -> deformed: x' = (sum_j w_j T_j) [x;1] (skinning(inverse=False),
+ * code/src/model/mano/deformer.py:145-170; n_bones = 1: ObjectDeformer.forward, obj/deformer.py:10-31). */
+int hold_skin_fwd(const float* x, int32_t ldx, int64_t P, int64_t pts_per_frame, const float* w, const float* tfs,
+                  int32_t n_bones, float* xd, int32_t ldxd, hold_stream_t stream);
 int hold_invskin_bwd(const float* xc, int32_t ldxc, const float* w, const float* tfs, int32_t n_bones, int64_t P,
                      int64_t pts_per_frame, const float* xcbar, int32_t ldxb, float* dtfs /* [B][n_bones][16], += */,
                      hold_stream_t stream);
@@ -307,6 +316,48 @@ int hold_chain(const hold_chain_desc* d, hold_stream_t stream);
  * ---------------------------------------------------------------------------------------- */
 int hold_mesh_sdf(const float* pts, int32_t B, int64_t P, const float* verts, int32_t verts_shared, int32_t V,
                   const int32_t* faces, int32_t F, float cull_dist, const float* aabb, float* sd, hold_stream_t stream);
+
+/* ---- step tail: per-pixel loss terms and the optimiser step on one flat fp32 bucket ----
+ * hold_pixel_loss_fwd/bwd: the ray-wise terms of Loss.forward (code/src/hold/loss.py:17-93) in one launch each --
+ *   sums[0] = sum |rgb - gt| over rows without NaN, sums[2] = number of such rows (loss_terms.get_rgb_loss :14-20)
+ *   sums[1] = sum (semantics - onehot(class(gt_mask)))^2     (get_sem_loss :67-98; class bounds 25 / 100 / 200)
+ *   sums[3+2i], sums[4+2i] = sum / count of node i's mask_prob over its off-surface rays (get_opacity_sparse_loss :44-56)
+ * the host divides by the pixel counts and applies the schedule weights; bwd takes g = dL/d sums and writes
+ * d rgb [N,3], d semantics [N,4], d mask_prob_i [N] (rows outside the index get 0).
+ * hold_sumsq + hold_adam_step: torch.optim.Adam(eps=1e-8) of code/src/hold/hold.py:79-101 over a flat bucket whose
+ * first n_low elements (the per-frame pose tables) use lr_low = 0.1 lr, with clip_grad_norm_(0.5) of code/train.py:30
+ * folded in: grads are scaled by grad_mul * min(1, clip_norm / (sqrt(sumsq[0]) * |grad_mul| + 1e-6)); sumsq is a
+ * DEVICE scalar (no host sync).  step >= 1 is the 1-based Adam step used for the bias corrections. */
+typedef struct hold_loss_nodes {
+  const float* mask_prob[3];
+  const uint8_t* off[3]; /* bool index_off_surface per ray, NULL = node has no target yet */
+  float* d_mask[3];      /* bwd only */
+} hold_loss_nodes;
+int64_t hold_reduce_workspace_floats(void); /* scratch of the two-pass (deterministic, atomic-free) reductions */
+int hold_pixel_loss_fwd(const float* rgb, const float* gt_rgb, const float* sem, const float* gt_mask, int64_t N,
+                        int32_t n_nodes, const hold_loss_nodes* nodes, float* sums /* [10], overwritten */,
+                        float* workspace, hold_stream_t stream);
+int hold_pixel_loss_bwd(const float* rgb, const float* gt_rgb, const float* sem, const float* gt_mask, int64_t N,
+                        int32_t n_nodes, const hold_loss_nodes* nodes, const float* g, float* d_rgb, float* d_sem,
+                        hold_stream_t stream);
+int hold_sumsq(const float* x, int64_t n, float* out /* [1] */, int32_t accumulate, float* workspace,
+               hold_stream_t stream);
+int hold_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_low, float lr_low, float lr,
+                   float beta1, float beta2, float eps, int32_t step, float grad_mul, float clip_norm,
+                   const float* sumsq, hold_stream_t stream);
+
+/* ---- canonical meshing: marching tetrahedra on a dense n^3 SDF grid (x-major), replacing MISE +
+ * skimage marching cubes of code/src/utils/meshing.py:9-72 / code/src/libmise/mise.pyx.  Three passes around two host
+ * scans: classify (flags of the 7 lattice edges owned by each grid point, triangle count per cube), vertices (one
+ * per flagged edge, id = exclusive scan of the flags), triangles (vertex ids through the edge scan; winding from the
+ * host-generated case tables tet_corner [6][4], ntri_tab [6][16], tri_tab [6][16][2][3][2], hold_amd/meshing.py). */
+int hold_mt_classify(const float* sdf, int32_t n, float level, const int8_t* ntri_tab, const int8_t* tet_corner,
+                     int32_t* edge_flag /* [n^3][7] */, int32_t* cube_ntri /* [n^3] */, hold_stream_t stream);
+int hold_mt_vertices(const float* sdf, int32_t n, float level, float ox, float oy, float oz, float h,
+                     const int32_t* edge_flag, const int64_t* edge_scan, float* verts /* [V][3] */, hold_stream_t stream);
+int hold_mt_triangles(const float* sdf, int32_t n, float level, const int8_t* ntri_tab, const int8_t* tet_corner,
+                      const int8_t* tri_tab, const int32_t* cube_ntri, const int64_t* cube_scan,
+                      const int64_t* edge_scan, int64_t* faces /* [F][3] */, hold_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Pose-refinement inner loop (hold_amd/csrc/silhouette.hip).

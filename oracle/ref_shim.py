@@ -103,13 +103,32 @@ def install():
     p3dops = _stub("pytorch3d.ops", knn_points=_knn_points)
     p3d.ops = p3dops
     for name in ["trimesh", "cv2", "comet_ml", "pytorch_lightning", "torchmetrics", "omegaconf",
-                 "pymeshlab", "open3d", "imageio"]:
+                 "pymeshlab", "open3d", "imageio", "pygit2"]:
         _stub(name)
     sys.modules["trimesh"].Trimesh = object
     sk = _stub("skimage")
     sk.measure = _stub("skimage.measure")
     _stub("smplx", MANO=object)
     sys.modules["pytorch_lightning"].LightningModule = torch.nn.Module
+    # what code/src/hold/hold.py pulls in at import time (Lightning module, metrics, comet logging, debug plots)
+    pll = _stub("pytorch_lightning.loggers", CometLogger=object)
+    sys.modules["pytorch_lightning"].loggers = pll
+
+    class _PSNR(torch.nn.Module):  # torchmetrics.image.PeakSignalNoiseRatio(data_range=1.0)
+        def __init__(self, data_range=1.0):
+            super().__init__()
+            self.data_range = data_range
+
+        def forward(self, preds, target):
+            return 10.0 * torch.log10(self.data_range ** 2 / ((preds - target) ** 2).mean())
+
+    tmi = _stub("torchmetrics.image", PeakSignalNoiseRatio=_PSNR)
+    sys.modules["torchmetrics"].image = tmi
+    for name in ["matplotlib", "matplotlib.pyplot"]:
+        try:
+            __import__(name)
+        except Exception:
+            _stub(name)
     # src.libmise is a Cython extension that is not built here; only meshing uses it
     _stub("src_libmise_placeholder")
 
