@@ -2,17 +2,28 @@
 """Headline benchmark: rendered rays/sec (fwd+bwd) at 512x512, 64(+2+32 extra) samples per fg node after
 the 128-sample error-bound hierarchy, single-hand scene (right hand + object + background).
 
-One "step" = one full fwd + loss + bwd pass of the HIP hot path over one synthetic 512x512 frame
-(262 144 rays) per GPU, ray-chunked with gradient accumulation, followed (N>1) by the flat RCCL gradient
-all-reduce.  Inputs (rays, poses, weights, gt) are resident in HBM before the timed region.
+One "step" (default --mode train) = zero the gradient bucket + one full forward + Loss + backward pass of the HIP hot
+path over one synthetic 512x512 frame (262 144 rays) per GPU, ray-chunked with gradient accumulation + the optimiser
+step (hold_amd.optim.FlatAdam: RCCL all-reduce of the flat gradient bucket when N > 1, global-norm clip, Adam).
+Inputs (rays, poses, weights, gt) are resident in HBM before the timed region.
 
     python bench.py --gpus 1 --steps 2 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (the MFMA kernel with
-the largest share of the timed region -- chain / fused_sdf / gemm_nt / wgrad, all fp32 MFMA -- measured live with
-events on the launch stream; every kernel's figures under roofline.kernels) and
-`cpu_baseline` (the CPU oracle restatement of the reference timed on this box's host cores).
+Other workloads of BASELINE.json (secondary lines, same JSON contract):
+    --mode render            C2 eval-mode forward only
+    --two-hands              C4-like ARCTIC scene (right + left + object)
+    --mode c3                C3: the reference's own training step (10 frames x 128 rays, full Loss, pose-table
+                             gradients, Adam) in steps/s -> value is still rays/s; plus pose-refinement iters/s
+    --mode c5                C5: 1024x1024 eval render with N_samples = 128 (162 samples per fg node)
+    --loss pixel|full        train modes: rgb + semantic loss only (what round 1 timed) or the full reference Loss
+                             with the canonical-mesh loss targets (eikonal, MANO-cano SDF, opacity sparsity)
+    --fp32-mfma              every matrix product on the fp32 MFMA (default: the sampler trunk and the weight-gradient
+                             kernel use the exact 3-limb bf16 split, see hold_amd/config.py)
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (the MFMA kernel with the largest share
+of the timed region, measured live with events on the launch stream; every kernel's figures under roofline.kernels)
+and `cpu_baseline` (the CPU oracle restatement of the reference timed on this box's host cores).
 """
 import argparse
 import json
@@ -26,7 +37,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 matrix)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 matrix, same guide
+ROUND = "r02"
 
 
 def parse():
@@ -34,26 +47,29 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--res", type=int, default=512)
-    ap.add_argument("--chunk", type=int, default=16384, help="rays per microbatch (≈60 GB of saved activations per fg node)")
+    ap.add_argument("--res", type=int, default=None, help="frame side (default 512; 1024 for --mode c5)")
+    ap.add_argument("--chunk", type=int, default=16384, help="rays per microbatch (~85 GB of saved activations per fg node)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=16, help="cpu baseline renders cpu_rays^2 rays of the frame")
     ap.add_argument("--cpu-threads", type=int, default=32)
-    ap.add_argument("--mode", default="train", choices=["train", "render"],
-                    help="train = fwd+loss+bwd (headline metric); render = eval-mode forward only (secondary)")
+    ap.add_argument("--mode", default="train", choices=["train", "render", "c3", "c5"])
+    ap.add_argument("--loss", default="full", choices=["pixel", "full"])
     ap.add_argument("--two-hands", action="store_true", help="ARCTIC-style scene (right + left + object), config C4")
+    ap.add_argument("--fp32-mfma", action="store_true", help="true-fp32 MFMA everywhere (no split-precision kernels)")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--shape-report", default="", help="write per-(kernel,N,K) launch aggregates to this json file")
+    ap.add_argument("--no-refine", action="store_true", help="--mode c3: skip the pose-refinement leg")
+    ap.add_argument("--shape-report", default="", help="write per-(kernel, flop bucket) launch aggregates to this json file")
     return ap.parse_args()
 
 
-def cpu_baseline(sc, sd_np, side, frame, threads=32):
-    """fwd + loss + bwd of the CPU oracle (port of the reference's PyTorch path) on a side x side crop
-    of the same frame, all host cores."""
+def cpu_baseline(sc, sd_np, threads=32, repeats=3):
+    """The CPU oracle (torch restatement of the reference's PyTorch path, oracle/hold_oracle.py) timed on the host:
+    the reference's own training batch -- 10 frames x 128 random pixels = 1 280 rays (general.yaml:82, tempo_dataset.py
+    :27-36) -- fwd + loss + backward, median of `repeats` steps."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from hold_amd import synthetic as syn
     from hold_amd.train import pixel_losses
     from oracle import hold_oracle as ho
+    from parity_common import oracle_input
 
     # the GPU box exposes 256 hardware threads; torch's intra-op pool stops scaling (and can thrash) far
     # below that on these small per-ray tensors, so the baseline uses the best-measured pool size
@@ -62,27 +78,40 @@ def cpu_baseline(sc, sd_np, side, frame, threads=32):
     mano = {"right": syn.make_mano_model(True), "left": syn.make_mano_model(False)}
     osc = ho.OracleScene(sc, mano)
     sd = {k: torch.as_tensor(v) for k, v in sd_np.items()}
-    from parity_common import oracle_input
-    W = side
-    N = W * W
+    frames = list(range(min(10, sc["n_frames"])))
+    W = 512
     times = []
-    for rep in range(2):
+    for rep in range(repeats):
         sdg = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in sd.items()}
-        b, inp = oracle_input(sc, sdg, [frame], W, W)
         g = torch.Generator().manual_seed(rep)
+        pix = torch.randperm(W * W, generator=g)[:128].numpy()
+        uv = syn.make_uv(W, W)[pix]
+        b = syn.make_batch(sc, frames, uv, W, W)
+        inp = {k: torch.from_numpy(v) for k, v in b.items()}
+        idx = inp["idx"]
+        for nid in sc["entities"]:
+            pre = f"nodes.{nid}.params."
+            if nid == "object":
+                inp["object.global_orient"], inp["object.transl"] = sdg[pre + "global_orient.weight"][idx], sdg[pre + "transl.weight"][idx]
+            else:
+                inp[f"{nid}.global_orient"], inp[f"{nid}.pose"] = sdg[pre + "global_orient.weight"][idx], sdg[pre + "pose.weight"][idx]
+                inp[f"{nid}.transl"] = sdg[pre + "transl.weight"][idx]
+                inp[f"{nid}.betas"] = sdg[pre + "betas.weight"][torch.zeros_like(idx)]
+        N = len(frames) * 128
         rng = {"bg_t": torch.rand(N, 32, generator=g)}
         for n in sc["entities"]:
             rng[n] = {"t_uniform": torch.rand(N, 128, generator=g), "u_final": torch.rand(N, 64, generator=g),
                       "perm": (lambda S: torch.randperm(S))}
         t0 = time.time()
         out = ho.holdnet_forward(osc, sdg, inp, True, rng=rng, current_epoch=0, barf_alpha_iter=4000)
-        loss, _ = pixel_losses(out, torch.from_numpy(b["gt.rgb"]).view(-1, 3), torch.from_numpy(b["gt.mask"]).view(-1),
-                               N, 0)
+        loss, _ = pixel_losses(out, torch.from_numpy(b["gt.rgb"]).view(-1, 3), torch.from_numpy(b["gt.mask"]).view(-1), N, 0)
         loss.backward()
         times.append(time.time() - t0)
-    return {"value": N / min(times), "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"{N} rays ({W}x{W} pixel grid of the same synthetic frame), fwd+loss+bwd, best of 2, "
-                      f"oracle/hold_oracle.py (torch CPU restatement of the reference), {cores} threads"}
+    med = float(np.median(times))
+    return {"value": N / med, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{repeats} training steps of the reference's batch (10 frames x 128 pixels = {N} rays), fwd + rgb/sem "
+                      f"loss + backward, median step {med:.2f} s; oracle/hold_oracle.py (torch CPU restatement of the "
+                      f"reference, pinned to it by tests/golden), {cores} of {os.cpu_count()} host threads"}
 
 
 def gemm_shapes(prof):
@@ -100,13 +129,23 @@ def gemm_shapes(prof):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the separate rocprofv3 --pmc passes of this same command
-    (scripts/pmc.sh -> profiles/r01_pmc_traffic.json, FETCH_SIZE doubled per the gfx950 calibration)."""
-    f = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(f):
-        return None
-    d = json.load(open(f))
-    k = d.get("kernels", {}).get(kernel)
-    return k.get("hbm_bytes_per_launch") if k else None
+    (scripts/pmc.sh -> profiles/<round>_pmc_traffic.json, FETCH_SIZE doubled per the gfx950 calibration)."""
+    for rnd in (ROUND, "r01"):
+        f = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
+        if os.path.exists(f):
+            k = json.load(open(f)).get("kernels", {}).get(kernel)
+            return (k.get("hbm_bytes_per_launch") if k else None), os.path.basename(f)
+    return None, None
+
+
+def refine_bench(dev, iters=60):
+    """C3's pose-refinement inner loop (optimize_ckpt.py -> fitting/model.py:161-200): iterations/s at B = 10 frames,
+    300x300 masks, sealed hand (1 554 faces) + a 5 096-face object."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_fitting", os.path.join(ROOT, "scripts", "bench_fitting.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.run(iters=iters)
 
 
 def main():
@@ -128,41 +167,79 @@ def main():
     torch.cuda.set_device(dev)
 
     import hold_amd
-    from hold_amd import gemm, parallel
+    from hold_amd import gemm, meshing
     from hold_amd import synthetic as syn
-    from hold_amd.train import train_step
+    from hold_amd.hold_net import DEFAULT_SAMPLER
+    from hold_amd.loss import Loss
+    from hold_amd.optim import FlatAdam
+    from hold_amd.train import render_frame, train_step
 
-    n_frames = max(8, world)
+    hold_amd.set_precision("f32" if args.fp32_mfma else "f32x6")
+    training = args.mode in ("train", "c3")
+    W = H = args.res or (1024 if args.mode == "c5" else 512)
+    n_frames = max(16, world) if args.mode == "c3" else max(8, world)
     sc = syn.make_scene(n_frames=n_frames, two_hands=args.two_hands)
     sd_np = syn.make_state_dict(sc, barf_iter=3999)
-    net = hold_amd.build_from_scene(sc, sd_np, device=dev)
+    sampler_opt = dict(DEFAULT_SAMPLER, N_samples=128) if args.mode == "c5" else None
+    net = hold_amd.build_from_scene(sc, sd_np, device=dev, sampler_opt=sampler_opt)
     for node in net.nodes.values():
         node.params.defrost()
         node.implicit_network.embedder_obj.step()
         node.ray_sampler.rng_device = "cuda"  # statistically identical draws without the per-step H2D copy
-    net.train()
-    if args.mode == "render":
-        net.eval()
+    net.train(training)
+    if not training:
         for node in net.nodes.values():
             node.implicit_network.embedder_obj.eval()
-    params = parallel.grad_params(net)
+    loss_fn = None
+    if training and args.loss == "full":
+        # steady-state loss targets (every step after the first canonical-mesh spawn, hold_net.py:154-179): the sealed +
+        # subdivided canonical MANO of each hand (spawned at step % 200 == 0) and the object's canonical mesh
+        loss_fn = Loss()
+        with torch.no_grad():
+            obj = net.nodes["object"]
+            obj.meshing_cano()  # marching tetrahedra of the object's SDF at the reference's resolution (128^3)
+            for nid, node in net.nodes.items():
+                if nid != "object":
+                    so = node.server(torch.full((1,), sc["scene_scale"], device=dev), node.params.transl.weight[:1],
+                                     torch.cat([node.params.global_orient.weight[:1], node.params.pose.weight[:1]], 1),
+                                     node.params.betas.weight[:1])
+                    node.spawn_cano_mano(so)
+    opt = FlatAdam(net, lr=5e-4, clip_norm=0.5) if training else None
 
-    W = H = args.res
-    frame = rank % n_frames
     uv = syn.make_uv(W, H)
-    b = syn.make_batch(sc, [frame], uv, W, H)
-    inp = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
-
+    if args.mode == "c3":  # the reference's batch: 10 frames x 128 random pixels, a different draw every step
+        frames = [(rank * 10 + i) % n_frames for i in range(10)]
+        gpix = torch.Generator().manual_seed(1234 + rank)
+        batches = []
+        for _ in range(4):
+            pix = torch.randperm(W * H, generator=gpix)[:128].numpy()
+            bb = syn.make_batch(sc, frames, uv[pix], W, H)
+            batches.append({k: torch.from_numpy(v).to(dev) for k, v in bb.items()})
+        rays_per_step = 10 * 128
+    else:
+        frame = rank % n_frames
+        b = syn.make_batch(sc, [frame], uv, W, H)
+        inp = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
+        rays_per_step = W * H
     def step(i):
-        if args.mode == "render":
-            from hold_amd.train import render_frame
+        if args.mode in ("render", "c5"):
             render_frame(net, inp, args.chunk)
-            return 0.0, inp["uv"].shape[0] * inp["uv"].shape[1]
-        for p in params:
-            p.grad = None
-        loss, n = train_step(net, inp, args.chunk, step=i, epoch=0)
-        parallel.allreduce_grads(params)
-        return loss, n
+            return 0.0
+        opt.zero_grad()
+        if args.mode == "c3":
+            from hold_amd.train import training_step
+            bi = batches[i % len(batches)]
+            if loss_fn is None:
+                loss, _ = train_step(net, bi, 128, step=i + 1, epoch=0)
+                lv = loss
+            else:
+                loss, _, _ = training_step(net, loss_fn, bi, epoch=0, step=i + 1)
+                loss.backward()
+                lv = loss.detach()
+        else:
+            lv, _ = train_step(net, inp, args.chunk, step=i + 1, epoch=0, loss_fn=loss_fn)
+        opt.step()
+        return lv
 
     for i in range(args.warmup):
         step(i)
@@ -171,11 +248,14 @@ def main():
     torch.cuda.synchronize()
     if not args.no_profile:
         gemm.PROFILE = []
+    from hold_amd import _lib as _L
+    calls0 = _L.CALLS
     t0 = time.perf_counter()
     rays = 0
+    loss = 0.0
     for i in range(args.steps):
-        loss, n = step(args.warmup + i)
-        rays += n
+        loss = step(args.warmup + i)
+        rays += rays_per_step
     torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()
@@ -190,19 +270,37 @@ def main():
     if rank == 0:
         total_rays = rays * world
         iters = {nid: node.ray_sampler.last_iters for nid, node in net.nodes.items()}
+        x6 = hold_amd.precision() == "f32x6"
+        scene = ("configs[3]-like ARCTIC two-hand (right+left+object+background), " if args.two_hands else
+                 "hold_bottle1_itw-like single-hand (right+object+background), ")
+        if args.mode == "c3":
+            workload = ("configs[2]: the reference's training step -- 10 frames x 128 random pixels = 1 280 rays, " + scene +
+                        f"fwd + {'full Loss (loss targets on)' if loss_fn else 'rgb/sem loss'} + bwd incl. pose-table "
+                        "gradients + clip + Adam")
+            metric = "rendered rays/sec (fwd+bwd) at the reference's 1 280-ray training batch -- secondary metric (configs[2])"
+        elif args.mode == "c5":
+            workload = (f"configs[4]: batch render, 1 sequence per GPU, {W}x{H} = {W * H} rays, N_samples = 128 (162 "
+                        "samples per fg node), eval forward only, frame stays on the device")
+            metric = "rendered rays/sec (forward only, eval mode) at 1024x1024, 128 samples -- secondary metric (configs[4])"
+        else:
+            workload = ("configs[1]: " + scene + f"1 frame {W}x{H} = {W * H} rays per GPU, 128-sample error-bound hierarchy -> "
+                        "64 importance + 2 + 32 extra samples per fg node, 32 bg samples, " +
+                        ("fwd + " + ("full reference Loss (eikonal, MANO-cano SDF, opacity-sparsity targets on)" if loss_fn else
+                                     "rgb/sem loss") + " + bwd + grad clip + Adam step" if training else "eval forward only"))
+            metric = ("rendered rays/sec (fwd+bwd) at 512x512, 64+64 samples" if training else
+                      "rendered rays/sec (forward only, eval mode) -- secondary metric")
         res = {
-            "metric": "rendered rays/sec (fwd+bwd) at 512x512, 64+64 samples" if args.mode == "train" else
-                      "rendered rays/sec (forward only, eval mode) -- secondary metric",
-            "value": total_rays / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("configs[3]-like ARCTIC two-hand (right+left+object+background), " if args.two_hands else
-                                    "configs[1]: hold_bottle1_itw-like single-hand (right+object+background), ") +
-                                   f"1 frame {W}x{H} = {W * H} rays per GPU, 128-sample error-bound hierarchy -> "
-                                   "64 importance + 2 + 32 extra samples per fg node, 32 bg samples, fwd+loss+bwd",
-                       "chunk_rays": args.chunk, "sampler_rounds_last_chunk": iters,
-                       "parallelism": f"dp{world} (frames sharded, flat RCCL grad all-reduce)",
-                       "loss": float(loss)},
+            "metric": metric, "value": total_rays / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": ("f32 (3-limb bf16 split, fp32 accumulate, on the sampler trunk + weight gradients; fp32 MFMA elsewhere)"
+                      if x6 else "f32"),
+            "data": "synthetic",
+            "config": {"workload": workload, "chunk_rays": args.chunk if args.mode != "c3" else 1280,
+                       "sampler_rounds_last_call": iters, "loss_terms": args.loss if training else None,
+                       "parallelism": f"dp{world} (frames sharded, one RCCL all-reduce of the flat gradient bucket)",
+                       "loss": float(loss), "precision": hold_amd.precision(),
+                       "steps_per_s": args.steps / dt},
         }
         if prof:
             agg = {}
@@ -212,30 +310,51 @@ def main():
                 a[1] += fl
                 a[2] += 1
             if args.shape_report:
-                shp = {}
-                for e0, e1, fl, name in prof:
-                    pass
-                json.dump({k: v for k, v in gemm_shapes(prof).items()}, open(args.shape_report, "w"), indent=1)
+                json.dump(gemm_shapes(prof), open(args.shape_report, "w"), indent=1)
+            split = {"fused_sdf_kernel", "wgrad_kernel"} if x6 else set()
             labels = {"gemm_nt_kernel": "gemm_nt_kernel (one layer per launch, v_mfma_f32_32x32x2_f32)",
                       "chain_kernel": "chain_kernel (7-8 trunk layers per launch, LDS-resident, v_mfma_f32_32x32x2_f32)",
-                      "fused_sdf_kernel": "fused_sdf_pipe_kernel (sampler SDF queries, v_mfma_f32_32x32x2_f32)",
-                      "wgrad_kernel": "wgrad_lds_kernel (weight gradients, v_mfma_f32_32x32x2_f32)"}
+                      "fused_sdf_kernel": ("fused_sdf_x6p_kernel (sampler SDF queries, 3-limb split on v_mfma_f32_32x32x16_bf16)"
+                                           if x6 else "fused_sdf_pipe_kernel (sampler SDF queries, v_mfma_f32_32x32x2_f32)"),
+                      "wgrad_kernel": ("wgrad_lds_kernel<x6> (weight gradients, 3-limb split on v_mfma_f32_32x32x16_bf16)"
+                                       if x6 else "wgrad_lds_kernel (weight gradients, v_mfma_f32_32x32x2_f32)")}
             ent = {}
             for name, (t_, fl_, n_) in agg.items():
-                ent[name] = {"achieved": fl_ / t_ / 1e12, "frac": fl_ / t_ / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                             "launches": n_, "avg_launch_ms": t_ / n_ * 1e3, "time_share": t_ / dt,
-                             "flop_per_launch_avg": fl_ / n_}
+                tf = fl_ / t_ / 1e12
+                ent[name] = {"achieved": tf, "frac": tf / FP32_MFMA_PEAK_TFLOPS, "launches": n_,
+                             "avg_launch_ms": t_ / n_ * 1e3, "time_share": t_ / dt, "flop_per_launch_avg": fl_ / n_,
+                             "arithmetic": "f32x6" if name in split else "f32"}
+                if name in split:  # disclosure: algorithmic (fp32-equivalent) rate vs what the matrix cores actually issue
+                    ent[name]["fp32_equivalent_tflops"] = tf
+                    ent[name]["bf16_mfma_tflops_issued"] = 6.0 * tf
+                    ent[name]["frac_of_bf16_mfma_peak"] = 6.0 * tf / BF16_MFMA_PEAK_TFLOPS
+                    ent[name]["note"] = ("frac is fp32-equivalent FLOP/s over the fp32-MFMA peak (can exceed 1: the kernel does not "
+                                         "run on the fp32 pipe); frac_of_bf16_mfma_peak prices the 6 limb products it issues")
             dom = max(ent, key=lambda k: ent[k]["time_share"])
+            traffic, tsrc = pmc_traffic(dom)
             res["roofline"] = {"bound": "mfma", "achieved": ent[dom]["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ent[dom]["frac"], "traffic": pmc_traffic(dom),
+                               "unit": "TFLOP/s", "frac": ent[dom]["frac"], "traffic": traffic,
                                "kernel": labels.get(dom, dom), "launches": ent[dom]["launches"],
                                "avg_launch_ms": ent[dom]["avg_launch_ms"], "time_share": ent[dom]["time_share"],
                                "flop_per_launch_avg": ent[dom]["flop_per_launch_avg"],
-                               "traffic_note": "HBM bytes/launch of this kernel from separate --pmc passes "
-                                               "(profiles/r01_pmc_traffic.json)",
+                               "arithmetic": ent[dom]["arithmetic"],
+                               "traffic_note": f"HBM bytes/launch of this kernel from separate --pmc passes (profiles/{tsrc})",
                                "kernels": ent}
+            for k in ("fp32_equivalent_tflops", "bf16_mfma_tflops_issued", "frac_of_bf16_mfma_peak", "note"):
+                if k in ent[dom]:
+                    res["roofline"][k] = ent[dom][k]
+            mf = sum(v[1] for v in agg.values())
+            res["roofline"]["end_to_end"] = {"mfma_tflops_fp32_equivalent": mf / dt / 1e12,
+                                             "frac_of_fp32_mfma_peak": mf / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                             "time_in_mfma_kernels": sum(v[0] for v in agg.values()) / dt}
+        res["config"]["c_abi_calls_per_step"] = (_L.CALLS - calls0) / args.steps
+        if args.mode == "c3" and not args.no_refine:
+            try:
+                res["config"]["pose_refine"] = refine_bench(dev)
+            except Exception as e:  # the refinement leg is reported beside the step rate, never instead of it
+                res["config"]["pose_refine"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1 and args.mode == "train" and not args.two_hands:
-            res["cpu_baseline"] = cpu_baseline(sc, sd_np, args.cpu_rays, frame, args.cpu_threads)
+            res["cpu_baseline"] = cpu_baseline(sc, sd_np, args.cpu_threads)
             res["config"]["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
         print(json.dumps(res))
     if dist.is_initialized():

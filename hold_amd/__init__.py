@@ -1,5 +1,7 @@
 """hold_amd -- MI355X-native volumetric hand-object rendering path for HOLD."""
-__all__ = ["build_from_scene", "reference_holdnet", "install", "xdict"]
+from .config import precision, set_precision  # noqa: F401
+
+__all__ = ["build_from_scene", "reference_holdnet", "install", "xdict", "set_precision", "precision"]
 
 
 def build_from_scene(scene, state_dict=None, device="cuda", **kw):

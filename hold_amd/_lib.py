@@ -85,10 +85,16 @@ class ManoModel(C.Structure):
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+# developer-build-only symbols (HOLD_DEV=1 at build time): declared when present
+DEV_SIGNATURES = {
+    "hold_diag_mfma_peak": [_P, _I, _I, _I, _P],
+    "hold_diag_mfma_lds": [_P, _P, _I, _I, _I, _P],
+}
 # every exported symbol of include/hold_hip.h with its argument types (stream is always last)
 SIGNATURES = {
     "hold_gemm_nt": [C.POINTER(GemmDesc), _P],
     "hold_wgrad": [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _P],
+    "hold_wgrad_x6": [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _P],
     "hold_ray_points": [_P, _P, _P, _I, _I, _L, _P, _I, _P],
     "hold_embed_fwd": [_P, _I, _I, _I, _P, _L, _P, _I, _P, _I, _P, _I, _L, _P],
     "hold_embed_bwd": [_P, _I, _I, _P, _L, _P, _I, _P, _I, _I, _P],
@@ -115,12 +121,10 @@ SIGNATURES = {
     "hold_composite_bwd": [C.POINTER(CompositeDesc), _P],
     "hold_bg_composite_fwd": [_P, _P, _P, _I, _I, _L, _P, _P, _P],
     "hold_bg_composite_bwd": [_P, _P, _P, _I, _I, _L, _P, _P, _P, _P],
-    "hold_diag_mfma_peak": [_P, _I, _I, _I, _P],
     "hold_silhouette_fwd": [_P, _I, _I, _P, _I, _F, _F, _F, _F, _I, _I, _F, _F, _P, _P, _P],
     "hold_silhouette_bwd": [_P, _I, _I, _P, _I, _F, _F, _F, _F, _I, _I, _F, _F, _P, _P, _P, _P, _P],
     "hold_knn1_fwd": [_P, _I, _I, _P, _I, _P, _P, _P],
     "hold_knn1_bwd": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P],
-    "hold_diag_mfma_lds": [_P, _P, _I, _I, _I, _P],
     "hold_fused_sdf": [_P, _I, _L, _P, _P, _P, _F, _P, _P, _I, _P],
     "hold_chain": [C.POINTER(ChainDesc), _P],
     "hold_mesh_sdf": [_P, _I, _L, _P, _I, _I, _P, _I, _F, _P, _P, _P],
@@ -152,10 +156,20 @@ def _declare(L):
         fn = getattr(L, name)  # AttributeError here = symbol missing from the shared object
         fn.argtypes = args
         fn.restype = C.c_int
+    for name, args in DEV_SIGNATURES.items():
+        if hasattr(L, name):
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+
+
+CALLS = 0  # number of C-ABI kernel entry points invoked so far (bench.py reports calls per step)
 
 
 def call(name, *args):
     """invoke an exported entry point on the current torch stream; raise on a non-zero code."""
+    global CALLS
+    CALLS += 1
     L = lib()
     code = getattr(L, name)(*args, stream_ptr())
     if code != 0:
@@ -174,5 +188,7 @@ def ptr(t):
 
 
 def check(code, what):
+    global CALLS
+    CALLS += 1
     if code != 0:
         raise RuntimeError(f"libholdhip: {what} failed with code {code}")

@@ -9,10 +9,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(_HERE, "csrc")
 OUT = os.path.join(_HERE, "libholdhip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+# developer build (HOLD_DEV=1 in the environment of the BUILD): adds the diagnostics kernels (csrc/dev/diag.hip) and
+# compiles the timing-ablation / variant-selection environment switches into the launchers (-DHOLD_DEV).  The product
+# library has neither: its entry points are stateless and read no environment variables.
+DEV = os.environ.get("HOLD_DEV") == "1"
 
 
 def sources():
-    return sorted(glob.glob(os.path.join(SRC_DIR, "*.hip")))
+    src = sorted(glob.glob(os.path.join(SRC_DIR, "*.hip")))
+    if DEV:
+        src += sorted(glob.glob(os.path.join(SRC_DIR, "dev", "*.hip")))
+    return src
 
 
 def needs_build():
@@ -32,7 +39,8 @@ def build(force=False, verbose=False):
     for s in sources():
         o = os.path.join(_HERE, "build", os.path.basename(s) + ".o")
         objs.append(o)
-        procs.append((s, subprocess.Popen(["hipcc", *FLAGS, "-c", s, "-o", o], stdout=subprocess.PIPE,
+        procs.append((s, subprocess.Popen(["hipcc", *FLAGS, *(["-DHOLD_DEV"] if DEV else []), "-c", s, "-o", o],
+                                          stdout=subprocess.PIPE,
                                           stderr=subprocess.STDOUT)))
     for s, p in procs:
         out, _ = p.communicate()

@@ -762,8 +762,10 @@ extern "C" int hold_fused_sdf(const float* xc, int32_t ldx, int64_t P, const flo
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return HOLD_E_LAUNCH;
     n_cu = prop.multiProcessorCount;
-    const char* v = getenv("HOLD_FUSED_VARIANT");
-    variant = v ? atoi(v) : 129;  // 129: software-pipelined 128-point blocks (default); 128: un-pipelined; 64: 2 x 64
+    variant = 129;  // 129: software-pipelined 128-point blocks (the product path); 128: un-pipelined; 64: 2 x 64
+#ifdef HOLD_DEV
+    if (const char* v = getenv("HOLD_FUSED_VARIANT")) variant = atoi(v);
+#endif
   }
   const size_t sh128 = (size_t)(128 * ASTR + 128 * ESTR) * sizeof(float);  // 153 600 B, one block per CU
   const size_t sh64 = (size_t)(64 * ASTR + 64 * ESTR) * sizeof(float);     //  76 800 B, two blocks per CU
@@ -786,20 +788,25 @@ extern "C" int hold_fused_sdf(const float* xc, int32_t ldx, int64_t P, const flo
   } else if (variant == 128) {
     const long blocks = (P + 127) / 128;
     int dbg = 0;
+#ifdef HOLD_DEV
     if (const char* e = getenv("HOLD_FUSED_DEBUG")) {  // timing ablations only: parts of the kernel are skipped
       static bool warned = false;
       if (!warned) fprintf(stderr, "libholdhip: HOLD_FUSED_DEBUG=%s -- timing ablation, hold_fused_sdf results are WRONG\n", e);
       warned = true;
       dbg = atoi(e);
     }
+#endif
     hipLaunchKernelGGL((fused_sdf_kernel<4, 1>), dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(512), sh128,
                        (hipStream_t)st, a, dbg);
   } else {
     const long blocks = (P + 63) / 64;
     const long res = 2L * n_cu;
+    int stg = blocks >= 4 * res ? 3 : 0;
+#ifdef HOLD_DEV
+    if (const char* e = getenv("HOLD_FUSED_STAGGER")) stg = atoi(e);
+#endif
     hipLaunchKernelGGL((fused_sdf_kernel<2, 2>), dim3((unsigned)(blocks < res ? blocks : res)), dim3(256), sh64,
-                       (hipStream_t)st, a,
-                       getenv("HOLD_FUSED_STAGGER") ? atoi(getenv("HOLD_FUSED_STAGGER")) : (blocks >= 4 * res ? 3 : 0));
+                       (hipStream_t)st, a, stg);
   }
   return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
 }
@@ -808,7 +815,7 @@ extern "C" int64_t hold_fused_sdf_x6_pack_bytes(void) {
   return (int64_t)(X6_L0_STEPS + 7 * X6_LK_STEPS) * X6_STEP_UNITS * 16;
 }
 
-// EXPERIMENTAL split-precision (3 bf16 limbs, 6 products) variant of hold_fused_sdf; same contract, the weights as
+// split-precision (3 bf16 limbs, 6 products, fp32 accumulate) variant of hold_fused_sdf; same contract, the weights as
 // wpack_x6 (hold_fused_sdf_x6_pack_bytes() bytes, layout in include/hold_hip.h).
 extern "C" int hold_fused_sdf_x6(const float* xc, int32_t ldx, int64_t P, const void* wpack_x6, const float* bias,
                                  const float* w8, float b8, const float* barf_w, float* sdf, int32_t ld_sdf,
@@ -834,8 +841,11 @@ extern "C" int hold_fused_sdf_x6(const float* xc, int32_t ldx, int64_t P, const 
     attr_set = true;
   }
   FusedArgs a = {xc, ldx, (long)P, nullptr, bias, w8, b8, barf_w, sdf, ld_sdf};
-  const char* var = getenv("HOLD_FUSED_X6_VARIANT");
-  if (var && atoi(var) == 1) {  // limb planes in LDS, 64-point blocks (not yet run on hardware)
+  int x6_variant = 1;  // 1: limb planes in LDS, 64-point blocks (the product path, 176 TF-equivalent); 0: split on the fly
+#ifdef HOLD_DEV
+  if (const char* var = getenv("HOLD_FUSED_X6_VARIANT")) x6_variant = atoi(var);
+#endif
+  if (x6_variant == 1) {
     const size_t shp = (size_t)3 * XP_PLANE * 2 + (size_t)(XP_PTS * ESTR + 8 * XP_PTS) * sizeof(float);
     static bool attr_p = false;
     if (!attr_p) {
@@ -850,8 +860,11 @@ extern "C" int hold_fused_sdf_x6(const float* xc, int32_t ldx, int64_t P, const 
     return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
   }
   const long blocks = (P + 127) / 128;
-  const char* sp = getenv("HOLD_X6_SPLIT");
-  if (sp && sp[0] == 't')
+  bool trunc_split = false;
+#ifdef HOLD_DEV
+  if (const char* sp = getenv("HOLD_X6_SPLIT")) trunc_split = sp[0] == 't';
+#endif
+  if (trunc_split)
     hipLaunchKernelGGL(fused_sdf_x6_kernel<true>, dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(512), sh,
                        (hipStream_t)st, a, reinterpret_cast<const bf16x8*>(wpack_x6));
   else

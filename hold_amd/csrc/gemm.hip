@@ -663,12 +663,14 @@ static int launch_gemm(const hold_gemm_desc& d, hipStream_t s) {
   // stagger the second half of a full persistent grid by ~half a tile (s_sleep(127) = 8128 cycles each)
   const int nkk = (d.K + BKc - 1) / BKc;
   int stagger = (tiles >= 2 * resident) ? (nkk * BKc >= 192 ? 2 : 1) : 0;
-  if (const char* dbg = getenv("HOLD_GEMM_DEBUG")) {  // timing ablations only: parts of the kernel are skipped
+#ifdef HOLD_DEV  // developer build only (hold_amd/build.py, HOLD_DEV=1): timing ablations that skip parts of the kernel
+  if (const char* dbg = getenv("HOLD_GEMM_DEBUG")) {
     static bool warned = false;
     if (!warned) fprintf(stderr, "libholdhip: HOLD_GEMM_DEBUG=%s -- timing ablation, hold_gemm_nt results are WRONG\n", dbg);
     warned = true;
     stagger |= atoi(dbg);
   }
+#endif
   switch (d.epilogue) {
 #define HOLD_CASE(E) \
   case E: hipLaunchKernelGGL((gemm_nt_kernel<E, NT>), grid, block, 0, s, d, tiles, stagger); break;
@@ -700,7 +702,9 @@ extern "C" int hold_gemm_nt(const hold_gemm_desc* dp, hold_stream_t stream) {
   if (d.P == 0) return HOLD_OK;
   hipStream_t s = (hipStream_t)stream;
   int wide = d.N > 128;
+#ifdef HOLD_DEV
   if (const char* w = getenv("HOLD_GEMM_TILE")) wide = atoi(w) == 256;
+#endif
   return wide ? launch_gemm<4>(d, s) : launch_gemm<2>(d, s);
 }
 
@@ -708,21 +712,24 @@ extern "C" int64_t hold_wgrad_workspace_floats(int32_t N, int32_t K, int32_t spl
   return (int64_t)splits * ((int64_t)N * K + N);
 }
 
-extern "C" int hold_wgrad(const float* R, int32_t ldr, const float* X, int32_t ldx, int32_t P, int32_t N, int32_t K,
-                          float* dW, int32_t lddw, float* db, int32_t accumulate, int32_t splits, float* workspace,
-                          hold_stream_t stream) {
+// mode 0: fp32 MFMA; 1 / 2: split precision (3 bf16 limbs x 6 products, fp32 accumulate) with the round-to-nearest /
+// truncating limb split (both decompose the 24-bit significand exactly)
+static int wgrad_impl(const float* R, int32_t ldr, const float* X, int32_t ldx, int32_t P, int32_t N, int32_t K,
+                      float* dW, int32_t lddw, float* db, int32_t accumulate, int32_t splits, float* workspace,
+                      hold_stream_t stream, int mode) {
   if (!R || !X || !dW || !workspace || N <= 0 || K <= 0 || P < 0 || splits <= 0) return HOLD_E_ARG;
   hipStream_t s = (hipStream_t)stream;
   const long chunks = ((long)P + 31) / 32;
   if (splits > chunks) splits = (int)(chunks > 0 ? chunks : 1);
   float* part = workspace;
   float* part_b = db ? workspace + (long)splits * N * K : nullptr;
-  const bool lds_ok = !(ldr & 3) && !(ldx & 3) && !((uintptr_t)R & 15) && !((uintptr_t)X & 15) && ldr >= 4 && ldx >= 4 &&
-                      !getenv("HOLD_WGRAD_DIRECT");
-  if (lds_ok && getenv("HOLD_WGRAD_X6")) {  // EXPERIMENTAL split-precision path (128 x 128 tiles)
+  bool lds_ok = !(ldr & 3) && !(ldx & 3) && !((uintptr_t)R & 15) && !((uintptr_t)X & 15) && ldr >= 4 && ldx >= 4;
+#ifdef HOLD_DEV
+  if (getenv("HOLD_WGRAD_DIRECT")) lds_ok = false;
+#endif
+  if (lds_ok && mode != 0) {  // split-precision path (128 x 128 tiles)
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-    const char* sp = getenv("HOLD_X6_SPLIT");
-    if (sp && sp[0] == 't')
+    if (mode == 2)
       hipLaunchKernelGGL((wgrad_lds_kernel<2, 2>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits,
                          part, part_b);
     else
@@ -750,4 +757,20 @@ extern "C" int hold_wgrad(const float* R, int32_t ldr, const float* X, int32_t l
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, part_b, splits,
                        (long)N, N, db, N, accumulate);
   return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+}
+
+extern "C" int hold_wgrad(const float* R, int32_t ldr, const float* X, int32_t ldx, int32_t P, int32_t N, int32_t K,
+                          float* dW, int32_t lddw, float* db, int32_t accumulate, int32_t splits, float* workspace,
+                          hold_stream_t stream) {
+  return wgrad_impl(R, ldr, X, ldx, P, N, K, dW, lddw, db, accumulate, splits, workspace, stream, 0);
+}
+
+extern "C" int hold_wgrad_x6(const float* R, int32_t ldr, const float* X, int32_t ldx, int32_t P, int32_t N, int32_t K,
+                             float* dW, int32_t lddw, float* db, int32_t accumulate, int32_t splits, float* workspace,
+                             hold_stream_t stream) {
+  int mode = 2;
+#ifdef HOLD_DEV
+  if (const char* sp = getenv("HOLD_X6_SPLIT")) mode = sp[0] == 'r' ? 1 : 2;
+#endif
+  return wgrad_impl(R, ldr, X, ldx, P, N, K, dW, lddw, db, accumulate, splits, workspace, stream, mode);
 }

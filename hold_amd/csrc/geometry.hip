@@ -1,7 +1,7 @@
 // Training loss-target geometry without kaolin: signed distance of query points to a closed triangle
 // mesh, replacing kaolin.metrics.trianglemesh.point_to_mesh_distance + kaolin.ops.mesh.check_sign as used by
 // compute_mano_cano_sdf / check_off_in_surface_points_cano_mesh (code/src/engine/volsdf_utils.py:172-217) on the sealed,
-// once-subdivided canonical MANO (3 111 vertices, 6 216 faces; mano_node.py:126-135).
+// once-subdivided canonical MANO (3 110 vertices, 6 216 faces; mano_node.py:126-135).
 //   unsigned distance: min over faces of the distance to the closest point of the triangle (Ericson RTCD 5.1.5)
 //   sign: inside <=> |sum of signed solid angles| > 2 pi (generalised winding number; Van Oosterom & Strackee)
 // One thread per point, the frame's triangles staged through LDS 128 at a time (9 floats each, gathered through the

@@ -19,13 +19,12 @@ import os
 
 import torch
 
+from . import config
 from . import gemm as G
 from . import kernels as K
 
 FEAT = 256
 FUSED_SDF = os.environ.get("HOLD_FUSED_SDF", "1") != "0"  # sampler queries through the fused LDS-resident kernel
-# EXPERIMENTAL: sampler queries through the split-precision (bf16 x 6) fused kernel -- opt-in until hardware-validated
-FUSED_SDF_X6 = os.environ.get("HOLD_FUSED_SDF_X6", "0") == "1"
 # training-path sweeps as LDS-resident layer chains (hold_chain) instead of one hold_gemm_nt per layer
 USE_CHAIN = os.environ.get("HOLD_CHAIN", "1") != "0"
 RIN_X, RIN_N, RIN_POSE, RIN_FEAT = 0, 3, 6, 14
@@ -133,7 +132,7 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
     for l in range(8):
         bias8[l, :pk["b"][l].shape[0]] = pk["b"][l]
     pk["fused"] = (torch.cat(parts).contiguous(), bias8.contiguous())
-    if FUSED_SDF_X6:
+    if config.x6():
         pk["fused_x6"] = pack_x6(W[:8])
     # descending sweeps (hold_chain DSP): layer j contracts over the outputs of trunk layer l = 7 - j, M_j = W_l^T
     parts = []
@@ -228,7 +227,7 @@ class NodeField:
         """no-grad SDF query of the sampler (sdf_func_with_deformer, volsdf_utils.py:150-169).  out_sdf [P,1]."""
         self.gen += 1  # overwrites the pooled canonical points a pending backward would read
         xc, _ = self._deform(x, P, ppf, dfm, want_w=False)
-        if FUSED_SDF and FUSED_SDF_X6:
+        if FUSED_SDF and "fused_x6" in pk:
             K.fused_sdf_x6(xc, P, pk["fused_x6"], pk["fused"][1], pk["w8_sdf"], float(pk["b8_sdf"]), barf_w, out_sdf)
             return
         if FUSED_SDF:

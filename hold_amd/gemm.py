@@ -5,7 +5,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _lib, config
 from ._lib import (EPI_DBWD, EPI_MUL_DRELU, EPI_MUL_DSIG, EPI_MUL_DSP, EPI_NONE, EPI_RELU, EPI_SIGMOID,  # noqa: F401
                    EPI_SOFTPLUS, GemmDesc, check, ptr, stream_ptr)
 
@@ -92,7 +92,8 @@ def wgrad(R, X, dW, db=None, *, N=None, K=None, accumulate=False, splits=None):
     L = _lib.lib()
     ws = _workspace(L.hold_wgrad_workspace_floats(N, K, splits), R.device)
     e0 = _prof_begin()
-    check(L.hold_wgrad(ptr(R), _ld(R), ptr(X), _ld(X), P, N, K, ptr(dW), _ld(dW), ptr(db), 1 if accumulate else 0,
-                       splits, ptr(ws), stream_ptr()), "hold_wgrad")
+    fn = L.hold_wgrad_x6 if config.x6() else L.hold_wgrad
+    check(fn(ptr(R), _ld(R), ptr(X), _ld(X), P, N, K, ptr(dW), _ld(dW), ptr(db), 1 if accumulate else 0,
+             splits, ptr(ws), stream_ptr()), "hold_wgrad")
     _prof_end(e0, 2.0 * P * N * K, "wgrad_kernel")
     return dW

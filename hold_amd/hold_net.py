@@ -558,7 +558,7 @@ class MANONode(Node):
 
     def spawn_cano_mano(self, sample_dict_h):
         """mano_node.py:126-135: seal the pose-corrected canonical vertices (first frame of the batch) and Loop-
-        subdivide once -> 3 111 vertices / 6 216 faces."""
+        subdivide once -> 3 110 vertices / 6 216 faces."""
         so = sample_dict_h.get("output", sample_dict_h)
         v, f = seal_mano_mesh(so["v_posed"].detach(), self.mesh_f_cano, self.is_rhand)
         self.mesh_v_cano_div, self.mesh_f_cano_div = subdivide_loop(v[0].float(), f)

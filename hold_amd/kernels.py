@@ -109,7 +109,7 @@ def fused_sdf(xc, P, wpack, bias8, w8, b8, barf_w, out_sdf):
 
 
 def fused_sdf_x6(xc, P, wpack_x6, bias8, w8, b8, barf_w, out_sdf):
-    """EXPERIMENTAL split-precision (3 bf16 limbs x 6 products) variant of fused_sdf; wpack_x6 from field.pack_x6."""
+    """split-precision (3 bf16 limbs x 6 products, fp32 accumulate) variant of fused_sdf; wpack_x6 from field.pack_x6."""
     assert wpack_x6.numel() * wpack_x6.element_size() == _lib.lib().hold_fused_sdf_x6_pack_bytes()
     from . import gemm as _g
     e0 = _g._prof_begin()

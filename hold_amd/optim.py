@@ -29,10 +29,11 @@ def split_params(net):
     low, low_ids = [], set()
     for node in net.nodes.values():
         for p in node.params.parameters():
-            if p.requires_grad:
+            if p.requires_grad and p.numel():
                 low.append(p)
                 low_ids.add(id(p))
-    main = [p for p in net.parameters() if p.requires_grad and id(p) not in low_ids]
+    # zero-sized parameters (the object's lin_pose.weight is [8, 0]) stay outside the bucket
+    main = [p for p in net.parameters() if p.requires_grad and p.numel() and id(p) not in low_ids]
     return low, main
 
 

@@ -79,6 +79,11 @@ int64_t hold_wgrad_workspace_floats(int32_t N, int32_t K, int32_t splits);
 int hold_wgrad(const float* R, int32_t ldr, const float* X, int32_t ldx, int32_t P, int32_t N, int32_t K,
                float* dW, int32_t lddw, float* db, int32_t accumulate, int32_t splits, float* workspace,
                hold_stream_t stream);
+/* same contract, split-precision arithmetic: both operands are decomposed into three bf16 limbs as they leave LDS
+ * (exact 8+8+8-bit split of the significand), six limb products on v_mfma_f32_32x32x16_bf16, fp32 accumulation. */
+int hold_wgrad_x6(const float* R, int32_t ldr, const float* X, int32_t ldx, int32_t P, int32_t N, int32_t K,
+                  float* dW, int32_t lddw, float* db, int32_t accumulate, int32_t splits, float* workspace,
+                  hold_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Per-point kernels (hold_amd/csrc/points.hip)
@@ -259,7 +264,8 @@ int64_t hold_fused_sdf_pack_floats(void);
 int hold_fused_sdf(const float* xc, int32_t ldx, int64_t P, const float* wpack, const float* bias, const float* w8,
                    float b8, const float* barf_w, float* sdf, int32_t ld_sdf, hold_stream_t stream);
 
-/* EXPERIMENTAL (opt-in via HOLD_FUSED_SDF_X6=1 in hold_amd/field.py; not hardware-validated in round 1): the same
+/* Split-precision variant (selected by hold_amd.set_precision("f32x6"), the default since its round-2 hardware
+ * validation: 1.4e-6 max abs vs the fp32-MFMA kernel, 176 vs 124 TFLOP/s fp32-equivalent): the same
  * contract as hold_fused_sdf with split-precision arithmetic -- every fp32 operand is the exact sum of three bf16 limbs
  * (limb t = bf16 rounding of what limbs < t left over), six of the nine limb products on v_mfma_f32_32x32x16_bf16 with
  * fp32 accumulation (dropped terms <= 2^-24 relative; scripts/split_precision_study.py).
@@ -382,6 +388,7 @@ int hold_knn1_fwd(const float* q, int32_t B, int32_t Nq, const float* t, int32_t
 int hold_knn1_bwd(const float* q, int32_t B, int32_t Nq, const float* t, int32_t Nt, const int32_t* idx, const float* g,
                   float* dq, float* dt_accum, hold_stream_t stream);
 
+#ifdef HOLD_DEV /* developer build only (HOLD_DEV=1 python -m hold_amd.build): hold_amd/csrc/dev/diag.hip */
 /* diagnostic: pure v_mfma_f32_32x32x2_f32 issue loop (blocks x 256 threads, iters x 64 MFMAs per wave);
  * out needs blocks*256 floats; random_operands != 0 feeds 32 pseudo-random operand values per lane (realistic
  * switching power).  Used only to calibrate the MFMA ceiling at the sustained clock. */
@@ -389,6 +396,7 @@ int hold_diag_mfma_peak(float* out, int32_t blocks, int32_t iters, int32_t rando
 /* diagnostic: same MFMA count with A operands read from LDS (mode 2) and B streamed from wsrc (mode 3; >= 64 Ki floats);
  * out needs blocks*512 floats */
 int hold_diag_mfma_lds(float* out, const float* wsrc, int32_t blocks, int32_t iters, int32_t mode, hold_stream_t stream);
+#endif
 
 #ifdef __cplusplus
 }

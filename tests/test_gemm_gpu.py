@@ -124,15 +124,10 @@ def test_fused_sdf_matches_layered_path():
         assert err < 2e-5 * max(1.0, float(ref.abs().max())), (kind, err)
 
 
-@pytest.mark.skipif(__import__("os").environ.get("HOLD_TEST_EXPERIMENTAL") != "1",
-                    reason="hold_fused_sdf_x6 is opt-in until validated on hardware (HOLD_TEST_EXPERIMENTAL=1)")
-@pytest.mark.parametrize("variant,split", [("0", "rne"), ("0", "trunc"), ("1", "rne")])
-def test_fused_sdf_x6_matches_fp32_fused(variant, split, monkeypatch):
-    """split-precision (3 bf16 limbs x 6 products) sampler trunk against the fp32-MFMA fused kernel
-    (variant 0: fp32 activations split on the fly; 1: limb planes in LDS, 64-point blocks)"""
+def test_fused_sdf_x6_matches_fp32_fused():
+    """split-precision (3 bf16 limbs x 6 products) sampler trunk (limb planes in LDS, 64-point blocks -- the product
+    variant; hardware-validated in round 2) against the fp32-MFMA fused kernel"""
     from hold_amd import field as F, kernels as K, synthetic as syn
-    monkeypatch.setenv("HOLD_FUSED_X6_VARIANT", variant)
-    monkeypatch.setenv("HOLD_X6_SPLIT", split)
     dev = _dev()
     sc = syn.make_scene(2)
     sd = {k: torch.as_tensor(v).to(dev) for k, v in syn.make_state_dict(sc, perturb=0.05).items()}
@@ -160,20 +155,25 @@ def test_fused_sdf_x6_matches_fp32_fused(variant, split, monkeypatch):
         assert err < 5e-6 * max(1.0, float(ref.abs().max())), (kind, err)
 
 
-@pytest.mark.skipif(__import__("os").environ.get("HOLD_TEST_EXPERIMENTAL") != "1",
-                    reason="split-precision wgrad (HOLD_WGRAD_X6=1) has not run on hardware yet: HOLD_TEST_EXPERIMENTAL=1")
-@pytest.mark.parametrize("P,N,K", [(4096, 256, 256), (5000, 217, 256), (777, 256, 40), (130, 3, 256)])
-def test_wgrad_x6_matches_fp64(P, N, K, monkeypatch):
+@pytest.mark.parametrize("mode", ["f32x6", "f32"])
+@pytest.mark.parametrize("P,N,K", [(4096, 256, 256), (5000, 217, 256), (777, 256, 40), (130, 3, 256), (70000, 257, 256)])
+def test_wgrad_matches_fp64_in_both_precisions(P, N, K, mode):
+    """hold_wgrad (fp32 MFMA) and hold_wgrad_x6 (3-limb split, fp32 accumulate) against fp64, same tolerance"""
+    import hold_amd
     from hold_amd import gemm
     dev = _dev()
+    prev = hold_amd.precision()
+    hold_amd.set_precision(mode)
     g = torch.Generator().manual_seed(P + N + K)
     R = torch.randn(P, N, generator=g).to(dev)
     X = torch.randn(P, K, generator=g).to(dev)
     ref = R.double().t() @ X.double()
     refb = R.double().sum(0)
-    monkeypatch.setenv("HOLD_WGRAD_X6", "1")
     dW = torch.zeros(N, K, device=dev)
     db = torch.zeros(N, device=dev)
-    gemm.wgrad(R, X, dW, db)
+    try:
+        gemm.wgrad(R, X, dW, db)
+    finally:
+        hold_amd.set_precision(prev)
     assert float((dW.double() - ref).abs().max()) < 3e-5 * max(1.0, float(ref.abs().max()))
     assert float((db.double() - refb).abs().max()) < 3e-5 * max(1.0, float(refb.abs().max()))

@@ -15,14 +15,22 @@ def test_library_exports_every_declared_symbol():
 
     build.build()
     hdr = open(os.path.join(ROOT, "include", "hold_hip.h")).read()
+    dev_only = set(re.findall(r"\b(?:int|int64_t)\s+(hold_[a-z0-9_]+)\s*\(", "".join(re.findall(r"#ifdef HOLD_DEV.*?#endif", hdr, re.S))))
+    assert dev_only == set(_lib.DEV_SIGNATURES)  # diagnostics: developer build only, absent from the product library
+    hdr = re.sub(r"#ifdef HOLD_DEV.*?#endif", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(?:int|int64_t)\s+(hold_[a-z0-9_]+)\s*\(", hdr))
     assert len(declared) >= 27
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
     assert declared - {"hold_abi_version", "hold_wgrad_workspace_floats", "hold_fused_sdf_pack_floats", "hold_chain_pack_floats", "hold_fused_sdf_x6_pack_bytes",
-                       "hold_silhouette_workspace_floats"} == set(_lib.SIGNATURES)
+                       "hold_silhouette_workspace_floats", "hold_reduce_workspace_floats"} == set(_lib.SIGNATURES)
     assert L.hold_abi_version() == 1
+    assert not any(hasattr(L, n) for n in dev_only)
+    # the product library reads no environment variables (stateless C ABI): no getenv import in the shared object
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in syms
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():
