@@ -123,11 +123,13 @@ SIGNATURES = {
     "hold_bg_composite_bwd": [_P, _P, _P, _I, _I, _L, _P, _P, _P, _P],
     "hold_silhouette_fwd": [_P, _I, _I, _P, _I, _F, _F, _F, _F, _I, _I, _F, _F, _P, _P, _P],
     "hold_silhouette_bwd": [_P, _I, _I, _P, _I, _F, _F, _F, _F, _I, _I, _F, _F, _P, _P, _P, _P, _P],
+    "hold_silhouette_max_faces": [_P, _I, _I, _P, _I, _F, _F, _F, _F, _I, _I, _F, _P, _P, _P],
     "hold_knn1_fwd": [_P, _I, _I, _P, _I, _P, _P, _P],
     "hold_knn1_bwd": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P],
     "hold_fused_sdf": [_P, _I, _L, _P, _P, _P, _F, _P, _P, _I, _P],
     "hold_chain": [C.POINTER(ChainDesc), _P],
     "hold_mesh_sdf": [_P, _I, _L, _P, _I, _I, _P, _I, _F, _P, _P, _P],
+    "hold_ray_off_surface": [_P, _I, _L, _I, _P, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P],
     "hold_pixel_loss_fwd": [_P, _P, _P, _P, _L, _I, C.POINTER(LossNodes), _P, _P, _P],
     "hold_pixel_loss_bwd": [_P, _P, _P, _P, _L, _I, C.POINTER(LossNodes), _P, _P, _P, _P],
     "hold_sumsq": [_P, _L, _P, _I, _P, _P],

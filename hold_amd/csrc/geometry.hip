@@ -121,7 +121,90 @@ __global__ __launch_bounds__(256) void mesh_sdf_kernel(const float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Per-ray off-surface test of check_off_in_surface_points_cano_mesh (volsdf_utils.py:189-217) without visiting every
+// face for every sample: off(ray) <=> min over the ray's samples of the signed distance > thr.  Built on two structures
+// made once per canonical-mesh update (hold_amd/geometry.py:MeshIndex):
+//   node_sdf [G^3]  exact signed distances at the nodes of a uniform grid (spacing h, h*sqrt(3) < thr) around the mesh
+//   cell lists      for every grid cell, the triangles whose thr-dilated bounding box touches it (CSR)
+// For a sample x with nearest node g, a = |x - g|, v = sd(g), the 1-Lipschitz bound sd(x) in [v - a, v + a] decides most
+// samples: v - a > thr -> farther than thr outside; v + a <= thr -> sd <= thr.  Only samples in the band in between look
+// at their cell's triangles (exact closest-point distance, early exit at d <= thr); if none is within thr, |sd(x)| > thr
+// > h*sqrt(3) >= 2a, so the segment x-g cannot cross the surface and sign(sd(x)) = sign(v).  The decisions are those of
+// the brute-force kernel above (same distance routine), at a few hundred point-triangle tests per ray instead of
+// samples x faces.  One wavefront per ray: lanes = samples, a ballot ends the ray at the first sample with sd <= thr.
+struct MeshGrid {
+  const float* node_sdf;
+  int G;
+  float ox, oy, oz, h, thr;
+  const int* cell_start;
+  const int* cell_tris;
+  const float* verts;
+  const int* faces;
+};
+
+__global__ __launch_bounds__(256) void ray_off_surface_kernel(const float* __restrict__ xc, int ldx, long n_rays, int S,
+                                                              MeshGrid m, uint8_t* __restrict__ off) {
+  const int lane = threadIdx.x & 63;
+  const long ray = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= n_rays) return;
+  const float inv_h = 1.0f / m.h;
+  const float hi = (float)(m.G - 1);
+  bool any_in = false;
+  for (int s0 = 0; s0 < S && !any_in; s0 += 64) {
+    const int s = s0 + lane;
+    int state = 0;  // 0 = farther than thr outside, 1 = sd <= thr, 2 = undecided
+    float px = 0.f, py = 0.f, pz = 0.f, v = 0.f;
+    int cx = 0, cy = 0, cz = 0;
+    if (s < S) {
+      const float* q = xc + (ray * S + s) * (long)ldx;
+      px = q[0]; py = q[1]; pz = q[2];
+      const float gx = (px - m.ox) * inv_h, gy = (py - m.oy) * inv_h, gz = (pz - m.oz) * inv_h;
+      if (gx >= 0.f && gy >= 0.f && gz >= 0.f && gx <= hi && gy <= hi && gz <= hi) {
+        const int ix = (int)(gx + 0.5f), iy = (int)(gy + 0.5f), iz = (int)(gz + 0.5f);
+        v = m.node_sdf[((long)ix * m.G + iy) * m.G + iz];
+        const float ax = (gx - (float)ix) * m.h, ay = (gy - (float)iy) * m.h, az = (gz - (float)iz) * m.h;
+        const float a = sqrtf(ax * ax + ay * ay + az * az);
+        state = (v - a > m.thr) ? 0 : ((v + a <= m.thr) ? 1 : 2);
+        cx = min((int)gx, m.G - 2); cy = min((int)gy, m.G - 2); cz = min((int)gz, m.G - 2);
+      }
+    }
+    if (__ballot(state == 1)) { any_in = true; break; }
+    if (state == 2) {
+      const long cell = ((long)cx * (m.G - 1) + cy) * (m.G - 1) + cz;
+      const int b = m.cell_start[cell], e = m.cell_start[cell + 1];
+      const V3 x = {px, py, pz};
+      const float thr2 = m.thr * m.thr;
+      bool within = false;
+      for (int k = b; k < e; ++k) {
+        const int* f = m.faces + (long)m.cell_tris[k] * 3;
+        const float *pa = m.verts + (long)f[0] * 3, *pb = m.verts + (long)f[1] * 3, *pc = m.verts + (long)f[2] * 3;
+        const V3 a3 = {pa[0], pa[1], pa[2]}, b3 = {pb[0], pb[1], pb[2]}, c3 = {pc[0], pc[1], pc[2]};
+        if (tri_d2(x, a3, b3, c3) <= thr2) { within = true; break; }
+      }
+      state = (within || v < 0.f) ? 1 : 0;
+    }
+    if (__ballot(state == 1)) any_in = true;
+  }
+  if (lane == 0) off[ray] = any_in ? 0 : 1;
+}
+
 }  // namespace
+
+extern "C" int hold_ray_off_surface(const float* xc, int32_t ldx, int64_t n_rays, int32_t S, const float* node_sdf, int32_t G,
+                                    float ox, float oy, float oz, float h, float thr, const int32_t* cell_start,
+                                    const int32_t* cell_tris, const float* verts, const int32_t* faces, uint8_t* off,
+                                    hold_stream_t st) {
+  if (!xc || !node_sdf || !cell_start || !cell_tris || !verts || !faces || !off || ldx < 3 || S <= 0 || G < 2 || h <= 0.f ||
+      thr <= 0.f || n_rays < 0)
+    return HOLD_E_ARG;
+  if (!(h * 1.7320508f < thr)) return HOLD_E_ARG;  // the sign inference needs h * sqrt(3) < thr
+  if (n_rays == 0) return HOLD_OK;
+  MeshGrid m = {node_sdf, G, ox, oy, oz, h, thr, cell_start, cell_tris, verts, faces};
+  hipLaunchKernelGGL(ray_off_surface_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)st, xc, ldx,
+                     (long)n_rays, S, m, off);
+  return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+}
 
 extern "C" int hold_mesh_sdf(const float* pts, int32_t B, int64_t P, const float* verts, int32_t verts_shared, int32_t V,
                              const int32_t* faces, int32_t F, float cull_dist, const float* aabb, float* sd,

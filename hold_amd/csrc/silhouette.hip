@@ -255,7 +255,47 @@ inline int ok() { return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUN
 
 }  // namespace
 
+// number of faces contributing to a pixel (inside, or within the blur radius), maximum over the frame batch: the check
+// behind pytorch3d's faces_per_pixel = 100 cap (fitting/utils.py:107) -- while no pixel sees more than K faces the cap
+// is inactive and the product over ALL faces (what silhouette_kernel computes) is what the capped rasteriser returns
+__global__ __launch_bounds__(256) void silhouette_count_kernel(const FaceSetup* __restrict__ fs, int F, int H, int W,
+                                                               float blur, int* __restrict__ max_count) {
+  const int b = blockIdx.z;
+  const int tx = threadIdx.x % TILE, ty = threadIdx.x / TILE;
+  const int j = blockIdx.x * TILE + tx, i = blockIdx.y * TILE + ty;
+  const float s = 0.5f * (float)(H < W ? H : W);
+  const float px = -((j + 0.5f) - 0.5f * W) / s, py = -((i + 0.5f) - 0.5f * H) / s;
+  int cnt = 0;
+  if (i < H && j < W) {
+    const FaceSetup* fb = fs + (long)b * F;
+    for (int f = 0; f < F; ++f) {
+      const FaceSetup cur = fb[f];
+      if (cur.valid == 0.f || cur.xmax < px || cur.xmin > px || cur.ymax < py || cur.ymin > py) continue;
+      float d, t;
+      int e;
+      if (face_dist(cur, px, py, blur, d, e, t)) ++cnt;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt = max(cnt, __shfl_down(cnt, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(max_count, cnt);
+}
+
 extern "C" int64_t hold_silhouette_workspace_floats(int32_t B, int32_t F) { return (int64_t)B * F * 12; }
+
+extern "C" int hold_silhouette_max_faces(const float* v3d_c, int32_t B, int32_t V, const int32_t* faces, int32_t F, float fx,
+                                         float fy, float cx, float cy, int32_t H, int32_t W, float blur_radius,
+                                         float* workspace, int32_t* max_count, hold_stream_t st) {
+  if (!v3d_c || !faces || !workspace || !max_count || B <= 0 || V <= 0 || F <= 0 || H <= 0 || W <= 0) return HOLD_E_ARG;
+  hipStream_t s = (hipStream_t)st;
+  FaceSetup* fs = reinterpret_cast<FaceSetup*>(workspace);
+  hipLaunchKernelGGL(face_setup_kernel, dim3((unsigned)(((long)B * F + 255) / 256)), dim3(256), 0, s, v3d_c, V, faces, F,
+                     B, fx, fy, cx, cy, H, W, blur_radius, fs);
+  if (hipMemsetAsync(max_count, 0, sizeof(int32_t), s) != hipSuccess) return HOLD_E_LAUNCH;
+  hipLaunchKernelGGL(silhouette_count_kernel, dim3((W + TILE - 1) / TILE, (H + TILE - 1) / TILE, B), dim3(256), 0, s, fs, F,
+                     H, W, blur_radius, max_count);
+  return ok();
+}
 
 extern "C" int hold_silhouette_fwd(const float* v3d_c, int32_t B, int32_t V, const int32_t* faces, int32_t F, float fx,
                                    float fy, float cx, float cy, int32_t H, int32_t W, float sigma, float blur_radius,

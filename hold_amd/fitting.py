@@ -62,6 +62,30 @@ def soft_silhouette(v3d_c, faces, fx, fy, cx, cy, H, W, sigma=SIGMA, blur=BLUR):
                                int(H), int(W), float(sigma), float(blur))
 
 
+FACES_PER_PIXEL = 100  # RasterizationSettings(faces_per_pixel=100), fitting/utils.py:107
+
+
+def max_faces_per_pixel(v3d_c, faces, fx, fy, cx, cy, H, W, blur=BLUR):
+    """largest number of faces contributing to any pixel (hold_silhouette_max_faces) -- one host read."""
+    v = v3d_c.detach().contiguous().float()
+    f = faces.to(torch.int32).contiguous()
+    B, V, _ = v.shape
+    ws = torch.empty(int(_lib.lib().hold_silhouette_workspace_floats(B, f.shape[0])), device=v.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=v.device)
+    call("hold_silhouette_max_faces", ptr(v), B, V, ptr(f), f.shape[0], float(fx), float(fy), float(cx), float(cy), int(H), int(W),
+         float(blur), ptr(ws), ptr(cnt))
+    return int(cnt)
+
+
+def check_faces_per_pixel(v3d_c, faces, fx, fy, cx, cy, H, W, blur=BLUR):
+    """raise if pytorch3d's K = 100 nearest-faces cap would be active (then the uncapped product differs from it)."""
+    k = max_faces_per_pixel(v3d_c, faces, fx, fy, cx, cy, H, W, blur)
+    if k > FACES_PER_PIXEL:
+        raise NotImplementedError(f"{k} faces overlap one pixel: the reference rasteriser keeps only the {FACES_PER_PIXEL} "
+                                  "nearest (fitting/utils.py:107); hold_silhouette_fwd multiplies over all of them")
+    return k
+
+
 class _Knn1Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, t):
@@ -236,3 +260,192 @@ class FittingModelIH(torch.nn.Module):
         return loss_fn_ih(self.fwd_params(), self.targets, self.contact_idx)
 
     fit = FittingModel.fit
+
+
+# ------------------------------------------------------------------------------------------ reference call surface
+SEGM_IDS = {"bg": 0, "object": 50, "right": 150, "left": 250}  # code/src/utils/const.py:1
+
+
+def construct_targets(target_masks):
+    """fitting/utils.py:161-166"""
+    return {k: (target_masks == SEGM_IDS[k]).float() for k in ("object", "right", "left")}
+
+
+def scaling_masks_K(masks, K, target_dim):
+    """fitting/utils.py:189-212: nearest-neighbour resize so the longer side is target_dim, intrinsics scaled alike."""
+    B, im_h, im_w = masks.shape
+    k = target_dim / max(im_h, im_w)
+    masks = torch.nn.functional.interpolate(masks[:, None], size=(int(im_h * k), int(im_w * k)), mode="nearest")[:, 0]
+    K4 = torch.eye(4, device=K.device)
+    K4[:3, :3] = K[0]
+    Ks = torch.diag(torch.tensor([k, k, 1.0, 1.0], device=K.device)) @ K4
+    return masks, Ks[None].repeat(B, 1, 1)
+
+
+class MyParameterDict(torch.nn.ParameterDict):
+    """fitting/utils.py:281-294"""
+
+    def search(self, keyword):
+        sub = MyParameterDict()
+        for key, value in self.items():
+            if keyword in key:
+                sub[key] = value
+        return sub
+
+    def fuzzy_get(self, keyword):
+        for k, v in self.items():
+            if keyword in k:
+                return v
+        return None
+
+
+def _forward_param(server, pd):
+    """GenericServer.forward_param / ObjectServer.forward_param (mano/server.py:101-113, obj/server.py:49-56)."""
+    go, transl = pd.fuzzy_get("global_orient"), pd.fuzzy_get("transl")
+    B = go.shape[0]
+    scale = pd.fuzzy_get("scene_scale").view(-1).repeat(B)
+    pose = pd.fuzzy_get("__pose")
+    if pose is None:
+        return server.forward(scale, transl, go)
+    return server.forward(scale, transl, torch.cat((go, pose), dim=1), pd.fuzzy_get("betas").repeat(B, 1))
+
+
+class Model(torch.nn.Module):
+    """``Model`` of code/src/fitting/model.py:30-200 with the reference's constructor and methods: any set of nodes
+    (right / left / object), every entry of ``param_dict`` a Parameter (keys ``model.nodes.<entity>.params.<name>.weight``
+    -> ``<entity>__<name>``), ``obj_scale`` learnable, the loss picked from the node set (:64-78), Adam(1e-2) +
+    ReduceLROnPlateau(patience 30) (:146-151), ``fit`` stopping on NaN or lr < 1e-5 (:161-200).  Rendering, the MANO
+    LBS and the nearest-neighbour contact term run on the HIP kernels."""
+
+    def __init__(self, servers, scene_scale, obj_scale, param_dict, device, target_masks, w2c, K, fnames, faces,
+                 contact_idx=None):
+        super().__init__()
+        self.w2c, self.servers, self.faces, self.fnames = w2c, servers, faces, fnames
+        self.imsize = (target_masks.shape[1], target_masks.shape[2])
+        self.node_ids = list(servers.keys())
+        self.scene_scale = scene_scale.clone().to(device)
+        self.obj_scale = torch.nn.Parameter(torch.as_tensor(np.array(obj_scale), dtype=torch.float32).clone().to(device))
+        new = {}
+        for key, val in param_dict.items():
+            parts = key.split(".")
+            new[f"{parts[2]}__{parts[4]}"] = torch.nn.Parameter(val)
+        for node_id in servers.keys():
+            new[f"{node_id}__scene_scale"] = torch.nn.Parameter(self.scene_scale)
+        self.param_dict = MyParameterDict(new)
+        self.targets = construct_targets(target_masks)
+        self.K = K.clone()
+        if contact_idx is None:  # fitting.py:10-13 / loss.py:29-32 read it from ./body_models/contact_zones.pkl
+            import pickle
+            with open("./body_models/contact_zones.pkl", "rb") as f:
+                cz = pickle.load(f)["contact_zones"]
+            contact_idx = np.array([i for sub in cz.values() for i in sub])
+        self.contact_idx = torch.as_tensor(np.asarray(contact_idx), dtype=torch.long, device=device)
+        if "left" in self.node_ids and "right" in self.node_ids:
+            self.loss_fn = lambda out, tg: loss_fn_ih(out, tg, self.contact_idx)
+        elif "left" in self.node_ids:
+            self.loss_fn = lambda out, tg: loss_fn_h(out, tg, "left", self.contact_idx)
+        elif "right" in self.node_ids:
+            self.loss_fn = lambda out, tg: loss_fn_h(out, tg, "right", self.contact_idx)
+        else:
+            raise AssertionError(f"Unknown node ids: {self.node_ids}")
+        self.pbar = None
+        self._k_checked = False
+
+    def freeze_all(self):
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def defrost_all(self):
+        for p in self.parameters():
+            p.requires_grad = True
+
+    def print_requires_grad(self):
+        print("requires_grad status:")
+        for n, p in self.named_parameters():
+            print(f"\t{n}: {p.requires_grad}")
+
+    def fwd_params(self):
+        from .xdict import xdict
+        H, W = self.imsize
+        K0 = self.K[0] if self.K.dim() == 3 else self.K
+        fx, fy, cx, cy = float(K0[0, 0]), float(K0[1, 1]), float(K0[0, 2]), float(K0[1, 2])
+        R, T = self.w2c[:, :3, :3], self.w2c[:, :3, 3:]
+        out_dict = xdict()
+        self.servers["object"].object_model.obj_scale = self.obj_scale
+        for node_id in self.node_ids:
+            out = dict(_forward_param(self.servers[node_id], self.param_dict.search(node_id)))
+            v3d_c = rigid_tf(out["verts"], R, T)
+            out["v3d_c"] = v3d_c
+            if node_id in ("right", "left"):
+                v_s, f_s = seal_mano_mesh(v3d_c, self.faces[node_id], node_id == "right")
+            else:
+                v_s, f_s = v3d_c, self.faces[node_id]
+            if not self._k_checked:  # once per batch: the K = 100 cap of the reference rasteriser must be inactive
+                check_faces_per_pixel(v_s, f_s, fx, fy, cx, cy, H, W)
+            out["mask"] = soft_silhouette(v_s, f_s, fx, fy, cx, cy, H, W)
+            out_dict.merge(xdict(out).prefix(node_id + "."))
+        out_dict["K"] = self.K.clone()
+        self._k_checked = True
+        return out_dict
+
+    def forward(self):
+        out = self.fwd_params()
+        return self.loss_fn(out, self.targets), out
+
+    def setup_optimizer(self):
+        self.optimizer = torch.optim.Adam(self.parameters(), lr=1e-2)
+        self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, patience=30)
+
+    def fit(self, num_iterations=200, vis_every=50, write_gif=False, out_ps=None):
+        """model.py:161-200 (gif writing is visual QA outside the path and is not reproduced).  Returns the loss history."""
+        tol_lr = 1e-5
+        hist = []
+        for _ in range(num_iterations):
+            self.optimizer.zero_grad()
+            loss_dict, _ = self()
+            loss = loss_dict["loss"]
+            if torch.isnan(loss) > 0:
+                break
+            loss.backward()
+            self.optimizer.step()
+            self.scheduler.step(loss)
+            hist.append(float(loss))
+            if self.optimizer.param_groups[0]["lr"] < tol_lr:
+                break
+        return hist
+
+
+def extract_batch_data(batch_idx, out, masks, device):
+    """fitting/utils.py:297-330 with the mask images already decoded (``masks`` [n_frames,H,W] of SEGM ids; the reference
+    opens PNGs here): per-batch masks, scene scale, the batch's rows of every parameter, file names, world->camera."""
+    idx = np.asarray(batch_idx)
+    masks_batch = torch.as_tensor(np.asarray(masks)[idx], dtype=torch.float32).to(device)
+    scene_scale = out["scene_scale"].to(device)
+    pd = {k: (v[idx].to(device) if ".betas" not in k else v.to(device)) for k, v in out["param_dict"].items()}
+    return masks_batch, scene_scale, pd, [out["fnames"][i] for i in batch_idx], out["w2c"].repeat(len(batch_idx), 1, 1).to(device)
+
+
+def optimize_batch(batch_idx, args, pbar, out, device, obj_scale=None, freeze_scale=False, freeze_shape=False, masks=None,
+                   contact_idx=None):
+    """code/src/fitting/fitting.py:22-76.  ``out``: {servers, faces, K, w2c, scene_scale, param_dict, fnames}; ``masks``:
+    decoded SEGM-id masks of all frames (the reference reads them from disk next to out["fnames"])."""
+    masks_batch, scene_scale, param_batch, fnames_batch, w2c_batch = extract_batch_data(batch_idx, out, masks, device)
+    masks_batch, K_scaled = scaling_masks_K(masks_batch, out["K"], target_dim=300)
+    model = Model(out["servers"], scene_scale, obj_scale, param_batch, device, masks_batch, w2c_batch, K_scaled,
+                  fnames_batch, out["faces"], contact_idx=contact_idx)
+    model.pbar = pbar
+    model.defrost_all()
+    model.obj_scale.requires_grad = not freeze_scale
+    for k in model.param_dict.keys():
+        if "betas" in k and freeze_shape:
+            model.param_dict[k].requires_grad = False
+        if "pose" in k:
+            model.param_dict[k].requires_grad = False
+        if "global_orient" in k and "object" not in k:
+            model.param_dict[k].requires_grad = False
+        if "scene_scale" in k:
+            model.param_dict[k].requires_grad = False
+    model.setup_optimizer()
+    model.history = model.fit(num_iterations=getattr(args, "iters", 300), vis_every=getattr(args, "vis_every", 50),
+                              write_gif=False)
+    return model

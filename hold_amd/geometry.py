@@ -27,6 +27,72 @@ def mesh_sdf(points, verts, faces, cull_dist=0.0):
     return out
 
 
+class MeshIndex:
+    """Acceleration structure for the per-ray off-surface test against ONE canonical mesh and ONE threshold (built when
+    the loss-target mesh changes: every 200 steps for a hand, every canonical re-meshing for the object): exact signed
+    distances at the nodes of a uniform grid with h * sqrt(3) < threshold, and per-cell lists of the triangles whose
+    threshold-dilated bounding box touches the cell.  See csrc/geometry.hip:ray_off_surface_kernel for how the two
+    decide ``min over a ray's samples of sd > threshold`` with the decisions of the brute-force test."""
+
+    def __init__(self, verts, faces, threshold, max_nodes=160):
+        assert verts.dim() == 2 and faces.dim() == 2
+        dev = verts.device
+        self.verts = verts.detach().contiguous().float()
+        self.faces = faces.to(torch.int32).contiguous()
+        self.thr = float(threshold)
+        lo, hi = self.verts.min(0).values, self.verts.max(0).values
+        ext = float((hi - lo).max())
+        h = 0.5 * self.thr  # h * sqrt(3) = 0.87 thr < thr
+        margin = self.thr + 2.0 * h
+        G = int(torch.ceil(torch.tensor((ext + 2 * margin) / h))) + 1
+        if G > max_nodes:
+            raise ValueError(f"MeshIndex: threshold {self.thr} needs a {G}^3 node grid for a mesh of extent {ext:.3f}")
+        self.G, self.h = G, h
+        ctr = 0.5 * (lo + hi)
+        self.origin = (ctr - 0.5 * (G - 1) * h).tolist()
+        ax = torch.arange(G, device=dev, dtype=torch.float32) * h
+        gx, gy, gz = torch.meshgrid(ax + self.origin[0], ax + self.origin[1], ax + self.origin[2], indexing="ij")
+        nodes = torch.stack([gx, gy, gz], -1).reshape(1, -1, 3)
+        self.node_sdf = mesh_sdf(nodes, self.verts, self.faces).reshape(-1).contiguous()
+        # cell lists (CSR) from the thr-dilated triangle bounding boxes
+        tri = self.verts[self.faces.long()]  # [F,3,3]
+        o = torch.tensor(self.origin, device=dev)
+        c_lo = torch.floor((tri.min(1).values - self.thr - o) / h).long().clamp_(0, G - 2)
+        c_hi = torch.floor((tri.max(1).values + self.thr - o) / h).long().clamp_(0, G - 2)
+        span = (c_hi - c_lo + 1)
+        D = [int(span[:, k].max()) for k in range(3)]
+        F = self.faces.shape[0]
+        fid = torch.arange(F, device=dev)
+        cells, tris = [], []
+        for dx in range(D[0]):
+            for dy in range(D[1]):
+                for dz in range(D[2]):
+                    ok = (dx < span[:, 0]) & (dy < span[:, 1]) & (dz < span[:, 2])
+                    if not bool(ok.any()):
+                        continue
+                    c = ((c_lo[ok, 0] + dx) * (G - 1) + (c_lo[ok, 1] + dy)) * (G - 1) + (c_lo[ok, 2] + dz)
+                    cells.append(c)
+                    tris.append(fid[ok])
+        cells, tris = torch.cat(cells), torch.cat(tris)
+        order = torch.argsort(cells, stable=True)
+        self.cell_tris = tris[order].to(torch.int32).contiguous()
+        counts = torch.bincount(cells, minlength=(G - 1) ** 3)
+        self.cell_start = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.cumsum(counts, 0)]).to(torch.int32).contiguous()
+
+    def off_surface(self, x_cano, num_rays):
+        """x_cano [..., 3] canonical sample points, ray-major (num_rays x S) -> bool [num_rays]."""
+        x = x_cano.detach().reshape(-1, x_cano.shape[-1])
+        if x.dtype != torch.float32 or x.stride(1) != 1:
+            x = x.float().contiguous()
+        S = x.shape[0] // num_rays
+        assert S * num_rays == x.shape[0]
+        out = torch.empty(num_rays, dtype=torch.uint8, device=x.device)
+        call("hold_ray_off_surface", ptr(x), x.stride(0), num_rays, S, ptr(self.node_sdf), self.G, self.origin[0],
+             self.origin[1], self.origin[2], self.h, self.thr, ptr(self.cell_start), ptr(self.cell_tris), ptr(self.verts),
+             ptr(self.faces), ptr(out))
+        return out.bool()
+
+
 def compute_mano_cano_sdf(mesh_v_cano, mesh_f_cano, x_cano):
     """volsdf_utils.py:172-186 (the kaolin face-vertex tensor argument is not needed)."""
     return mesh_sdf(x_cano, mesh_v_cano, mesh_f_cano)

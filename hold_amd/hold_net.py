@@ -21,8 +21,7 @@ from . import gemm as G
 from . import kernels as K
 from .field import FEAT, FieldSpec, NodeField, Pool, pack_weights, pad4
 from .fitting import seal_mano_mesh
-from .geometry import (PointInSpace, check_off_in_surface_points_cano_mesh, compute_mano_cano_sdf,
-                       sample_on_barycentric_mesh, subdivide_loop)
+from .geometry import MeshIndex, PointInSpace, compute_mano_cano_sdf, sample_on_barycentric_mesh, subdivide_loop
 from .mano import MANOServer, ObjectServer
 from .sampler import ErrorBoundSampler, UniformSampler
 from .xdict import output_class
@@ -562,6 +561,7 @@ class MANONode(Node):
         so = sample_dict_h.get("output", sample_dict_h)
         v, f = seal_mano_mesh(so["v_posed"].detach(), self.mesh_f_cano, self.is_rhand)
         self.mesh_v_cano_div, self.mesh_f_cano_div = subdivide_loop(v[0].float(), f)
+        self._mesh_index = MeshIndex(self.mesh_v_cano_div, self.mesh_f_cano_div, 0.01)  # threshold of hold_utils.py:222
 
     def meshing_cano(self, pose=None):
         """mano_node.py:137-151: canonical mesh of the learnt SDF inside MANO's canonical bounding box."""
@@ -578,14 +578,12 @@ class MANONode(Node):
         nid = self.node_id
         mesh_v = self.mesh_v_cano_div[None]
         mesh_f = self.mesh_f_cano_div
-        cano_pts = fac["canonical_pts"].reshape(B, -1, 3)
         if frame_terms:
             samples = sample_on_barycentric_mesh(mesh_v.expand(B, -1, -1), mesh_f, num_samples=256)
             samples = self.pt_sampler.get_points(samples, local_sigma=0.008, global_ratio=0.20)
             out[f"{nid}.pts2mano_sdf_cano"] = compute_mano_cano_sdf(mesh_v[0], mesh_f, samples)
             out[f"{nid}.pred_sdf"] = self.query_oc(samples)
-        off, _ = check_off_in_surface_points_cano_mesh(mesh_v[0], mesh_f, cano_pts, B * n_pix, threshold=0.01)
-        out[f"{nid}.index_off_surface"] = off
+        out[f"{nid}.index_off_surface"] = self._mesh_index.off_surface(fac["canonical_pts"], B * n_pix)
         if frame_terms:
             verts_c = self.cano_verts[None].expand(B, -1, -1)
             esamp, g = self._gradient_samples(self.pt_sampler, verts_c, 256, 0.008, 0.20)
@@ -640,16 +638,14 @@ class ObjectNode(Node):
         self.mesh_vo_cano = torch.as_tensor(np.asarray(mesh_canonical.vertices)[None], device=dev).float()
         self.mesh_fo_cano = torch.as_tensor(np.asarray(mesh_canonical.faces).astype(np.int64), device=dev)
         self.mesh_o = self.mesh_vo_cano[:, self.mesh_fo_cano]
+        self._mesh_index = MeshIndex(self.mesh_vo_cano[0], self.mesh_fo_cano, 0.05)  # threshold of hold_utils.py:166
 
     def loss_targets(self, out, fac, B, n_pix, frame_terms=True):
         """prepare_loss_targets_object (code/src/hold/hold_utils.py:149-183)."""
         if self.mesh_o is None:
             return
         nid = self.node_id
-        cano_pts = fac["canonical_pts"].reshape(B, -1, 3)
-        off, _ = check_off_in_surface_points_cano_mesh(self.mesh_vo_cano[0], self.mesh_fo_cano, cano_pts, B * n_pix,
-                                                       threshold=0.05)
-        out[f"{nid}.index_off_surface"] = off
+        out[f"{nid}.index_off_surface"] = self._mesh_index.off_surface(fac["canonical_pts"], B * n_pix)
         if frame_terms:
             xyz = self.mesh_vo_cano[0].abs().max(dim=0).values * 1.1
             sampler = PointInSpace(global_sigma_xyz=xyz)

@@ -45,42 +45,47 @@ class FlatAdam:
         self.params = low + main
         assert self.params, "no trainable parameters"
         dev = self.params[0].device
-        self.n_low = sum(p.numel() for p in low)
-        self.n = self.n_low + sum(p.numel() for p in main)
-        self.flat = torch.empty(self.n, device=dev)
+        # every parameter starts on a 256-byte boundary of the bucket (the kernels read weights with 16-byte vector
+        # loads and LDS DMA); the padding elements stay zero in all four buffers, so they are inert under Adam
+        self.offsets, off = [], 0
+        for p in self.params:
+            if p is (main[0] if main else None):
+                self.n_low = off
+            self.offsets.append(off)
+            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        if not main:
+            self.n_low = off
+        self.n = off
+        self.n_params = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(self.n, device=dev)
         self.grad = torch.zeros(self.n, device=dev)
         self.m = torch.zeros(self.n, device=dev)
         self.v = torch.zeros(self.n, device=dev)
         self.sumsq = torch.zeros(1, device=dev)
-        off = 0
         with torch.no_grad():
-            for p in self.params:
+            for p, off in zip(self.params, self.offsets):
                 k = p.numel()
                 assert p.dtype == torch.float32 and p.device == dev
                 self.flat[off:off + k].copy_(p.reshape(-1))
                 p.data = self.flat[off:off + k].view(p.shape)
                 p.grad = self.grad[off:off + k].view(p.shape)
-                off += k
         self.step_count = 0
+
+    ALIGN = 64  # floats
 
     def zero_grad(self):
         self.grad.zero_()
-        off = 0
-        for p in self.params:  # autograd accumulates in place into these views; re-attach any that were replaced
-            k = p.numel()
+        for p, off in zip(self.params, self.offsets):  # autograd accumulates in place into these views; re-attach any that were replaced
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
-                p.grad = self.grad[off:off + k].view(p.shape)
-            off += k
+                p.grad = self.grad[off:off + p.numel()].view(p.shape)
 
     def gather_stray_grads(self):
         """fold gradients that autograd attached as fresh tensors (instead of accumulating into the bucket view) back in."""
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             k = p.numel()
             if p.grad is not None and p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
                 self.grad[off:off + k].add_(p.grad.reshape(-1))
                 p.grad = self.grad[off:off + k].view(p.shape)
-            off += k
 
     def allreduce(self, average=True):
         """the ONE collective of a data-parallel step: RCCL all-reduce of the gradient bucket over xGMI."""

@@ -68,6 +68,12 @@ def make_mano_model(is_rhand: bool = True, seed: int = 7) -> dict:
     st = np.sqrt(1.0 - t * t)
     dirs = np.zeros((NUM_VERTS + 1, 3))
     dirs[free_ids] = np.stack([t, st * np.cos(phi), st * np.sin(phi)], 1)
+    # break the lattice's symmetry: on a regular lattice many query points are (nearly) equidistant from their 15th and
+    # 16th nearest vertex, and which one a K = 15 neighbour search keeps then depends on the last bit of the distance
+    # arithmetic (fma contraction, summation order) -- real MANO vertices are irregular
+    jit = np.random.RandomState(4242 + (0 if is_rhand else 1)).normal(scale=0.02, size=(m, 3))
+    dirs[free_ids] += jit
+    dirs[free_ids] /= np.linalg.norm(dirs[free_ids], axis=1, keepdims=True)
     az = 2.0 * np.pi * np.arange(16) / 16.0
     dirs[ring_ids] = np.stack([-np.cos(alpha) * np.ones(16), np.sin(alpha) * np.cos(az), np.sin(alpha) * np.sin(az)], 1)
     dirs[NUM_VERTS] = [-1.0, 0.0, 0.0]
@@ -168,7 +174,9 @@ def make_scene(n_frames: int = 4, two_hands: bool = False, seed: int = 1,
     obj_rot = rs.normal(scale=0.3, size=(n_frames, 3))
     obj_t = rs.normal(scale=0.03, size=(n_frames, 3)) + np.array([-0.05, 0.02, -0.02])
     pts = rs.normal(size=(2000, 3))
-    pts = pts / np.linalg.norm(pts, axis=1, keepdims=True) * 0.3
+    # radius 0.45: the object's canonical point cloud bounds the meshing box (object_node.py:49-50: bbox x 2), which must
+    # contain the level set of the synthetic SDF net (the reference's geometric init, a sphere of radius ~0.6)
+    pts = pts / np.linalg.norm(pts, axis=1, keepdims=True) * 0.45
     sc["entities"]["object"] = {
         "object_poses": np.concatenate([obj_rot, obj_t], 1).astype(np.float32),
         "pts.cano": pts.astype(np.float32),

@@ -323,6 +323,17 @@ int hold_chain(const hold_chain_desc* d, hold_stream_t stream);
 int hold_mesh_sdf(const float* pts, int32_t B, int64_t P, const float* verts, int32_t verts_shared, int32_t V,
                   const int32_t* faces, int32_t F, float cull_dist, const float* aabb, float* sd, hold_stream_t stream);
 
+/* per-ray off-surface test of check_off_in_surface_points_cano_mesh (code/src/engine/volsdf_utils.py:189-217):
+ * off[r] = 1 iff min over the ray's S samples of the signed distance to the (single, canonical) closed mesh > thr, using
+ * the node-SDF grid + per-cell triangle lists built by hold_amd/geometry.py:MeshIndex (node_sdf [G^3] x-major at
+ * origin + h * index with h * sqrt(3) < thr; cell_start [(G-1)^3 + 1], cell_tris [*] = triangles whose thr-dilated
+ * bounding box touches the cell).  xc [n_rays * S][ldx] ray-major canonical points.  Same decisions as evaluating
+ * hold_mesh_sdf on every sample (the band the grid cannot decide is resolved by exact point-triangle distances). */
+int hold_ray_off_surface(const float* xc, int32_t ldx, int64_t n_rays, int32_t S, const float* node_sdf, int32_t G,
+                         float ox, float oy, float oz, float h, float thr, const int32_t* cell_start,
+                         const int32_t* cell_tris, const float* verts, const int32_t* faces, uint8_t* off,
+                         hold_stream_t stream);
+
 /* ---- step tail: per-pixel loss terms and the optimiser step on one flat fp32 bucket ----
  * hold_pixel_loss_fwd/bwd: the ray-wise terms of Loss.forward (code/src/hold/loss.py:17-93) in one launch each --
  *   sums[0] = sum |rgb - gt| over rows without NaN, sums[2] = number of such rows (loss_terms.get_rgb_loss :14-20)
@@ -383,6 +394,12 @@ int hold_silhouette_fwd(const float* v3d_c, int32_t B, int32_t V, const int32_t*
 int hold_silhouette_bwd(const float* v3d_c, int32_t B, int32_t V, const int32_t* faces, int32_t F, float fx, float fy,
                         float cx, float cy, int32_t H, int32_t W, float sigma, float blur_radius, float* workspace,
                         const float* d_mask, float* d_ndc_scratch, float* d_v3d_c, hold_stream_t stream);
+/* the most faces any pixel sees (inside or within the blur radius): pytorch3d keeps only the faces_per_pixel = 100
+ * nearest of them (fitting/utils.py:107); while this stays <= 100 the cap is inactive and hold_silhouette_fwd, which
+ * multiplies over all faces, equals the capped rasteriser.  max_count: one int32 on the device. */
+int hold_silhouette_max_faces(const float* v3d_c, int32_t B, int32_t V, const int32_t* faces, int32_t F, float fx, float fy,
+                              float cx, float cy, int32_t H, int32_t W, float blur_radius, float* workspace,
+                              int32_t* max_count, hold_stream_t stream);
 int hold_knn1_fwd(const float* q, int32_t B, int32_t Nq, const float* t, int32_t Nt, float* d2, int32_t* idx,
                   hold_stream_t stream);
 int hold_knn1_bwd(const float* q, int32_t B, int32_t Nq, const float* t, int32_t Nt, const int32_t* idx, const float* g,

@@ -60,8 +60,10 @@ def _seg_d2(p, a, b):
     return ((p - q) ** 2).sum(-1)
 
 
-def soft_silhouette(v3d_c, faces, fx, fy, cx, cy, H, W, sigma=SIGMA, blur=BLUR, chunk=2048):
-    """v3d_c [B,V,3] camera-space vertices, faces [F,3] -> alpha [B,H,W]."""
+def soft_silhouette(v3d_c, faces, fx, fy, cx, cy, H, W, sigma=SIGMA, blur=BLUR, chunk=2048, return_count=False):
+    """v3d_c [B,V,3] camera-space vertices, faces [F,3] -> alpha [B,H,W] (and, with return_count, the number of faces
+    contributing to each pixel [B,H,W]: the rasteriser of the reference keeps at most faces_per_pixel = 100 of them,
+    fitting/utils.py:107 -- the product over all faces below equals it while that count stays <= 100)."""
     B = v3d_c.shape[0]
     ndc = to_ndc(v3d_c, fx, fy, cx, cy, H, W)  # [B,V,2]
     z = v3d_c[..., 2]
@@ -70,8 +72,9 @@ def soft_silhouette(v3d_c, faces, fx, fy, cx, cy, H, W, sigma=SIGMA, blur=BLUR, 
     px = -((jj + 0.5) - W / 2.0) / s
     py = -((ii + 0.5) - H / 2.0) / s
     pix = torch.stack([px, py], -1).reshape(-1, 2)  # [HW,2]
-    out = []
+    out, counts = [], []
     for b in range(B):
+        cnt = torch.zeros(pix.shape[0], dtype=torch.long)
         tri = ndc[b][faces]  # [F,3,2]
         zf = z[b][faces]  # [F,3]
         logacc = torch.zeros(pix.shape[0], dtype=v3d_c.dtype)
@@ -89,7 +92,11 @@ def soft_silhouette(v3d_c, faces, fx, fy, cx, cy, H, W, sigma=SIGMA, blur=BLUR, 
             # 1 - prob = sigmoid(d / sigma)
             l1mp = torch.nn.functional.logsigmoid(d / sigma)
             logacc[c0:c0 + chunk] = torch.where(valid, l1mp, torch.zeros_like(l1mp)).sum(-1)
+            cnt[c0:c0 + chunk] = valid.sum(-1)
         out.append((1.0 - torch.exp(logacc)).reshape(H, W))
+        counts.append(cnt.reshape(H, W))
+    if return_count:
+        return torch.stack(out), torch.stack(counts)
     return torch.stack(out)
 
 

@@ -92,3 +92,26 @@ def mesh_stats(verts, faces):
     rkey = e[:, 1].astype(np.int64) * (v.shape[0] + 1) + e[:, 0]
     closed = len(np.unique(key)) == len(key) and set(key.tolist()) == set(rkey.tolist())
     return dict(area=float(area), volume=float(vol), closed_oriented=bool(closed))
+
+
+def triangles_match(tris_a, tris_b, atol=2e-5):
+    """bijection between two triangle soups up to cyclic rotation (orientation preserved) and `atol` per coordinate --
+    what a comparison of an fp32 extraction with the fp64 oracle needs (rounded keys flip at decimal boundaries)."""
+    from scipy.spatial import cKDTree
+    a = np.asarray([t for t in tris_a if np.linalg.norm(np.cross(t[1] - t[0], t[2] - t[0])) > 1e-9], dtype=np.float64)
+    b = np.asarray([t for t in tris_b if np.linalg.norm(np.cross(t[1] - t[0], t[2] - t[0])) > 1e-9], dtype=np.float64)
+    if len(a) != len(b):
+        return False, f"{len(a)} vs {len(b)} non-degenerate triangles"
+    tree = cKDTree(b.mean(1))
+    used = np.zeros(len(b), dtype=bool)
+    for i, t in enumerate(a):
+        hit = False
+        for j in tree.query_ball_point(t.mean(0), r=4 * atol):
+            if used[j]:
+                continue
+            if any(np.abs(t - np.roll(b[j], r, axis=0)).max() < atol for r in range(3)):
+                used[j] = hit = True
+                break
+        if not hit:
+            return False, f"triangle {i} of the first set has no partner: {t.tolist()}"
+    return True, ""

@@ -23,7 +23,7 @@ def main(path):
     torch.manual_seed(11)
     sc, sd_np, sd, osc = setup()
     net = hip_net(sc, sd_np, train=True)
-    r = 0.45
+    r = 0.12
     net.nodes["object"].update_cano(M.generate_mesh(lambda x: {"sdf": x.norm(dim=1) - r},
                                                     np.array([[-r, -r, -r], [r, r, r]]), res_init=24, res_up=0))
     b, _ = oracle_input(sc, sd, [0, 2], 8, 8)

@@ -134,3 +134,103 @@ def test_fitting_losses_match_reference_golden():
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fitting_losses.npz"))
     assert run_two_hand(g, ft.loss_fn_ih, "cuda") < 2e-5
     assert run_single_hand(g, ft.loss_fn_h, "cuda") < 2e-5
+
+
+def test_reference_model_and_optimize_batch_surface():
+    """Model(servers, scene_scale, obj_scale, param_dict, device, target_masks, w2c, K, fnames, faces) and
+    optimize_batch(batch_idx, args, pbar, out, device, ...) with the reference's signatures (fitting/model.py:30-200,
+    fitting/fitting.py:22-76): same first-iteration loss as the explicit single-hand FittingModel, requires_grad
+    pattern of optimize_batch, and a loss that goes down."""
+    import types
+    from hold_amd import fitting as ft
+    sc, sd_np, sd, osc = setup(n_frames=6)
+    net = hip_net(sc, sd_np)
+    dev = torch.device("cuda")
+    hand, obj = net.nodes["right"], net.nodes["object"]
+    n = sc["n_frames"]
+    nlat, nlon = 12, 16
+    th = torch.linspace(0.15, np.pi - 0.15, nlat)
+    ph = torch.linspace(0, 2 * np.pi, nlon + 1)[:-1]
+    sv = torch.stack([torch.sin(th)[:, None] * torch.cos(ph)[None], torch.sin(th)[:, None] * torch.sin(ph)[None],
+                      torch.cos(th)[:, None].expand(nlat, nlon)], -1).reshape(-1, 3) * 0.07
+    obj.server.object_model.v3d_cano = sv.to(dev)
+    fl = []
+    for a in range(nlat - 1):
+        for b in range(nlon):
+            i0, i1 = a * nlon + b, a * nlon + (b + 1) % nlon
+            fl += [[i0, i1, i0 + nlon], [i1, i1 + nlon, i0 + nlon]]
+    faces = {"right": torch.as_tensor(hand.server.faces.astype(np.int64), device=dev), "object": torch.tensor(fl, device=dev)}
+    pre = "model.nodes."
+    pd = {pre + "right.params.global_orient.weight": hand.params.global_orient.weight.detach().clone(),
+          pre + "right.params.pose.weight": hand.params.pose.weight.detach().clone(),
+          pre + "right.params.betas.weight": hand.params.betas.weight.detach().clone(),
+          pre + "right.params.transl.weight": hand.params.transl.weight.detach().clone(),
+          pre + "object.params.global_orient.weight": obj.params.global_orient.weight.detach().clone(),
+          pre + "object.params.transl.weight": obj.params.transl.weight.detach().clone()}
+    w2c = torch.eye(4, device=dev)[None]
+    w2c[:, 2, 3] = 0.9
+    K = torch.tensor([[[260.0, 0, 40.0], [0, 260.0, 40.0], [0, 0, 1]]], device=dev)
+    out = dict(servers={"right": hand.server, "object": obj.server}, faces=faces, K=K, w2c=w2c,
+               scene_scale=torch.tensor([1.0]), param_dict=pd, fnames=[f"{i:04d}.png" for i in range(n)])
+    # target masks = hard silhouettes of the un-perturbed parameters, coded with SEGM ids (object 50, right 150)
+    batch_idx = [0, 2, 3]
+    contact_idx = np.arange(700, 778)
+    args = types.SimpleNamespace(iters=0, vis_every=50, itw=True, write_gif=False)
+    m0 = ft.optimize_batch(batch_idx, args, None, out, dev, obj_scale=[1.0], masks=np.zeros((n, 80, 80), np.float32),
+                           contact_idx=contact_idx)
+    with torch.no_grad():
+        o = m0.fwd_params()
+    assert m0.imsize == (300, 300) and o["right.mask"].shape == (3, 300, 300) and hasattr(o, "search")
+    masks = np.zeros((n, 300, 300), np.float32)
+    hard_o, hard_h = (o["object.mask"] > 0.5).cpu().numpy(), (o["right.mask"] > 0.5).cpu().numpy()
+    for j, i in enumerate(batch_idx):
+        masks[i][hard_o[j]] = 50
+        masks[i][hard_h[j]] = 150
+    # requires_grad pattern of fitting.py:57-67
+    rg = {k: p.requires_grad for k, p in m0.param_dict.items()}
+    assert rg == {"right__global_orient": False, "right__pose": False, "right__betas": True, "right__transl": True,
+                  "object__global_orient": True, "object__transl": True, "right__scene_scale": False,
+                  "object__scene_scale": False} and m0.obj_scale.requires_grad
+    # perturbed start, 40 iterations through the reference-signature entry point
+    pd2 = dict(pd)
+    pd2[pre + "right.params.transl.weight"] = pd[pre + "right.params.transl.weight"] + torch.tensor([0.01, -0.008, 0.0], device=dev)
+    pd2[pre + "object.params.transl.weight"] = pd[pre + "object.params.transl.weight"] + torch.tensor([-0.02, 0.015, 0.0], device=dev)
+    args.iters = 40
+    m = ft.optimize_batch(batch_idx, args, None, dict(out, param_dict=pd2), dev, obj_scale=[1.0], masks=masks,
+                          contact_idx=contact_idx, freeze_shape=True)
+    assert len(m.history) == 40 and all(np.isfinite(m.history)) and m.history[-1] < 0.7 * m.history[0]
+    # same first-iteration loss as the explicit single-hand model on the same inputs
+    idx = torch.tensor(batch_idx, device=dev)
+    params = {"scene_scale": torch.tensor([1.0], device=dev), "right.global_orient": pd2[pre + "right.params.global_orient.weight"][idx],
+              "right.pose": pd2[pre + "right.params.pose.weight"][idx], "right.betas": pd2[pre + "right.params.betas.weight"],
+              "right.transl": pd2[pre + "right.params.transl.weight"][idx],
+              "object.global_orient": pd2[pre + "object.params.global_orient.weight"][idx],
+              "object.transl": pd2[pre + "object.params.transl.weight"][idx]}
+    tm = torch.as_tensor(masks[batch_idx]).to(dev)
+    ref = ft.FittingModel(hand.server, obj.server, faces["right"], faces["object"], params, w2c.repeat(3, 1, 1), m.K[0, :3, :3],
+                          (300, 300), ft.construct_targets(tm), torch.as_tensor(contact_idx, device=dev))
+    obj.server.object_model.obj_scale = torch.tensor([1.0], device=dev)
+    with torch.no_grad():
+        l_ref = float(ref()["loss"])
+    assert m.history[0] == pytest.approx(l_ref, rel=1e-5)
+
+
+def test_faces_per_pixel_cap_is_detected():
+    """pytorch3d keeps the 100 nearest faces per pixel (fitting/utils.py:107); the HIP rasteriser multiplies over all
+    of them, which is the same thing while no pixel sees more than 100: the count kernel equals the oracle's count on
+    the sealed hand, and a stack of 150 coincident triangles trips the host-side check."""
+    from hold_amd import fitting as ft
+    net, verts, faces = _scene_verts(2)
+    vs, fs = ft.seal_mano_mesh(verts, faces, True)
+    H = W = 64
+    fx = fy = 180.0
+    cx = cy = 32.0
+    k = ft.max_faces_per_pixel(vs, fs, fx, fy, cx, cy, H, W)
+    _, cnt = fo.soft_silhouette(vs.cpu().double(), fs.cpu(), fx, fy, cx, cy, H, W, return_count=True)
+    assert k == int(cnt.max()) and 2 <= k <= ft.FACES_PER_PIXEL
+    assert ft.check_faces_per_pixel(vs, fs, fx, fy, cx, cy, H, W) == k
+    tri = torch.tensor([[[-0.1, -0.1, 0.5], [0.1, -0.1, 0.5], [0.0, 0.1, 0.5]]], device="cuda")
+    stack = torch.arange(150, device="cuda").repeat_interleave(3).view(150, 3) * 0 + torch.tensor([0, 1, 2], device="cuda")
+    assert ft.max_faces_per_pixel(tri, stack, fx, fy, cx, cy, H, W) == 150
+    with pytest.raises(NotImplementedError):
+        ft.check_faces_per_pixel(tri, stack, fx, fy, cx, cy, H, W)

@@ -78,12 +78,12 @@ def _holdnet_worker(rank, world, port, out):
     for node in net.nodes.values():
         node.params.defrost()
     opt = FlatAdam(net, lr=5e-4, clip_norm=0.5)
-    assert opt.n > 2_190_000 and opt.n_low == 4 * (3 + 3 + 45) + 10 + 4 * 6  # dense nets + tables
+    assert opt.n_params > 2_190_000  # dense nets + density betas + latents + pose tables
+    low = sum(p.numel() for node in net.nodes.values() for p in node.params.parameters())
+    assert low == 4 * (3 + 3 + 45) + 10 + 4 * 6 and opt.n_low >= low
     base = opt.grad.data_ptr()
-    off = 0
-    for p in opt.params:  # .grad and .data are views of the two buckets, in bucket order
-        assert p.grad.data_ptr() == base + 4 * off and p.data.data_ptr() == opt.flat.data_ptr() + 4 * off
-        off += p.numel()
+    for p, off in zip(opt.params, opt.offsets):  # .grad and .data are 256-byte aligned views of the two buckets
+        assert off % 64 == 0 and p.grad.data_ptr() == base + 4 * off and p.data.data_ptr() == opt.flat.data_ptr() + 4 * off
     opt.zero_grad()
     g = torch.Generator().manual_seed(7)
     vals = [torch.randn(p.shape, generator=g) for p in opt.params]  # same draws on every rank
