@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libholdhip.so")
+# HOLD_LIB: load another build of the same ABI (the developer build libholdhip_dev.so, `HOLD_DEV=1 python -m hold_amd.build`)
+LIB_PATH = os.environ.get("HOLD_LIB") or os.path.join(_HERE, "libholdhip.so")
 
 EPI_NONE, EPI_SOFTPLUS, EPI_RELU, EPI_SIGMOID, EPI_MUL_DSP, EPI_MUL_DRELU, EPI_DBWD, EPI_MUL_DSIG = range(8)
 
@@ -72,6 +73,7 @@ class CompositeDesc(C.Structure):
         ("out_zmerge", C.c_void_p),
         ("d_node", C.c_void_p * 3), ("d_comp", C.c_void_p), ("d_sem", C.c_void_p),
         ("d_sdf", C.c_void_p * 3), ("d_color", C.c_void_p * 3), ("d_normal", C.c_void_p * 3), ("d_beta", C.c_void_p),
+        ("out_w_node", C.c_void_p * 3),
     ]
 
 
@@ -138,6 +140,7 @@ SIGNATURES = {
     "hold_mt_vertices": [_P, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P],
     "hold_mt_triangles": [_P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P],
     "hold_fused_sdf_x6": [_P, _I, _L, _P, _P, _P, _F, _P, _P, _I, _P],
+    "hold_fused_sdf_x6q": [_P, _I, _L, _P, _P, _P, _F, _P, _P, _I, _P],
     "hold_mano_lbs_fwd": [C.POINTER(ManoModel), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "hold_mano_lbs_bwd": [C.POINTER(ManoModel), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
 }
@@ -150,6 +153,7 @@ def _declare(L):
     L.hold_reduce_workspace_floats.restype = C.c_int64
     L.hold_fused_sdf_pack_floats.restype = C.c_int64
     L.hold_fused_sdf_x6_pack_bytes.restype = C.c_int64
+    L.hold_fused_sdf_x6q_pack_floats.restype = C.c_int64
     L.hold_chain_pack_floats.argtypes = [C.c_int32, C.c_int32]
     L.hold_chain_pack_floats.restype = C.c_int64
     L.hold_silhouette_workspace_floats.argtypes = [C.c_int32, C.c_int32]

@@ -7,7 +7,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(_HERE, "csrc")
-OUT = os.path.join(_HERE, "libholdhip.so")
+OUT = os.path.join(_HERE, "libholdhip_dev.so" if os.environ.get("HOLD_DEV") == "1" else "libholdhip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # developer build (HOLD_DEV=1 in the environment of the BUILD): adds the diagnostics kernels (csrc/dev/diag.hip) and
 # compiles the timing-ablation / variant-selection environment switches into the launchers (-DHOLD_DEV).  The product
@@ -35,9 +35,10 @@ def build(force=False, verbose=False):
         return OUT
     objs = []
     procs = []
-    os.makedirs(os.path.join(_HERE, "build"), exist_ok=True)
+    bdir = os.path.join(_HERE, "build", "dev" if DEV else "")
+    os.makedirs(bdir, exist_ok=True)
     for s in sources():
-        o = os.path.join(_HERE, "build", os.path.basename(s) + ".o")
+        o = os.path.join(bdir, os.path.basename(s) + ".o")
         objs.append(o)
         procs.append((s, subprocess.Popen(["hipcc", *FLAGS, *(["-DHOLD_DEV"] if DEV else []), "-c", s, "-o", o],
                                           stdout=subprocess.PIPE,

@@ -32,6 +32,7 @@ struct CompArgs {
   float* out_sem;             // [N][4]
   float* out_w;               // [N][M] composite weights (nullable)
   float* out_zmerge;          // [N][M] merged z (nullable)
+  float* out_w_node[MAXN];    // [N][S] per-node weights (nullable)
   // backward
   const float* d_node[MAXN];  // [N][OUTW]
   const float* d_comp;        // [N][OUTW]
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(64 * WAVES) void composite_fwd_kernel(CompArgs a) {
       acc[3] += w;
       acc[4] += w * nm[0]; acc[5] += w * nm[1]; acc[6] += w * nm[2];
       acc[7] += w * zz[s];
+      if (a.out_w_node[n]) a.out_w_node[n][ray * S + s] = w;
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc[q] = wave_sum(acc[q]);
@@ -398,6 +400,7 @@ extern "C" int hold_composite_fwd(const hold_composite_desc* d, hold_stream_t st
     a.z[n] = d->z[n]; a.sdf[n] = d->sdf[n]; a.color[n] = d->color[n]; a.normal[n] = d->normal[n];
     a.ldc[n] = d->ldc[n]; a.ldn[n] = d->ldn[n]; a.class_id[n] = d->class_id[n]; a.beta[n] = d->beta[n];
     a.out_node[n] = d->out_node[n];
+    a.out_w_node[n] = d->out_w_node[n];
   }
   a.out_comp = d->out_comp; a.out_sem = d->out_sem; a.out_w = d->out_w; a.out_zmerge = d->out_zmerge;
   if (a.N == 0) return HOLD_OK;

@@ -577,7 +577,9 @@ __global__ __launch_bounds__(512, 2) void fused_sdf_x6_kernel(FusedArgs a, const
 constexpr int XP_PTS = 64, XP_ROW = 264, XP_PLANE = XP_PTS * XP_ROW;   // bf16 elements
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-template <int STEPS>
+// NOSTREAM (developer build only): every step re-reads the first weight fragment -- a timing ablation that removes the
+// L2 -> CU weight stream while keeping every instruction (results are wrong)
+template <int STEPS, bool NOSTREAM = false>
 __device__ __forceinline__ void xp_layer(const bf16x8* __restrict__ wq, const bf16x8* __restrict__ nxt,
                                          const __bf16* __restrict__ prow, f32x16 (&acc)[2], bf16x8 (&bn)[3]) {
   // prow: plane 0, row of point li, column 8 hh; tile m adds 32 rows, limb t adds a plane, step s adds 16 columns
@@ -611,7 +613,7 @@ __device__ __forceinline__ void xp_layer(const bf16x8* __restrict__ wq, const bf
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       b[t] = bn[t];
-      bn[t] = (s + 1 < STEPS) ? wq[(s + 1) * X6_STEP_UNITS + t * 512] : nxt[t * 512];
+      bn[t] = NOSTREAM ? wq[t * 512] : ((s + 1 < STEPS) ? wq[(s + 1) * X6_STEP_UNITS + t * 512] : nxt[t * 512]);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -630,6 +632,7 @@ __device__ __forceinline__ void xp_layer(const bf16x8* __restrict__ wq, const bf
     for (int r = 0; r < 16; ++r) acc[m][r] = part[m][0][r] + part[m][1][r];
 }
 
+template <bool NOSTREAM>
 __global__ __launch_bounds__(512, 2) void fused_sdf_x6p_kernel(FusedArgs a, const bf16x8* __restrict__ wx6) {
   constexpr int NTHR = 512;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -680,11 +683,11 @@ __global__ __launch_bounds__(512, 2) void fused_sdf_x6p_kernel(FusedArgs a, cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
       if (layer == 0) {
-        xp_layer<X6_L0_STEPS>(wl, wl + X6_L0_STEPS * X6_STEP_UNITS, prow, acc, bn);
-        wl += X6_L0_STEPS * X6_STEP_UNITS;
+        xp_layer<X6_L0_STEPS, NOSTREAM>(wl, wl + X6_L0_STEPS * X6_STEP_UNITS, prow, acc, bn);
+        if (!NOSTREAM) wl += X6_L0_STEPS * X6_STEP_UNITS;
       } else {
-        xp_layer<X6_LK_STEPS>(wl, layer < 7 ? wl + X6_LK_STEPS * X6_STEP_UNITS : w0, prow, acc, bn);
-        wl += X6_LK_STEPS * X6_STEP_UNITS;
+        xp_layer<X6_LK_STEPS, NOSTREAM>(wl, layer < 7 ? wl + X6_LK_STEPS * X6_STEP_UNITS : w0, prow, acc, bn);
+        if (!NOSTREAM) wl += X6_LK_STEPS * X6_STEP_UNITS;
       }
       __syncthreads();  // every wave has finished READING this layer's input
 #pragma unroll
@@ -849,13 +852,28 @@ extern "C" int hold_fused_sdf_x6(const float* xc, int32_t ldx, int64_t P, const 
     const size_t shp = (size_t)3 * XP_PLANE * 2 + (size_t)(XP_PTS * ESTR + 8 * XP_PTS) * sizeof(float);
     static bool attr_p = false;
     if (!attr_p) {
-      if (hipFuncSetAttribute((const void*)fused_sdf_x6p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+      if (hipFuncSetAttribute((const void*)fused_sdf_x6p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)shp) != hipSuccess)
         return HOLD_E_LAUNCH;
+#ifdef HOLD_DEV
+      if (hipFuncSetAttribute((const void*)fused_sdf_x6p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)shp) != hipSuccess)
+        return HOLD_E_LAUNCH;
+#endif
       attr_p = true;
     }
     const long blocks = (P + XP_PTS - 1) / XP_PTS;
-    hipLaunchKernelGGL(fused_sdf_x6p_kernel, dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(512), shp,
+#ifdef HOLD_DEV
+    if (getenv("HOLD_X6P_NOSTREAM")) {
+      static bool warned = false;
+      if (!warned) fprintf(stderr, "libholdhip: HOLD_X6P_NOSTREAM -- timing ablation, hold_fused_sdf_x6 results are WRONG\n");
+      warned = true;
+      hipLaunchKernelGGL(fused_sdf_x6p_kernel<true>, dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(512), shp,
+                         (hipStream_t)st, a, reinterpret_cast<const bf16x8*>(wpack_x6));
+      return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+    }
+#endif
+    hipLaunchKernelGGL(fused_sdf_x6p_kernel<false>, dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(512), shp,
                        (hipStream_t)st, a, reinterpret_cast<const bf16x8*>(wpack_x6));
     return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
   }

@@ -92,6 +92,17 @@ def pack_x6(W8):
     return torch.cat(parts).contiguous()
 
 
+def pack_x6q(W8):
+    """fp32 fragment pack of hold_fused_sdf_x6q (include/hold_hip.h): [K_l/16 steps][8 n-tiles][2 h][32 i][8 e] per layer."""
+    parts = []
+    for l, wl in enumerate(W8):
+        K = 48 if l == 0 else 256
+        m = torch.zeros(256, K, device=wl.device)
+        m[:wl.shape[0], :wl.shape[1]] = wl
+        parts.append(m.reshape(8, 32, K // 16, 2, 8).permute(2, 0, 3, 1, 4).reshape(-1))
+    return torch.cat(parts).contiguous()
+
+
 def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
     """iw/ib: 9 effective ImplicitNet weights/biases ([out,in] as nn.Linear); rw/rb: 5 RenderingNet ones (or None).
     Returns the re-laid-out (and, for sweeps that contract over the output index, transposed) copies the
@@ -133,7 +144,10 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
         bias8[l, :pk["b"][l].shape[0]] = pk["b"][l]
     pk["fused"] = (torch.cat(parts).contiguous(), bias8.contiguous())
     if config.x6():
-        pk["fused_x6"] = pack_x6(W[:8])
+        if config.X6_TRUNK == "q":
+            pk["fused_x6q"] = pack_x6q(W[:8])
+        else:
+            pk["fused_x6"] = pack_x6(W[:8])
     # descending sweeps (hold_chain DSP): layer j contracts over the outputs of trunk layer l = 7 - j, M_j = W_l^T
     parts = []
     for l in range(7, 0, -1):
@@ -227,6 +241,9 @@ class NodeField:
         """no-grad SDF query of the sampler (sdf_func_with_deformer, volsdf_utils.py:150-169).  out_sdf [P,1]."""
         self.gen += 1  # overwrites the pooled canonical points a pending backward would read
         xc, _ = self._deform(x, P, ppf, dfm, want_w=False)
+        if FUSED_SDF and "fused_x6q" in pk:
+            K.fused_sdf_x6q(xc, P, pk["fused_x6q"], pk["fused"][1], pk["w8_sdf"], float(pk["b8_sdf"]), barf_w, out_sdf)
+            return
         if FUSED_SDF and "fused_x6" in pk:
             K.fused_sdf_x6(xc, P, pk["fused_x6"], pk["fused"][1], pk["w8_sdf"], float(pk["b8_sdf"]), barf_w, out_sdf)
             return

@@ -385,17 +385,20 @@ class _CompositeFn(torch.autograd.Function):
         out_sem = torch.empty(n_rays, 4, device=dev)
         M = n * S - 2 * n + 1
         out_w = torch.empty(n_rays, M, device=dev) if want_w else None
-        K.composite_fwd(d, out_node, out_comp, out_sem, out_w)
+        out_wn = [torch.empty(n_rays, S, device=dev) for _ in range(n)] if want_w else None
+        K.composite_fwd(d, out_node, out_comp, out_sem, out_w, out_w_node=out_wn)
         ctx.save_for_backward(*z, *sdf, *color, *normal)
         ctx.meta = (S, n_rays, class_ids, betas, n)
         if out_w is None:
             out_w = torch.empty(0, device=dev)
-        ctx.mark_non_differentiable(out_w)
-        return (out_comp, out_sem, out_w, *out_node)
+            out_wn = [torch.empty(0, device=dev) for _ in range(n)]
+        ctx.mark_non_differentiable(out_w, *out_wn)
+        return (out_comp, out_sem, out_w, *out_node, *out_wn)
 
     @staticmethod
-    def backward(ctx, d_comp, d_sem, d_w, *d_node):
+    def backward(ctx, d_comp, d_sem, d_w, *d_rest):
         S, n_rays, class_ids, betas, n = ctx.meta
+        d_node = d_rest[:n]  # the per-node weights (d_rest[n:]) are non-differentiable outputs
         sv = ctx.saved_tensors
         z, sdf, color, normal = (sv[i * n:(i + 1) * n] for i in range(4))
         dev = sdf[0].device
@@ -898,6 +901,7 @@ class HOLDNet(nn.Module):
             out["fg_weights"] = w
             for k, i in enumerate(ids):
                 out.update(unpack(res[3 + k], f"{i}.", self.nodes[i].class_id))
+                out[f"{i}.fg_weights"] = res[3 + len(ids) + k]
                 out[f"{i}.z_vals"] = fac[i]["z_vals"]
             t_bg = None if rng is None else rng.get("bg_t")
             z_bg = self.background.inverse_sphere_sampler.inverse_sample(ray_dirs, cam_loc, training,

@@ -118,6 +118,17 @@ def fused_sdf_x6(xc, P, wpack_x6, bias8, w8, b8, barf_w, out_sdf):
     _g._prof_end(e0, 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256), "fused_sdf_kernel")
 
 
+def fused_sdf_x6q(xc, P, wpack_q, bias8, w8, b8, barf_w, out_sdf):
+    """second-generation split-precision trunk (96-point blocks, fp32 weight stream split in registers); wpack_q from
+    field.pack_x6q."""
+    assert wpack_q.numel() == _lib.lib().hold_fused_sdf_x6q_pack_floats() and wpack_q.dtype == torch.float32
+    from . import gemm as _g
+    e0 = _g._prof_begin()
+    call("hold_fused_sdf_x6q", ptr(xc), _ld(xc), P, ptr(wpack_q), ptr(bias8), ptr(w8), float(b8), ptr(barf_w),
+         ptr(out_sdf), _ld(out_sdf))
+    _g._prof_end(e0, 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256), "fused_sdf_kernel")
+
+
 CHAIN_SOFTPLUS, CHAIN_DSP, CHAIN_DBWD = 0, 1, 2
 
 
@@ -203,9 +214,11 @@ def make_composite_desc(S, n_rays, z, sdf, color, normal, class_ids, betas):
     return d
 
 
-def composite_fwd(d, out_node, out_comp, out_sem, out_w=None, out_zmerge=None):
+def composite_fwd(d, out_node, out_comp, out_sem, out_w=None, out_zmerge=None, out_w_node=None):
     for i, o in enumerate(out_node):
         d.out_node[i] = o.data_ptr()
+        if out_w_node is not None:
+            d.out_w_node[i] = out_w_node[i].data_ptr()
     d.out_comp, d.out_sem = out_comp.data_ptr(), out_sem.data_ptr()
     d.out_w = out_w.data_ptr() if out_w is not None else None
     d.out_zmerge = out_zmerge.data_ptr() if out_zmerge is not None else None

@@ -55,6 +55,10 @@ class ErrorBoundSampler:
         assert inverse_sphere_bg, "HOLD always samples up to the bounding-sphere exit (node.py:33-35)"
         self.inverse_sphere_sampler = UniformSampler(1.0, 0.0, 32, False, far=1.0)
         self.rng_device = rng_device  # "cpu" reproduces the reference's generator stream; "cuda" avoids the H2D copy
+        # data-parallel option (SURVEY 8(e) caveat): the convergence test `beta.max() > beta0` (ray_sampler.py:244) is a max
+        # over ALL rays of the call; with rays sharded over ranks, one 1-float MAX all-reduce per round makes every shard
+        # run the number of rounds the un-sharded call would (set to a process group, or True for the default group)
+        self.sync_group = None
         self.pool = None
         self.last_iters = 0
 
@@ -140,6 +144,12 @@ class ErrorBoundSampler:
             if int(fl[0, 0]) != 0:
                 raise RuntimeError("BOUNDING SPHERE PROBLEM!")  # ray_sampler.py:16-18
             max_beta = float(fl[0, 1:2].view(torch.float32))
+            if self.sync_group is not None:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized():
+                    mb = torch.tensor([max_beta], device=dev)
+                    dist.all_reduce(mb, op=dist.ReduceOp.MAX, group=None if self.sync_group is True else self.sync_group)
+                    max_beta = float(mb)
             not_converge = max_beta > beta0
             if not_converge and iters < self.max_total_iters:
                 K.sampler_sample(z, sdf, S, N, beta, True, self.add_tiny, u_more, n0, samp, slot)

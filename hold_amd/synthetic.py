@@ -174,8 +174,8 @@ def make_scene(n_frames: int = 4, two_hands: bool = False, seed: int = 1,
     obj_rot = rs.normal(scale=0.3, size=(n_frames, 3))
     obj_t = rs.normal(scale=0.03, size=(n_frames, 3)) + np.array([-0.05, 0.02, -0.02])
     pts = rs.normal(size=(2000, 3))
-    # radius 0.45: the object's canonical point cloud bounds the meshing box (object_node.py:49-50: bbox x 2), which must
-    # contain the level set of the synthetic SDF net (the reference's geometric init, a sphere of radius ~0.6)
+    # radius 0.45: the object's canonical point cloud bounds the canonical-meshing box (object_node.py:49-50: bbox x 2,
+    # then x 1.1), which has to contain the zero level set of the geometric-init SDF (radius up to ~0.8)
     pts = pts / np.linalg.norm(pts, axis=1, keepdims=True) * 0.45
     sc["entities"]["object"] = {
         "object_poses": np.concatenate([obj_rot, obj_t], 1).astype(np.float32),
@@ -260,8 +260,8 @@ def _linear_default(rs, out, inn):
 
 def make_state_dict(scene: dict, seed: int = 1, perturb: float = 0.02, barf_iter: int = 3999) -> dict:
     """name -> np.ndarray for every learnable tensor of HOLDNet (reference naming, SURVEY.md 5
-    'Checkpoint' row).  fg SDF nets follow the geometric init of shape_net.py:51-72 (sphere of
-    radius 0.6) plus an N(0, perturb^2) perturbation so features / colours are non-degenerate."""
+    'Checkpoint' row).  fg SDF nets follow the geometric init of shape_net.py:51-72 (a sphere-like SDF whose zero level
+    set has radius ~0.25, exactly what the reference constructor produces) plus a perturbation of the feature rows."""
     rs = np.random.RandomState(seed + 31337)
     sd = {}
     F = scene["n_frames"]
@@ -287,7 +287,14 @@ def make_state_dict(scene: dict, seed: int = 1, perturb: float = 0.02, barf_iter
                 w = rs.normal(0.0, std, size=(out, inn))
                 b = np.zeros((out,))
             g = np.linalg.norm(w, axis=1, keepdims=True)
-            v = w + rs.normal(0.0, perturb, size=w.shape) * (0.25 if l == 8 else 1.0)
+            # the trunk and the sdf row stay at the geometric init, so the zero level set (a sphere of radius ~0.25 in
+            # canonical space, as the reference's own constructor gives) survives; only the 256 FEATURE rows of the
+            # last layer are perturbed so that features / colours are not all alike.  (Perturbing every weight_v, as
+            # SURVEY 8(d) first planned, lifts the whole SDF above zero: softplus units are rectifiers, zero-mean
+            # weight noise has a positive mean effect -- the scene became fog without a surface.)
+            v = w.copy()
+            if l == 8:
+                v[1:] += rs.normal(0.0, 2.5 * perturb, size=v[1:].shape)
             sd[pfx + f"lin{l}.weight_g"] = g.astype(np.float32)
             sd[pfx + f"lin{l}.weight_v"] = v.astype(np.float32)
             sd[pfx + f"lin{l}.bias"] = (b + rs.normal(0, 0.005, size=b.shape) * (l < 8)).astype(np.float32)

