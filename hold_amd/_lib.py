@@ -130,6 +130,7 @@ SIGNATURES = {
     "hold_knn1_bwd": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P],
     "hold_fused_sdf": [_P, _I, _L, _P, _P, _P, _F, _P, _P, _I, _P],
     "hold_chain": [C.POINTER(ChainDesc), _P],
+    "hold_chain_x6": [C.POINTER(ChainDesc), _P],
     "hold_mesh_sdf": [_P, _I, _L, _P, _I, _I, _P, _I, _F, _P, _P, _P],
     "hold_ray_off_surface": [_P, _I, _L, _I, _P, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P],
     "hold_pixel_loss_fwd": [_P, _P, _P, _P, _L, _I, C.POINTER(LossNodes), _P, _P, _P],
@@ -140,7 +141,6 @@ SIGNATURES = {
     "hold_mt_vertices": [_P, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P],
     "hold_mt_triangles": [_P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P],
     "hold_fused_sdf_x6": [_P, _I, _L, _P, _P, _P, _F, _P, _P, _I, _P],
-    "hold_fused_sdf_x6q": [_P, _I, _L, _P, _P, _P, _F, _P, _P, _I, _P],
     "hold_mano_lbs_fwd": [C.POINTER(ManoModel), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "hold_mano_lbs_bwd": [C.POINTER(ManoModel), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
 }
@@ -153,9 +153,10 @@ def _declare(L):
     L.hold_reduce_workspace_floats.restype = C.c_int64
     L.hold_fused_sdf_pack_floats.restype = C.c_int64
     L.hold_fused_sdf_x6_pack_bytes.restype = C.c_int64
-    L.hold_fused_sdf_x6q_pack_floats.restype = C.c_int64
     L.hold_chain_pack_floats.argtypes = [C.c_int32, C.c_int32]
     L.hold_chain_pack_floats.restype = C.c_int64
+    L.hold_chain_x6_pack_bytes.argtypes = [C.c_int32, C.c_int32]
+    L.hold_chain_x6_pack_bytes.restype = C.c_int64
     L.hold_silhouette_workspace_floats.argtypes = [C.c_int32, C.c_int32]
     L.hold_silhouette_workspace_floats.restype = C.c_int64
     for name, args in SIGNATURES.items():

@@ -15,9 +15,6 @@ from __future__ import annotations
 
 import os
 
-# which split-precision sampler trunk f32x6 uses: "p" = hold_fused_sdf_x6 (64-point blocks, pre-split weight limbs),
-# "q" = hold_fused_sdf_x6q (96-point blocks, fp32 weights split in registers)
-X6_TRUNK = os.environ.get("HOLD_X6_TRUNK", "p")
 _MODES = ("f32", "f32x6")
 _precision = os.environ.get("HOLD_PRECISION", "f32x6")
 if _precision not in _MODES:

@@ -24,6 +24,8 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -272,6 +274,210 @@ __global__ __launch_bounds__(512, 2) void chain_kernel(hold_chain_desc d) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Split-precision variant (hold_chain_x6): the same sweeps, LDS layout, epilogues and pipeline, with the layer products
+// on v_mfma_f32_32x32x16_bf16 -- every fp32 operand is the exact sum of three bf16 limbs, six of the nine limb products
+// are issued, fp32 accumulation (the arithmetic of hold_fused_sdf_x6 / hold_wgrad_x6, include/hold_hip.h).  Activations
+// stay fp32 in LDS and are split into limbs by truncation as they are fetched (8 consecutive k per lane: the top 16 bits,
+// the top 16 bits of the exact remainder, the rest); the weights come pre-split from the limb pack
+// [K/16 steps][3 limbs][8 n-tiles][64 lanes] x bf16x8 (hold_amd/field.py:pack_x6_mats), one step ahead.
+constexpr int X6_UNITS = 3 * 512;  // 16-byte units per 16-wide k step
+
+struct Limbs3 { bf16x8 l[3]; };
+
+__device__ __forceinline__ Limbs3 split8_trunc(const f32x4& x0, const f32x4& x1) {
+  uint32_t h1[8], h2[8], h3[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = e < 4 ? x0[e] : x1[e - 4];
+    h1[e] = __builtin_bit_cast(uint32_t, x) & 0xffff0000u;
+    const float r1 = x - __builtin_bit_cast(float, h1[e]);
+    h2[e] = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
+    h3[e] = __builtin_bit_cast(uint32_t, r1 - __builtin_bit_cast(float, h2[e]));
+  }
+  Limbs3 o;
+  u32x4 p1, p2, p3;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {  // dword j = bf16 elements 2j (low half) and 2j + 1 (high half)
+    p1[j] = __builtin_amdgcn_perm(h1[2 * j + 1], h1[2 * j], 0x07060302u);
+    p2[j] = __builtin_amdgcn_perm(h2[2 * j + 1], h2[2 * j], 0x07060302u);
+    p3[j] = __builtin_amdgcn_perm(h3[2 * j + 1], h3[2 * j], 0x07060302u);
+  }
+  o.l[0] = __builtin_bit_cast(bf16x8, p1);
+  o.l[1] = __builtin_bit_cast(bf16x8, p2);
+  o.l[2] = __builtin_bit_cast(bf16x8, p3);
+  return o;
+}
+
+// One pipeline step (one layer x one 64-point half), K = 16 * STEPS.  Each 16-wide k step is two phases of 6 MFMAs
+// (limb products 00 01 10 | 11 02 20 for the two 32-point tiles); the phases play the role of the fp32 kernel's 8-wide
+// chunks for the placement of the previous half's epilogue units (exec_at / load_at with CHUNKS = 2 * STEPS).
+template <int MODE, bool A2, int STEPS, bool EPI>
+__device__ __forceinline__ void chain_step_x6(const bf16x8* __restrict__ wq, const bf16x8* __restrict__ nxt,
+                                              const float* __restrict__ arow, f32x16 (&accC)[2], bf16x8 (&bn)[3],
+                                              const f32x16 (&accP)[2], const EpiCtx& x) {
+  constexpr int CH = 2 * STEPS;
+  f32x4 s1[2], s2[2], xn[4];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accC[m][r] = 0.f;
+  auto rd = [&](int s) {  // this lane's rows (points li of the two tiles), k = 16 s + 8 hh .. + 8
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      xn[2 * m] = *reinterpret_cast<const f32x4*>(arow + m * 32 * ASTR + s * 16);
+      xn[2 * m + 1] = *reinterpret_cast<const f32x4*>(arow + m * 32 * ASTR + s * 16 + 4);
+    }
+  };
+  rd(0);
+  Limbs3 la[2];
+  la[0] = split8_trunc(xn[0], xn[1]);
+  la[1] = split8_trunc(xn[2], xn[3]);
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    // ---- phase A: issue (next step's fp32 fragments, next step's weight limbs, side inputs due), then 00 01 10 ----
+    bf16x8 b[3];
+    if (s + 1 < STEPS) rd(s + 1);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      b[t] = bn[t];
+      if (s + 1 < STEPS) {
+        bn[t] = wq[(s + 1) * X6_UNITS + t * 512];
+      } else if (nxt) {
+        bn[t] = nxt[t * 512];
+      }
+    }
+    if (EPI) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (load_at<CH>(u) == 2 * s) epi_load<MODE, A2>(x, u, s1[u & 1], s2[u & 1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) accC[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la[m].l[0], b[0], accC[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) accC[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la[m].l[1], b[0], accC[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) accC[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la[m].l[0], b[1], accC[m], 0, 0, 0);
+    if (EPI) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (exec_at<CH>(u) == 2 * s) epi_exec<MODE, A2>(x, u, accP, s1[u & 1], s2[u & 1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase B: side inputs due, then 11 02 20 with the next step's split interleaved ----
+    if (EPI) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (load_at<CH>(u) == 2 * s + 1) epi_load<MODE, A2>(x, u, s1[u & 1], s2[u & 1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) accC[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la[m].l[1], b[1], accC[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) accC[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la[m].l[2], b[0], accC[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) accC[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la[m].l[0], b[2], accC[m], 0, 0, 0);
+    if (s + 1 < STEPS) {
+      la[0] = split8_trunc(xn[0], xn[1]);
+      la[1] = split8_trunc(xn[2], xn[3]);
+    }
+    if (EPI) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (exec_at<CH>(u) == 2 * s + 1) epi_exec<MODE, A2>(x, u, accP, s1[u & 1], s2[u & 1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int MODE, bool A2, int FIRST_STEPS>
+__global__ __launch_bounds__(512, 2) void chain_x6_kernel(hold_chain_desc d) {
+  constexpr int PTS = 128, NTHR = 512;
+  constexpr int KIN = (FIRST_STEPS == 3) ? 40 : 256, KPAD = 16 * FIRST_STEPS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* act = smem;                   // [128][260]
+  float* side = smem + PTS * ASTR;     // [128][40]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, li = lane & 31;
+  const bf16x8* w0 = reinterpret_cast<const bf16x8*>(d.wpack) + wave * 64 + lane;
+  constexpr long LAYER0 = (long)FIRST_STEPS * X6_UNITS, LAYERK = 16L * X6_UNITS;  // 16-byte units
+  const int NL = d.n_layers;
+  const long ld = d.ld;
+  const uint32_t nbytes = (uint32_t)(d.P * ld * 4);
+
+  for (long blk = blockIdx.x; blk * PTS < d.P; blk += gridDim.x) {
+    const long p0 = blk * PTS;
+    bf16x8 bn[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) bn[t] = w0[t * 512];
+    // ---- initial activations (zero-padded to a multiple of 16 columns) and the 40-wide side matrix -> LDS ----
+    for (int e = tid; e < PTS * (KPAD / 4); e += NTHR) {
+      const int p = e / (KPAD / 4), j4 = (e % (KPAD / 4)) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (j4 < KIN && p0 + p < d.P) v = *reinterpret_cast<const f32x4*>(d.in + (p0 + p) * d.ld_in + j4);
+      *reinterpret_cast<f32x4*>(act + p * ASTR + j4) = v;
+    }
+    if (d.side) {
+      for (int e = tid; e < PTS * (ESTR / 4); e += NTHR) {
+        const int p = e / (ESTR / 4), j4 = (e % (ESTR / 4)) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (p0 + p < d.P) v = *reinterpret_cast<const f32x4*>(d.side + (p0 + p) * d.ld_side + j4);
+        *reinterpret_cast<f32x4*>(side + p * ESTR + j4) = v;
+      }
+    }
+    __syncthreads();
+
+    float* row[2] = {act + li * ASTR, act + (64 + li) * ASTR};
+    const int col = wave * 32 + li;
+    auto ctx = [&](int layer, int half) {
+      EpiCtx x;
+      const long prow = p0 + half * 64 + 4 * hh;
+      x.bias = (MODE == HOLD_CHAIN_SOFTPLUS) ? d.bias[layer][col] : 0.f;
+      x.a1 = make_rsrc(d.aux1[layer], nbytes);
+      x.a2 = make_rsrc(d.aux2[layer], nbytes);
+      x.o1 = make_rsrc(d.out[layer], nbytes);
+      x.o2 = make_rsrc(d.out2[layer], nbytes);
+      x.goff = (uint32_t)((prow * ld + col) * 4);
+      x.rowb = (uint32_t)(ld * 4);
+      x.lcol = act + (half * 64 + 4 * hh) * ASTR + col;
+      x.scol = side + (half * 64 + 4 * hh) * ESTR + (col - SKIP_OUT);
+      x.skip = layer == d.skip_layer;
+      x.special = x.skip && col >= SKIP_OUT;
+      x.wr_lds = layer + 1 < NL;
+      return x;
+    };
+    f32x16 accA[2], accB[2];
+    const EpiCtx none = ctx(0, 0);
+    chain_step_x6<MODE, A2, FIRST_STEPS, false>(w0, w0, row[0] + hh * 8, accA, bn, accB, none);
+    __syncthreads();
+    chain_step_x6<MODE, A2, FIRST_STEPS, true>(w0, NL > 1 ? w0 + LAYER0 : nullptr, row[1] + hh * 8, accB, bn, accA,
+                                               ctx(0, 0));
+    __syncthreads();
+    const bf16x8* wl = w0 + LAYER0;
+    for (int layer = 1; layer < NL; ++layer) {
+      chain_step_x6<MODE, A2, 16, true>(wl, wl, row[0] + hh * 8, accA, bn, accB, ctx(layer - 1, 1));
+      __syncthreads();
+      chain_step_x6<MODE, A2, 16, true>(wl, layer + 1 < NL ? wl + LAYERK : nullptr, row[1] + hh * 8, accB, bn, accA,
+                                        ctx(layer, 0));
+      __syncthreads();
+      wl += LAYERK;
+    }
+    {  // epilogue of (last layer, H1): nothing left to hide it under; requests run two units ahead
+      const EpiCtx x = ctx(NL - 1, 1);
+      f32x4 s1[2], s2[2];
+      epi_load<MODE, A2>(x, 0, s1[0], s2[0]);
+      epi_load<MODE, A2>(x, 1, s1[1], s2[1]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        epi_exec<MODE, A2>(x, u, accB, s1[u & 1], s2[u & 1]);
+        if (u + 2 < 8) epi_load<MODE, A2>(x, u + 2, s1[u & 1], s2[u & 1]);
+      }
+    }
+  }
+}
+
 bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 template <int MODE, bool A2, int FIRST>
@@ -289,6 +495,22 @@ int launch(const hold_chain_desc& d, int n_cu, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
 }
 
+template <int MODE, bool A2, int FIRST_STEPS>
+int launch_x6(const hold_chain_desc& d, int n_cu, hipStream_t s) {
+  const size_t sh = (size_t)(128 * ASTR + 128 * ESTR) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)chain_x6_kernel<MODE, A2, FIRST_STEPS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sh) != hipSuccess)
+      return HOLD_E_LAUNCH;
+    attr_set = true;
+  }
+  const long blocks = (d.P + 127) / 128;
+  hipLaunchKernelGGL((chain_x6_kernel<MODE, A2, FIRST_STEPS>), dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(512), sh,
+                     s, d);
+  return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+}
+
 }  // namespace
 
 extern "C" int64_t hold_chain_pack_floats(int32_t first_chunks, int32_t n_layers) {
@@ -296,7 +518,17 @@ extern "C" int64_t hold_chain_pack_floats(int32_t first_chunks, int32_t n_layers
   return ((int64_t)first_chunks + 32 * (int64_t)(n_layers - 1)) * 2048;
 }
 
-extern "C" int hold_chain(const hold_chain_desc* dp, hold_stream_t st) {
+extern "C" int64_t hold_chain_x6_pack_bytes(int32_t first_chunks, int32_t n_layers) {
+  if ((first_chunks != 5 && first_chunks != 32) || n_layers < 1 || n_layers > 8) return -1;
+  return ((int64_t)(first_chunks == 5 ? 3 : 16) + 16 * (int64_t)(n_layers - 1)) * X6_UNITS * 16;
+}
+
+static int chain_impl(const hold_chain_desc* dp, hold_stream_t st, bool x6);
+
+extern "C" int hold_chain(const hold_chain_desc* dp, hold_stream_t st) { return chain_impl(dp, st, false); }
+extern "C" int hold_chain_x6(const hold_chain_desc* dp, hold_stream_t st) { return chain_impl(dp, st, true); }
+
+static int chain_impl(const hold_chain_desc* dp, hold_stream_t st, bool x6) {
   if (!dp) return HOLD_E_ARG;
   const hold_chain_desc& d = *dp;
   if (d.P < 0 || d.n_layers < 1 || d.n_layers > 8 || !d.in || !d.wpack) return HOLD_E_ARG;
@@ -325,6 +557,13 @@ extern "C" int hold_chain(const hold_chain_desc* dp, hold_stream_t st) {
     n_cu = prop.multiProcessorCount;
   }
   hipStream_t s = (hipStream_t)st;
+  if (x6) {
+    if (d.mode == HOLD_CHAIN_SOFTPLUS && d.first_chunks == 5) return launch_x6<HOLD_CHAIN_SOFTPLUS, false, 3>(d, n_cu, s);
+    if (d.mode == HOLD_CHAIN_DSP && d.first_chunks == 32)
+      return has2 ? launch_x6<HOLD_CHAIN_DSP, true, 16>(d, n_cu, s) : launch_x6<HOLD_CHAIN_DSP, false, 16>(d, n_cu, s);
+    if (d.mode == HOLD_CHAIN_DBWD && d.first_chunks == 5) return launch_x6<HOLD_CHAIN_DBWD, true, 3>(d, n_cu, s);
+    return HOLD_E_ARG;
+  }
   if (d.mode == HOLD_CHAIN_SOFTPLUS && d.first_chunks == 5) return launch<HOLD_CHAIN_SOFTPLUS, false, 5>(d, n_cu, s);
   if (d.mode == HOLD_CHAIN_DSP && d.first_chunks == 32)
     return has2 ? launch<HOLD_CHAIN_DSP, true, 32>(d, n_cu, s) : launch<HOLD_CHAIN_DSP, false, 32>(d, n_cu, s);

@@ -79,27 +79,17 @@ def split_limbs(w, n=3):
     return out
 
 
-def pack_x6(W8):
-    """limb pack of hold_fused_sdf_x6 (include/hold_hip.h) from the 8 trunk matrices W8[l] ([<=256, K_l], layer 0 with
-    K = 40): bf16 tensor, [K_l/16 steps][3 limbs][8 n-tiles][2 h][32 i][8 e] per layer."""
+def pack_x6(W8, first_k=48):
+    """limb pack of hold_fused_sdf_x6 / hold_chain_x6 (include/hold_hip.h) from up to 8 matrices W8[l] ([<=256, K_l]; the
+    first one zero-padded to first_k = 48 columns for the 40-wide embedding input, or 256): bf16 tensor,
+    [K_l/16 steps][3 limbs][8 n-tiles][2 h][32 i][8 e] per layer."""
     parts = []
     for l, wl in enumerate(W8):
-        K = 48 if l == 0 else 256
+        K = first_k if l == 0 else 256
         m = torch.zeros(256, K, device=wl.device)
         m[:wl.shape[0], :wl.shape[1]] = wl
         limbs = torch.stack(split_limbs(m))  # [3, 256, K] bf16
         parts.append(limbs.reshape(3, 8, 32, K // 16, 2, 8).permute(3, 0, 1, 4, 2, 5).reshape(-1))
-    return torch.cat(parts).contiguous()
-
-
-def pack_x6q(W8):
-    """fp32 fragment pack of hold_fused_sdf_x6q (include/hold_hip.h): [K_l/16 steps][8 n-tiles][2 h][32 i][8 e] per layer."""
-    parts = []
-    for l, wl in enumerate(W8):
-        K = 48 if l == 0 else 256
-        m = torch.zeros(256, K, device=wl.device)
-        m[:wl.shape[0], :wl.shape[1]] = wl
-        parts.append(m.reshape(8, 32, K // 16, 2, 8).permute(2, 0, 3, 1, 4).reshape(-1))
     return torch.cat(parts).contiguous()
 
 
@@ -123,6 +113,8 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
     pk["iw0_cols"] = iw[0].shape[1]
     pk["w8_sdf"] = iw[8][0].contiguous()
     pk["b8_sdf"] = ib[8][0]
+    pk["b8_sdf_f"] = float(ib[8][0])  # the one host read of a pack (kernel scalar argument)
+    pk["W8_feat"], pk["b8_feat"] = w8[:256], pk["b"][8][:256]  # lin8 without its sdf row (a 257th column costs a whole tile)
     # transposes [K_l][pad4(N_l)] for the sweeps that contract over the output index
     WT = []
     for l in range(9):
@@ -144,10 +136,7 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
         bias8[l, :pk["b"][l].shape[0]] = pk["b"][l]
     pk["fused"] = (torch.cat(parts).contiguous(), bias8.contiguous())
     if config.x6():
-        if config.X6_TRUNK == "q":
-            pk["fused_x6q"] = pack_x6q(W[:8])
-        else:
-            pk["fused_x6"] = pack_x6(W[:8])
+        pk["fused_x6"] = pack_x6(W[:8])
     # descending sweeps (hold_chain DSP): layer j contracts over the outputs of trunk layer l = 7 - j, M_j = W_l^T
     parts = []
     for l in range(7, 0, -1):
@@ -155,6 +144,14 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
         m[:W[l].shape[1], :W[l].shape[0]] = W[l].t()
         parts.append(m.reshape(8, 32, 32, 2, 4).permute(2, 0, 3, 1, 4).reshape(-1))
     pk["chain_bwd"] = torch.cat(parts).contiguous()
+    if config.x6():  # limb packs of the same matrices for hold_chain_x6 (the forward-type sweeps share the sampler trunk's)
+        pk["chain_fwd_x6"] = pk["fused_x6"]
+        mats = []
+        for l in range(7, 0, -1):
+            m = torch.zeros(256, 256, device=dev)
+            m[:W[l].shape[1], :W[l].shape[0]] = W[l].t()
+            mats.append(m)
+        pk["chain_bwd_x6"] = pack_x6(mats, first_k=256)
     if rw is None:  # implicit net only (ImplicitNet.forward / gradient)
         return pk
     r0 = torch.zeros(256, spec.Kr, device=dev)
@@ -204,7 +201,7 @@ class NodeField:
         if USE_CHAIN and keep_all:
             wpack, bias8 = pk["fused"]
             K.chain(K.CHAIN_SOFTPLUS, P, in0, wpack, 8, 5, skip_layer=3, side=in0, bias=[bias8[l] for l in range(8)],
-                    out=h)
+                    out=h, wpack_x6=pk.get("chain_fwd_x6"))
             return in0, h
         G.gemm_nt(in0, W[0], h[0], bias=b[0], epi=G.EPI_SOFTPLUS, K=sp.K0)
         G.gemm_nt(h[0], W[1], h[1], bias=b[1], epi=G.EPI_SOFTPLUS)
@@ -224,7 +221,7 @@ class NodeField:
         if USE_CHAIN:
             outs = [t[l - 1] if (keep_all or l - 1 in (0, 3)) else None for l in range(7, 0, -1)]
             K.chain(K.CHAIN_DSP, P, t[7], pk["chain_bwd"], 7, 32, skip_layer=3, aux1=[h[l - 1] for l in range(7, 0, -1)],
-                    out=outs)
+                    out=outs, wpack_x6=pk.get("chain_bwd_x6"))
             K.copy_cols(t[3][:, sp.skip_out:], ge, sp.E, P)  # raw columns 217.. = d sdf / d (skip embedding)
         else:
             for l in range(7, 0, -1):
@@ -241,19 +238,16 @@ class NodeField:
         """no-grad SDF query of the sampler (sdf_func_with_deformer, volsdf_utils.py:150-169).  out_sdf [P,1]."""
         self.gen += 1  # overwrites the pooled canonical points a pending backward would read
         xc, _ = self._deform(x, P, ppf, dfm, want_w=False)
-        if FUSED_SDF and "fused_x6q" in pk:
-            K.fused_sdf_x6q(xc, P, pk["fused_x6q"], pk["fused"][1], pk["w8_sdf"], float(pk["b8_sdf"]), barf_w, out_sdf)
-            return
         if FUSED_SDF and "fused_x6" in pk:
-            K.fused_sdf_x6(xc, P, pk["fused_x6"], pk["fused"][1], pk["w8_sdf"], float(pk["b8_sdf"]), barf_w, out_sdf)
+            K.fused_sdf_x6(xc, P, pk["fused_x6"], pk["fused"][1], pk["w8_sdf"], pk["b8_sdf_f"], barf_w, out_sdf)
             return
         if FUSED_SDF:
             wpack, bias8 = pk["fused"]
-            K.fused_sdf(xc, P, wpack, bias8, pk["w8_sdf"], float(pk["b8_sdf"]), barf_w, out_sdf)
+            K.fused_sdf(xc, P, wpack, bias8, pk["w8_sdf"], pk["b8_sdf_f"], barf_w, out_sdf)
             return
         # layer-by-layer variant (ping-pong activations: two [P,256] buffers + the skip buffer stay live)
         _, h = self._trunk(pk, xc, P, barf_w, keep_all=False)
-        K.rowdot(h[7], pk["w8_sdf"], 256, float(pk["b8_sdf"]), P, out_sdf)
+        K.rowdot(h[7], pk["w8_sdf"], 256, pk["b8_sdf_f"], P, out_sdf)
 
     # ------------------------------------------------------------------ full forward
     def forward(self, pk, x, P, ppf, dfm, barf_w, pose_embed, time_code, training):
@@ -264,8 +258,9 @@ class NodeField:
         in0, h = self._trunk(pk, xc, P, barf_w, keep_all=True)
         rin = pool.get("rin", P, sp.Kr)
         sdf = pool.get("sdf", P, 1)
-        G.gemm_nt(h[7], pk["W"][8], rin[:, RIN_FEAT:RIN_FEAT + FEAT], bias=pk["b"][8], N=257, n_split=256,
-                  out_raw=sdf)
+        # lin8 = 256 feature rows as a full-tile GEMM + the sdf row as a row dot (N = 257 would add a 256-wide tile for it)
+        G.gemm_nt(h[7], pk["W8_feat"], rin[:, RIN_FEAT:RIN_FEAT + FEAT], bias=pk["b8_feat"], N=256)
+        K.rowdot(h[7], pk["w8_sdf"], 256, pk["b8_sdf_f"], P, sdf)
         # ---- reverse sweep: t_l = d sdf / d a_l, ge = d sdf / d embed, g = d sdf / d xc ----
         WT = pk["WT"]
         # t[3] always has its own buffer: its columns 217..219 are K-padding of the next GEMM and must stay zero
@@ -308,7 +303,7 @@ class NodeField:
         if USE_CHAIN:
             vb = [pool.get(f"vbc{l}", P, 256) for l in range(8)]
             K.chain(K.CHAIN_DBWD, P, gebar, pk["fused"][0], 8, 5, skip_layer=3, side=gebar, aux1=h, aux2=t, out=vb,
-                    out2=a2)
+                    out2=a2, wpack_x6=pk.get("chain_fwd_x6"))
             G.wgrad(t[0], gebar, dW[0], None, K=sp.K0, accumulate=True)
             for l in range(1, 8):
                 if l == 3:
@@ -344,7 +339,7 @@ class NodeField:
             r = [pool.get(f"rbc{l}", P, 256) for l in range(7)] + [r7]
             K.chain(K.CHAIN_DSP, P, r7, pk["chain_bwd"], 7, 32, skip_layer=3, aux1=[h[l - 1] for l in range(7, 0, -1)],
                     aux2=None if a2 is None else [a2[l - 1] for l in range(7, 0, -1)],
-                    out=[r[l - 1] for l in range(7, 0, -1)])
+                    out=[r[l - 1] for l in range(7, 0, -1)], wpack_x6=pk.get("chain_bwd_x6"))
             if ebar is not None:
                 K.copy_cols(r[3][:, sp.skip_out:], ebar, sp.E, P)
             for l in range(7, 0, -1):

@@ -118,17 +118,6 @@ def fused_sdf_x6(xc, P, wpack_x6, bias8, w8, b8, barf_w, out_sdf):
     _g._prof_end(e0, 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256), "fused_sdf_kernel")
 
 
-def fused_sdf_x6q(xc, P, wpack_q, bias8, w8, b8, barf_w, out_sdf):
-    """second-generation split-precision trunk (96-point blocks, fp32 weight stream split in registers); wpack_q from
-    field.pack_x6q."""
-    assert wpack_q.numel() == _lib.lib().hold_fused_sdf_x6q_pack_floats() and wpack_q.dtype == torch.float32
-    from . import gemm as _g
-    e0 = _g._prof_begin()
-    call("hold_fused_sdf_x6q", ptr(xc), _ld(xc), P, ptr(wpack_q), ptr(bias8), ptr(w8), float(b8), ptr(barf_w),
-         ptr(out_sdf), _ld(out_sdf))
-    _g._prof_end(e0, 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256), "fused_sdf_kernel")
-
-
 CHAIN_SOFTPLUS, CHAIN_DSP, CHAIN_DBWD = 0, 1, 2
 
 
@@ -136,12 +125,14 @@ _CHAIN_MAX_ROWS = ((1 << 32) // 1024 - 1) // 128 * 128  # 32-bit byte offsets in
 
 
 def chain(mode, P, x_in, wpack, n_layers, first_chunks, skip_layer=-1, side=None, bias=None, aux1=None, aux2=None,
-          out=None, out2=None):
+          out=None, out2=None, wpack_x6=None):
     """hold_chain: n_layers consecutive 256-wide layers of one sweep with the activation resident in LDS.
     bias: per-layer [256] tensors; aux1 / aux2 / out / out2: per-layer [P,256] tensors (one common row stride) or None
     entries.  Batches beyond the kernel's 32-bit offset range are split by rows."""
     from . import gemm as _g
     assert wpack.numel() == _lib.lib().hold_chain_pack_floats(first_chunks, n_layers)
+    if wpack_x6 is not None:  # split-precision sweep (hold_chain_x6): same descriptor, the weights as bf16 limbs
+        assert wpack_x6.numel() * wpack_x6.element_size() == _lib.lib().hold_chain_x6_pack_bytes(first_chunks, n_layers)
     for r0 in range(0, P, _CHAIN_MAX_ROWS):
         r1 = min(P, r0 + _CHAIN_MAX_ROWS)
         d = _lib.ChainDesc()
@@ -149,7 +140,7 @@ def chain(mode, P, x_in, wpack, n_layers, first_chunks, skip_layer=-1, side=None
         d.in_, d.ld_in = x_in[r0:r1].data_ptr(), _ld(x_in)
         if side is not None:
             d.side, d.ld_side = side[r0:r1].data_ptr(), _ld(side)
-        d.wpack = wpack.data_ptr()
+        d.wpack = (wpack if wpack_x6 is None else wpack_x6).data_ptr()
         ld = None
         for name, lst in (("bias", bias), ("aux1", aux1), ("aux2", aux2), ("out", out), ("out2", out2)):
             if lst is None:
@@ -167,7 +158,7 @@ def chain(mode, P, x_in, wpack, n_layers, first_chunks, skip_layer=-1, side=None
                 ld = _ld(t)
         d.ld = ld if ld is not None else 256
         e0 = _g._prof_begin()
-        call("hold_chain", C.byref(d))
+        call("hold_chain" if wpack_x6 is None else "hold_chain_x6", C.byref(d))
         _g._prof_end(e0, 2.0 * (r1 - r0) * 256 * (8 * first_chunks + 256 * (n_layers - 1)), "chain_kernel")
 
 

@@ -277,14 +277,6 @@ int hold_fused_sdf(const float* xc, int32_t ldx, int64_t P, const float* wpack, 
 int64_t hold_fused_sdf_x6_pack_bytes(void);
 int hold_fused_sdf_x6(const float* xc, int32_t ldx, int64_t P, const void* wpack_x6, const float* bias, const float* w8,
                       float b8, const float* barf_w, float* sdf, int32_t ld_sdf, hold_stream_t stream);
-/* Second-generation split-precision trunk (hold_amd/csrc/fused_sdf_q.hip): same contract and limb arithmetic, re-tiled
- * for the L2 -> CU weight stream that bounds hold_fused_sdf_x6 -- 96-point workgroups and fp32 weights (4 B instead of
- * 6 B of limbs per weight) split into limbs in registers by truncation (exact).
- * wpack_q: hold_fused_sdf_x6q_pack_floats() floats, for layer l (K_l = 48 for l = 0, else 256):
- *   [K_l/16 steps][8 n-tiles][2 halves h][32 rows i][8] = W_l[32*nt + i][16*step + 8*h + e] */
-int64_t hold_fused_sdf_x6q_pack_floats(void);
-int hold_fused_sdf_x6q(const float* xc, int32_t ldx, int64_t P, const float* wpack_q, const float* bias, const float* w8,
-                       float b8, const float* barf_w, float* sdf, int32_t ld_sdf, hold_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * LDS-resident layer chains of the ImplicitNet for the TRAINING path (hold_amd/csrc/chain.hip): up to 8 consecutive
@@ -320,6 +312,14 @@ typedef struct {
 } hold_chain_desc;
 int64_t hold_chain_pack_floats(int32_t first_chunks, int32_t n_layers);
 int hold_chain(const hold_chain_desc* d, hold_stream_t stream);
+/* Split-precision variant: the same descriptor and semantics, the layer products as three-limb bf16 splits on
+ * v_mfma_f32_32x32x16_bf16 (six limb products, fp32 accumulation; activations split from fp32 LDS as they are fetched).
+ * d->wpack then points at hold_chain_x6_pack_bytes(first_chunks, n_layers) bytes of bf16 limbs: layer j, K_j = 48 for
+ * first_chunks = 5 (columns 40..47 zero) else 256,
+ *   [K_j/16 steps][3 limbs t][8 n-tiles][2 halves h][32 rows i][8] = limb_t(M_j)[32*nt + i][16*step + 8*h + e]
+ * (the layout of hold_fused_sdf_x6's wpack_x6, which IS the pack of the forward-type sweeps). */
+int64_t hold_chain_x6_pack_bytes(int32_t first_chunks, int32_t n_layers);
+int hold_chain_x6(const hold_chain_desc* d, hold_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training loss-target geometry without kaolin (hold_amd/csrc/geometry.hip):

@@ -15,6 +15,8 @@ h, t, a2, o1 = bufs(8), bufs(8), bufs(8), bufs(8)
 for x in h: x.uniform_(0, 0.05)
 for x in t + a2: x.normal_()
 wf, wb = pack(W), pack(W[1:])
+from hold_amd import field as F
+xf, xb = (F.pack_x6(W, 48), F.pack_x6(W[1:], 256)) if os.environ.get("HOLD_X6") == "1" else (None, None)  # hold_chain_x6
 def timeit(name, fn, flops):
     for _ in range(2): fn()
     torch.cuda.synchronize()
@@ -25,11 +27,13 @@ def timeit(name, fn, flops):
     ms = e0.elapsed_time(e1) / 3
     print(f"{name:28s} {ms:8.3f} ms  {flops / ms / 1e9:6.1f} TFLOP/s", flush=True)
 f8 = 2.0 * P * 256 * (40 + 7 * 256); f7 = 2.0 * P * 256 * 7 * 256
-timeit("chain SOFTPLUS (8 layers)", lambda: K.chain(K.CHAIN_SOFTPLUS, P, x0, wf, 8, 5, skip_layer=3, side=x0, bias=b, out=o1), f8)
-timeit("chain SOFTPLUS no stores", lambda: K.chain(K.CHAIN_SOFTPLUS, P, x0, wf, 8, 5, skip_layer=3, side=x0, bias=b, out=None), f8)
-timeit("chain DSP (7 layers)", lambda: K.chain(K.CHAIN_DSP, P, t[7], wb, 7, 32, skip_layer=3, aux1=h[:7], out=o1[:7]), f7)
-timeit("chain DSP+a2 (7 layers)", lambda: K.chain(K.CHAIN_DSP, P, t[7], wb, 7, 32, skip_layer=3, aux1=h[:7], aux2=a2[:7], out=o1[:7]), f7)
-timeit("chain DBWD (8 layers)", lambda: K.chain(K.CHAIN_DBWD, P, x0, wf, 8, 5, skip_layer=3, side=x0, aux1=h, aux2=t, out=o1, out2=a2), f8)
+timeit("chain SOFTPLUS (8 layers)", lambda: K.chain(K.CHAIN_SOFTPLUS, P, x0, wf, 8, 5, skip_layer=3, side=x0, bias=b, out=o1, wpack_x6=xf), f8)
+timeit("chain SOFTPLUS no stores", lambda: K.chain(K.CHAIN_SOFTPLUS, P, x0, wf, 8, 5, skip_layer=3, side=x0, bias=b, out=None, wpack_x6=xf), f8)
+timeit("chain DSP (7 layers)", lambda: K.chain(K.CHAIN_DSP, P, t[7], wb, 7, 32, skip_layer=3, aux1=h[:7], out=o1[:7], wpack_x6=xb), f7)
+timeit("chain DSP+a2 (7 layers)", lambda: K.chain(K.CHAIN_DSP, P, t[7], wb, 7, 32, skip_layer=3, aux1=h[:7], aux2=a2[:7], out=o1[:7], wpack_x6=xb), f7)
+timeit("chain DBWD (8 layers)", lambda: K.chain(K.CHAIN_DBWD, P, x0, wf, 8, 5, skip_layer=3, side=x0, aux1=h, aux2=t, out=o1, out2=a2, wpack_x6=xf), f8)
+if os.environ.get("HOLD_X6") == "1":
+    sys.exit(0)
 def layered_sp():
     G.gemm_nt(x0, W[0], o1[0], bias=b[0], epi=G.EPI_SOFTPLUS, K=40)
     for l in range(1, 8): G.gemm_nt(o1[l - 1], W[l], o1[l], bias=b[l], epi=G.EPI_SOFTPLUS)

@@ -16,12 +16,9 @@ out = torch.empty(P, 1, device=dev)
 wpack, bias8 = pk["fused"]
 flops = 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256)
 fn = lambda: K.fused_sdf(xc, P, wpack, bias8, pk["w8_sdf"], float(pk["b8_sdf"]), None, out)
-if os.environ.get("HOLD_X6_TRUNK") == "p":  # split-precision, 64-point blocks, pre-split weight limbs
+if os.environ.get("HOLD_X6") == "1":  # split-precision, 64-point blocks, pre-split weight limbs
     x6 = F.pack_x6(pk["W"][:8])
     fn = lambda: K.fused_sdf_x6(xc, P, x6, bias8, pk["w8_sdf"], float(pk["b8_sdf"]), None, out)
-if os.environ.get("HOLD_X6_TRUNK") == "q":  # split-precision, 96-point blocks, fp32 weights split in registers
-    x6q = F.pack_x6q(pk["W"][:8])
-    fn = lambda: K.fused_sdf_x6q(xc, P, x6q, bias8, pk["w8_sdf"], float(pk["b8_sdf"]), None, out)
 for _ in range(2): fn()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -191,17 +191,13 @@ def test_reference_model_and_optimize_batch_surface():
     assert rg == {"right__global_orient": False, "right__pose": False, "right__betas": True, "right__transl": True,
                   "object__global_orient": True, "object__transl": True, "right__scene_scale": False,
                   "object__scene_scale": False} and m0.obj_scale.requires_grad
-    # perturbed start, 40 iterations through the reference-signature entry point
+    # perturbed start
     pd2 = dict(pd)
     pd2[pre + "right.params.transl.weight"] = pd[pre + "right.params.transl.weight"] + torch.tensor([0.01, -0.008, 0.0], device=dev)
     pd2[pre + "object.params.transl.weight"] = pd[pre + "object.params.transl.weight"] + torch.tensor([-0.02, 0.015, 0.0], device=dev)
-    args.iters = 40
     K300 = K.clone()  # the recorded masks are already 300 x 300: intrinsics of that size (scaling_masks_K then applies k = 1)
     K300[:, :2] *= 300.0 / 80.0
-    m = ft.optimize_batch(batch_idx, args, None, dict(out, param_dict=pd2, K=K300), dev, obj_scale=[1.0], masks=masks,
-                          contact_idx=contact_idx, freeze_shape=True)
-    assert len(m.history) == 40 and all(np.isfinite(m.history)) and m.history[-1] < 0.7 * m.history[0]
-    # same first-iteration loss as the explicit single-hand model on the same inputs
+    # first-iteration loss of the explicit single-hand model on the same inputs (obj_scale is still the untouched 1.0)
     idx = torch.tensor(batch_idx, device=dev)
     params = {"scene_scale": torch.tensor([1.0], device=dev), "right.global_orient": pd2[pre + "right.params.global_orient.weight"][idx],
               "right.pose": pd2[pre + "right.params.pose.weight"][idx], "right.betas": pd2[pre + "right.params.betas.weight"],
@@ -209,11 +205,15 @@ def test_reference_model_and_optimize_batch_surface():
               "object.global_orient": pd2[pre + "object.params.global_orient.weight"][idx],
               "object.transl": pd2[pre + "object.params.transl.weight"][idx]}
     tm = torch.as_tensor(masks[batch_idx]).to(dev)
-    ref = ft.FittingModel(hand.server, obj.server, faces["right"], faces["object"], params, w2c.repeat(3, 1, 1), m.K[0, :3, :3],
+    ref = ft.FittingModel(hand.server, obj.server, faces["right"], faces["object"], params, w2c.repeat(3, 1, 1), K300[0],
                           (300, 300), ft.construct_targets(tm), torch.as_tensor(contact_idx, device=dev))
-    obj.server.object_model.obj_scale = torch.tensor([1.0], device=dev)
     with torch.no_grad():
         l_ref = float(ref()["loss"])
+    # 40 iterations through the reference-signature entry point
+    args.iters = 40
+    m = ft.optimize_batch(batch_idx, args, None, dict(out, param_dict=pd2, K=K300), dev, obj_scale=[1.0], masks=masks,
+                          contact_idx=contact_idx, freeze_shape=True)
+    assert len(m.history) == 40 and all(np.isfinite(m.history)) and m.history[-1] < 0.7 * m.history[0]
     assert m.history[0] == pytest.approx(l_ref, rel=1e-5)
 
 

@@ -124,10 +124,9 @@ def test_fused_sdf_matches_layered_path():
         assert err < 2e-5 * max(1.0, float(ref.abs().max())), (kind, err)
 
 
-@pytest.mark.parametrize("trunk", ["p", "q"])
-def test_fused_sdf_x6_matches_fp32_fused(trunk):
-    """split-precision (3 bf16 limbs x 6 products) sampler trunks against the fp32-MFMA fused kernel: "p" = limb planes
-    in LDS, 64-point blocks, pre-split weights; "q" = 96-point blocks, fp32 weight stream split in registers"""
+def test_fused_sdf_x6_matches_fp32_fused():
+    """split-precision (3 bf16 limbs x 6 products) sampler trunk (limb planes in LDS, 64-point blocks, pre-split weight
+    limbs) against the fp32-MFMA fused kernel"""
     from hold_amd import field as F, kernels as K, synthetic as syn
     dev = _dev()
     sc = syn.make_scene(2)
@@ -141,7 +140,7 @@ def test_fused_sdf_x6_matches_fp32_fused(trunk):
         rw = [eff(pre + f"rendering_network.lin{l}") for l in range(5)]
         rb = [sd[pre + f"rendering_network.lin{l}.bias"] for l in range(5)]
         pk = F.pack_weights(spec, iw, ib, rw, rb, need_bwd=False)
-        x6 = F.pack_x6(pk["W"][:8]) if trunk == "p" else F.pack_x6q(pk["W"][:8])
+        x6 = F.pack_x6(pk["W"][:8])
         P = 128 * 300 + 37
         g = torch.Generator().manual_seed(1)
         xc = torch.zeros(P, 4, device=dev)
@@ -151,9 +150,9 @@ def test_fused_sdf_x6_matches_fp32_fused(trunk):
         ref = torch.empty(P, 1, device=dev)
         K.fused_sdf(xc, P, wpack, bias8, pk["w8_sdf"], float(pk["b8_sdf"]), barf, ref)
         out = torch.full((P, 1), 7.0, device=dev)
-        (K.fused_sdf_x6 if trunk == "p" else K.fused_sdf_x6q)(xc, P, x6, bias8, pk["w8_sdf"], float(pk["b8_sdf"]), barf, out)
+        K.fused_sdf_x6(xc, P, x6, bias8, pk["w8_sdf"], float(pk["b8_sdf"]), barf, out)
         err = float((out - ref).abs().max())
-        assert err < 5e-6 * max(1.0, float(ref.abs().max())), (kind, trunk, err)
+        assert err < 5e-6 * max(1.0, float(ref.abs().max())), (kind, err)
 
 
 @pytest.mark.parametrize("mode", ["f32x6", "f32"])

@@ -134,7 +134,8 @@ def test_sampler_rounds_match_trace(ctx, gold_dir):
         assert float((ds > 1e-3).float().mean()) < 0.01, (r, float(ds.max()))
         if more:
             zn = torch.from_numpy(g[f"r{r + 1}.z_vals"]).to(dev)
-            assert float((zw[:, :S + n_new] - zn).abs().max()) < 5e-2
+            dzw = (zw[:, :S + n_new] - zn).abs()  # a sample that lands in the neighbouring bin shifts the sorted window by one slot
+            assert float((dzw > 1e-3).float().mean()) < 0.01 and float(dzw.max()) < 0.1, float(dzw.max())
             assert torch.all(zw[:, 1:S + n_new] >= zw[:, :S + n_new - 1])
             # slots point at the new samples
             assert float((torch.gather(zw, 1, slot.long()) - samples).abs().max()) == 0.0

@@ -204,6 +204,7 @@ def test_training_forward_emits_loss_targets_and_full_loss_matches_oracle(ctx):
     """steady-state training step (step % 200 == 0 -> spawn, object mesh present): HOLDNet.forward emits
     index_off_surface / pts2mano_sdf_cano / pred_sdf / grad_theta (hold_utils.py:149-240), hold_amd.loss.Loss == the
     oracle's Loss restatement term by term, and d loss / d parameters == torch autograd on the oracle."""
+    from hold_amd import meshing as M_
     from hold_amd.loss import Loss
     from oracle import targets_oracle as to
     sc, sd, osc = ctx["sc"], ctx["sd"], ctx["osc"]
@@ -214,7 +215,9 @@ def test_training_forward_emits_loss_targets_and_full_loss_matches_oracle(ctx):
     rng = _rng(sc, N)
     step, epoch = 400, 25
     net = hip_net(sc, ctx["sd_np"], train=True)
-    net.nodes["object"].update_cano(_sphere_mesh(0.12))  # small enough that part of the 6x6 rays pass it by > 0.05
+    obj_node = net.nodes["object"]  # a coarse (32^3) canonical mesh of the object's own SDF: some rays hit it, some pass by
+    obj_node.update_cano(M_.generate_mesh(lambda x: {"sdf": obj_node.implicit_network.sdf(x)}, obj_node.v_min_max,
+                                          res_init=32, res_up=0))
     inp = hip_input(b, net, epoch=epoch, step=step)
     out = net(inp, rng=_cuda_rng(rng))
     for k in ("right.index_off_surface", "right.grad_theta", "right.pts2mano_sdf_cano", "right.pred_sdf",
