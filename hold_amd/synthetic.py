@@ -274,7 +274,9 @@ def make_state_dict(scene: dict, seed: int = 1, perturb: float = 0.02, barf_iter
             std = np.sqrt(2) / np.sqrt(out)
             if l == 8:
                 w = rs.normal(np.sqrt(np.pi) / np.sqrt(inn), 1e-4, size=(out, inn))
-                b = np.full((out,), -0.6)
+                # -0.35 (the config's init uses 0.6): level sets of radius ~0.15 (hand) / ~0.25 (object) in canonical space,
+                # i.e. blobs of hand / object size in front of the camera instead of spheres that swallow it
+                b = np.full((out,), -0.35)
             elif l == 0:
                 w = np.zeros((out, inn))
                 w[:, :3] = rs.normal(0.0, std, size=(out, 3))

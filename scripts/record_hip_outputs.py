@@ -23,8 +23,9 @@ def main(path):
     torch.manual_seed(11)
     sc, sd_np, sd, osc = setup()
     net = hip_net(sc, sd_np, train=True)
-    obj = net.nodes["object"]  # coarse canonical mesh of the object's own SDF (some rays hit it, some pass by)
-    obj.update_cano(M.generate_mesh(lambda x: {"sdf": obj.implicit_network.sdf(x)}, obj.v_min_max, res_init=32, res_up=0))
+    r = 0.08  # a small sphere inside the object's SDF blob: central rays come within 0.05 of it, outer rays do not
+    net.nodes["object"].update_cano(M.generate_mesh(lambda x: {"sdf": x.norm(dim=1) - r},
+                                                    np.array([[-r, -r, -r], [r, r, r]]), res_init=24, res_up=0))
     b, _ = oracle_input(sc, sd, [0, 2], 8, 8)
     step, epoch = 400, 25
     inp = hip_input(b, net, epoch=epoch, step=step)

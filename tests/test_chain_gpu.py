@@ -220,9 +220,15 @@ def test_field_chain_route_matches_layered_route(kind, node):
         a, b = res[False][0][k], res[True][0][k]
         assert (a - b).abs().max().item() <= 2e-5 * max(1.0, a.abs().max().item()), k
     ga, gb = res[False][1], res[True][1]
+    # The two routes differ by rounding only in the trunk (chain: split-precision or fp32 MFMA in another summation
+    # order).  Downstream of it sits the rendering net's ReLU: a pre-activation within rounding of zero switches its
+    # unit on in one route and off in the other, which moves that unit's share of a weight gradient discontinuously
+    # -- a few such flips among 666 points x 1 024 units bound the agreement of the rendering-net gradients at ~1 %.
+    tol = {"iw": 2e-4, "ib": 2e-4, "rw": 1e-2, "rb": 1e-2}
     for k in ("iw", "ib", "rw", "rb"):
         for i, (a, b) in enumerate(zip(ga[k], gb[k])):
-            assert (a - b).abs().max().item() <= 2e-4 * max(1e-3, a.abs().max().item()), (k, i)
+            assert (a - b).abs().max().item() <= tol[k] * max(1e-3, a.abs().max().item()), (k, i)
+            assert (a - b).norm().item() <= 2e-3 * max(1e-3, a.norm().item()), (k, i)  # and in norm they agree to 0.2 %
     for k in ("tfs", "pose_embed", "time_code"):
         if ga[k] is None:
             continue

@@ -86,7 +86,7 @@ def test_bench_chunk_matches_oracle_on_random_rays_and_gradients_are_additive(tw
     bad = [(k, e, tol) for k, e, tol in res["outputs"] if not e < tol]
     assert not bad, bad
     rels = res["grad_rel"]
-    assert len(rels) >= (100 if not two_hands else 140)
+    assert len(rels) >= (90 if not two_hands else 130)
     worst = max(rels, key=lambda kv: kv[1])
     # fp32 accumulation of 0.8-1.6 M per-point terms in two different orders: weight matrices agree to ~1e-6; sums with
     # heavy cancellation (biases, per-frame pose rows) lose a few more digits
