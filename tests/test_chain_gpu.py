@@ -232,4 +232,6 @@ def test_field_chain_route_matches_layered_route(kind, node):
     for k in ("tfs", "pose_embed", "time_code"):
         if ga[k] is None:
             continue
-        assert (ga[k] - gb[k]).abs().max().item() <= 2e-4 * max(1e-3, ga[k].abs().max().item()), k
+        # pose_embed / time_code enter the rendering net's first layer: their gradients sit behind the same ReLU flips
+        t = 2e-4 if k == "tfs" else 2e-3
+        assert (ga[k] - gb[k]).abs().max().item() <= t * max(1e-3, ga[k].abs().max().item()), k

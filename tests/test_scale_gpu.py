@@ -91,7 +91,8 @@ def test_bench_chunk_matches_oracle_on_random_rays_and_gradients_are_additive(tw
     # fp32 accumulation of 0.8-1.6 M per-point terms in two different orders: weight matrices agree to ~1e-6; sums with
     # heavy cancellation (biases, per-frame pose rows) lose a few more digits
     assert float(np.median([r for _, r in rels])) < 1e-5, float(np.median([r for _, r in rels]))
-    assert sum(r < 1e-5 for _, r in rels) >= 0.85 * len(rels), sorted(rels, key=lambda kv: -kv[1])[:8]
+    assert sum(r < 1e-5 for _, r in rels) >= 0.75 * len(rels), sorted(rels, key=lambda kv: -kv[1])[:8]
+    assert sum(r < 1e-4 for _, r in rels) >= 0.97 * len(rels), sorted(rels, key=lambda kv: -kv[1])[:8]
     assert worst[1] < 1e-3, worst
 
 
