@@ -95,6 +95,7 @@ DEV_SIGNATURES = {
 # every exported symbol of include/hold_hip.h with its argument types (stream is always last)
 SIGNATURES = {
     "hold_gemm_nt": [C.POINTER(GemmDesc), _P],
+    "hold_gemm_nt_x6": [C.POINTER(GemmDesc), _P],
     "hold_wgrad": [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _P],
     "hold_wgrad_x6": [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _P],
     "hold_ray_points": [_P, _P, _P, _I, _I, _L, _P, _I, _P],

@@ -90,7 +90,11 @@ __device__ __forceinline__ float dsp_from_h(float h) {
 // NT = number of 32-wide output tiles per wave: 2 -> block tile 128 x 128 (BK 32), 4 -> 128 x 256 (BK 16).
 // The wide tile loads 24 KiB per 64 MFMAs/wave instead of 32 KiB (and streams A once instead of twice):
 // the kernel is limited by the per-CU load path (ablation in DESIGN.md), not by MFMA issue.
-template <int EPI, int NT>
+// X6: 0 = fp32 MFMA; 2 = split precision: both operand fragments are split into three bf16 limbs (truncation split,
+// exact) as they leave LDS and 6 of the 9 limb products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+// Staging, swizzle, tile walk and epilogues are shared; a lane's 8 consecutive k of a fragment row are the two
+// 16-byte chunks it reads anyway.
+template <int EPI, int NT, int X6 = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(hold_gemm_desc d, int total_tiles, int stagger) {
   constexpr int BNc = 64 * NT;              // block outputs
   constexpr int BKc = (NT == 2) ? 32 : 16;  // k per stage
@@ -240,6 +244,47 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(hold_gemm_desc d, int t
       const float* pw = sW + buf * (BNc * BKc) + roww0 * BKc;
       // fragments of the next 16-byte k group are requested before this group's MFMAs (pinned with sched barriers:
       // left alone the scheduler issues them a couple of MFMAs before their use)
+      if constexpr (X6 != 0) {
+#pragma unroll
+        for (int g = 0; g < QN / 2; ++g) {
+          const int c = hh * QN + 2 * g;
+          Limbs3 la[2];
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            const int kk = key(rowa0 + 32 * a);
+            const f32x4 u0 = *reinterpret_cast<const f32x4*>(pa + a * 32 * BKc + ((c ^ kk) << 2));
+            const f32x4 u1 = *reinterpret_cast<const f32x4*>(pa + a * 32 * BKc + (((c + 1) ^ kk) << 2));
+            const float x[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
+            la[a] = split8s_trunc(x);
+          }
+          // output tiles two at a time (4 accumulators in rotation, 12 + 24 limb registers live)
+#pragma unroll
+          for (int bp = 0; bp < NT; bp += 2) {
+            Limbs3 lb[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              const int kk = key(roww0 + 32 * (bp + b));
+              const f32x4 u0 = *reinterpret_cast<const f32x4*>(pw + (bp + b) * 32 * BKc + ((c ^ kk) << 2));
+              const f32x4 u1 = *reinterpret_cast<const f32x4*>(pw + (bp + b) * 32 * BKc + (((c + 1) ^ kk) << 2));
+              const float x[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
+              lb[b] = split8s_trunc(x);
+            }
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr) {
+              const int il = (pr == 2 || pr == 3) ? 1 : (pr == 5 ? 2 : 0);  // (A limb, W limb): 00 01 10 11 02 20
+              const int jl = (pr == 1 || pr == 3) ? 1 : (pr == 4 ? 2 : 0);
+#pragma unroll
+              for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                  acc[a][bp + b] =
+                      __builtin_amdgcn_mfma_f32_32x32x16_bf16(la[a].l[il], lb[b].l[jl], acc[a][bp + b], 0, 0, 0);
+            }
+          }
+        }
+        if (!(stagger & 512)) stage_wait();
+        continue;
+      }
       f32x4 avn[2], bvn[NT];
       auto frag = [&](int q) {
         const int c = hh * QN + q;
@@ -537,14 +582,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restri
     const float* pr = sR + buf * PC * 128 + (hh * STEPS) * 128 + wn * 64 + li;
     const float* px = sX + buf * PC * BKW + (hh * STEPS) * BKW + wk * (32 * KT) + li;
     if constexpr (X6 != 0) {
-      // EXPERIMENTAL split precision (opt-in HOLD_WGRAD_X6=1, not yet run on hardware): both operands are split into
-      // three bf16 limbs as they leave LDS, six limb products per 16 reduction rows on v_mfma_f32_32x32x16_bf16.
+      // split precision (hold_wgrad_x6): both operands are split into three bf16 limbs as they leave LDS, six limb
+      // products per 16 reduction rows on v_mfma_f32_32x32x16_bf16.
       // Lane (hh, li) supplies rows 16 step + 8 hh .. + 7 of column li of its n / k tile to both operands.
       const float* pr6 = sR + buf * PC * 128 + (hh * 8) * 128 + wn * 64 + li;
       const float* px6 = sX + buf * PC * BKW + (hh * 8) * BKW + wk * (32 * KT) + li;
 #pragma unroll
       for (int st = 0; st < PC / 16; ++st) {
-        Limbs3 la[2], lb[KT];
+        Limbs3 la[2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
           float x[8];
@@ -553,22 +598,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restri
           bsum[a] += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
           la[a] = (X6 == 2) ? split8s_trunc(x) : split8s(x);
         }
+        // k tiles two at a time: 4 accumulators in rotation, 24 + 24 limb registers live
 #pragma unroll
-        for (int b = 0; b < KT; ++b) {
-          float x[8];
+        for (int bp = 0; bp < KT; bp += 2) {
+          Limbs3 lb[2];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) x[e] = px6[(st * 16 + e) * BKW + b * 32];
-          lb[b] = (X6 == 2) ? split8s_trunc(x) : split8s(x);
-        }
+          for (int b = 0; b < 2; ++b) {
+            float x[8];
 #pragma unroll
-        for (int pr = 0; pr < 6; ++pr) {
-          const int il = (pr == 2 || pr == 3) ? 1 : (pr == 5 ? 2 : 0);   // (R limb, X limb): 00 01 10 11 02 20
-          const int jl = (pr == 1 || pr == 3) ? 1 : (pr == 4 ? 2 : 0);
+            for (int e = 0; e < 8; ++e) x[e] = px6[(st * 16 + e) * BKW + (bp + b) * 32];
+            lb[b] = (X6 == 2) ? split8s_trunc(x) : split8s(x);
+          }
 #pragma unroll
-          for (int a = 0; a < 2; ++a)
+          for (int pr = 0; pr < 6; ++pr) {
+            const int il = (pr == 2 || pr == 3) ? 1 : (pr == 5 ? 2 : 0);   // (R limb, X limb): 00 01 10 11 02 20
+            const int jl = (pr == 1 || pr == 3) ? 1 : (pr == 4 ? 2 : 0);
 #pragma unroll
-            for (int b = 0; b < KT; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la[a].l[il], lb[b].l[jl], acc[a][b], 0, 0, 0);
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int b = 0; b < 2; ++b)
+                acc[a][bp + b] =
+                    __builtin_amdgcn_mfma_f32_32x32x16_bf16(la[a].l[il], lb[b].l[jl], acc[a][bp + b], 0, 0, 0);
+          }
         }
       }
     } else {
@@ -639,11 +690,34 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, 
   *o = accumulate ? *o + s : s;
 }
 
+// The same reduction for K % 4 == 0 with 16-byte accesses and the partial sums spread over 16 thread groups: a block
+// owns 64 consecutive elements (16 lanes x float4 = one 256-byte segment per partial tile), thread group g sums the
+// tiles g, g + 16, ... (independent loads in flight instead of one dependent chain of `splits` loads per thread),
+// then the 16 group sums are added in a fixed order -- deterministic, ~5x faster than the scalar version at 256 splits.
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ part, int splits, long NK, int K,
+                                                            float* __restrict__ dW, int lddw, int accumulate) {
+  __shared__ f32x4 red[16][16];
+  const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const long i = ((long)blockIdx.x * 16 + e) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i < NK)
+    for (int sp = g; sp < splits; sp += 16) s += *reinterpret_cast<const f32x4*>(part + (long)sp * NK + i);
+  red[g][e] = s;
+  __syncthreads();
+  if (g != 0 || i >= NK) return;
+#pragma unroll
+  for (int j = 1; j < 16; ++j) s += red[j][e];
+  const long n = i / K, k = i % K;
+  float* o = dW + n * lddw + k;
+  if (accumulate) s += *reinterpret_cast<const f32x4*>(o);
+  *reinterpret_cast<f32x4*>(o) = s;
+}
+
 }  // namespace
 
 extern "C" int hold_abi_version(void) { return 1; }
 
-template <int NT>
+template <int NT, int X6 = 0>
 static int launch_gemm(const hold_gemm_desc& d, hipStream_t s) {
   constexpr int BNc = 64 * NT, BKc = (NT == 2) ? 32 : 16;
   const long mt = ((long)d.P + BM - 1) / BM;
@@ -673,7 +747,7 @@ static int launch_gemm(const hold_gemm_desc& d, hipStream_t s) {
 #endif
   switch (d.epilogue) {
 #define HOLD_CASE(E) \
-  case E: hipLaunchKernelGGL((gemm_nt_kernel<E, NT>), grid, block, 0, s, d, tiles, stagger); break;
+  case E: hipLaunchKernelGGL((gemm_nt_kernel<E, NT, X6>), grid, block, 0, s, d, tiles, stagger); break;
     HOLD_CASE(HOLD_EPI_NONE)
     HOLD_CASE(HOLD_EPI_SOFTPLUS)
     HOLD_CASE(HOLD_EPI_RELU)
@@ -688,7 +762,7 @@ static int launch_gemm(const hold_gemm_desc& d, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
 }
 
-extern "C" int hold_gemm_nt(const hold_gemm_desc* dp, hold_stream_t stream) {
+static int gemm_nt_impl(const hold_gemm_desc* dp, hold_stream_t stream, int x6) {
   if (!dp) return HOLD_E_ARG;
   hold_gemm_desc d = *dp;
   if (!d.A || !d.W || !d.C || d.P < 0 || d.N <= 0 || d.K <= 0) return HOLD_E_ARG;
@@ -705,8 +779,12 @@ extern "C" int hold_gemm_nt(const hold_gemm_desc* dp, hold_stream_t stream) {
 #ifdef HOLD_DEV
   if (const char* w = getenv("HOLD_GEMM_TILE")) wide = atoi(w) == 256;
 #endif
+  if (x6) return wide ? launch_gemm<4, 2>(d, s) : launch_gemm<2, 2>(d, s);
   return wide ? launch_gemm<4>(d, s) : launch_gemm<2>(d, s);
 }
+
+extern "C" int hold_gemm_nt(const hold_gemm_desc* dp, hold_stream_t stream) { return gemm_nt_impl(dp, stream, 0); }
+extern "C" int hold_gemm_nt_x6(const hold_gemm_desc* dp, hold_stream_t stream) { return gemm_nt_impl(dp, stream, 1); }
 
 extern "C" int64_t hold_wgrad_workspace_floats(int32_t N, int32_t K, int32_t splits) {
   return (int64_t)splits * ((int64_t)N * K + N);
@@ -727,7 +805,17 @@ static int wgrad_impl(const float* R, int32_t ldr, const float* X, int32_t ldx, 
 #ifdef HOLD_DEV
   if (getenv("HOLD_WGRAD_DIRECT")) lds_ok = false;
 #endif
-  if (lds_ok && mode != 0) {  // split-precision path (128 x 128 tiles)
+  bool x6_wide = K > 128;  // 128 n x 256 k tiles: 6 fragment splits per 48 MFMAs instead of 4 per 24
+#ifdef HOLD_DEV
+  if (const char* w = getenv("HOLD_WGRAD_X6_TILE")) x6_wide = atoi(w) == 256;
+#endif
+  if (lds_ok && mode == 2 && x6_wide) {
+    const int tiles = ((N + 127) / 128) * ((K + 255) / 256);
+    const long ch = ((long)P + 15) / 16;
+    if (splits > ch) splits = (int)(ch > 0 ? ch : 1);
+    hipLaunchKernelGGL((wgrad_lds_kernel<4, 2>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits,
+                       part, part_b);
+  } else if (lds_ok && mode != 0) {  // split-precision path (128 x 128 tiles)
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
     if (mode == 2)
       hipLaunchKernelGGL((wgrad_lds_kernel<2, 2>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits,
@@ -751,8 +839,12 @@ static int wgrad_impl(const float* R, int32_t ldr, const float* X, int32_t ldx, 
                        part_b);
   }
   const long NK = (long)N * K;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((NK + 255) / 256)), dim3(256), 0, s, part, splits, NK, K, dW,
-                     lddw, accumulate);
+  if (!(K & 3) && !(lddw & 3) && !((uintptr_t)dW & 15) && !((uintptr_t)part & 15))
+    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((NK / 4 + 15) / 16)), dim3(256), 0, s, part, splits, NK, K,
+                       dW, lddw, accumulate);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((NK + 255) / 256)), dim3(256), 0, s, part, splits, NK, K, dW,
+                       lddw, accumulate);
   if (db)
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, part_b, splits,
                        (long)N, N, db, N, accumulate);

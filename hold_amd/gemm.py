@@ -64,7 +64,10 @@ def gemm_nt(A, W, out, *, bias=None, epi=EPI_NONE, alpha=1.0, N=None, K=None, n_
         d.out2, d.ldout2 = ptr(out2), _ld(out2)
     d.accumulate = 1 if accumulate else 0
     e0 = _prof_begin()
-    check(_lib.lib().hold_gemm_nt(C.byref(d), stream_ptr()), "hold_gemm_nt")
+    if config.x6():
+        check(_lib.lib().hold_gemm_nt_x6(C.byref(d), stream_ptr()), "hold_gemm_nt_x6")
+    else:
+        check(_lib.lib().hold_gemm_nt(C.byref(d), stream_ptr()), "hold_gemm_nt")
     _prof_end(e0, 2.0 * P * N * K, "gemm_nt_kernel")
     return out
 

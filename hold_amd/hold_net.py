@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import config
 from . import gemm as G
 from . import kernels as K
 from .field import FEAT, FieldSpec, NodeField, Pool, pack_weights, pad4
@@ -88,6 +89,12 @@ def _lin(inn, out, weight_norm):
     return nn.utils.weight_norm(l) if weight_norm else l
 
 
+def _pack_key(modules, training):
+    """identity of the parameter values a weight pack was built from (see hold_amd/config.py: weight-pack invalidation)"""
+    return (config.precision(), bool(training), config.weights_epoch(),
+            tuple((p._version, p.data_ptr()) for m in modules for p in m.parameters()))
+
+
 def _eff(lin):
     """effective weight of a (possibly weight-normed) Linear, differentiable w.r.t. weight_g / weight_v."""
     if hasattr(lin, "weight_g"):
@@ -139,10 +146,19 @@ class ImplicitNet(nn.Module):
                 nn.init.uniform_(lin.weight, -1e-5, 1e-5)
             setattr(self, f"lin{l}", nn.utils.weight_norm(lin) if weight_norm else lin)
         self._fields = {}
+        self._pack_cache = (None, None)
 
     def effective(self):
         lins = [getattr(self, f"lin{l}") for l in range(9)]
         return [_eff(l) for l in lins], [l.bias for l in lins]
+
+    def _pack(self, spec, iw, ib):
+        """trunk-only weight pack for the kernel-backed call surface, rebuilt when a parameter changes"""
+        key = _pack_key((self,), True)
+        if self._pack_cache[0] != key:
+            with torch.no_grad():
+                self._pack_cache = (key, pack_weights(spec, iw, ib, None, None, need_bwd=True))
+        return self._pack_cache[1]
 
     # ---- kernel-backed call surface (shape_net.py:84-144) ----
     def _field(self, device, tag):
@@ -170,12 +186,12 @@ class ImplicitNet(nn.Module):
         P = x.shape[0]
         fld = self._field(x.device, "oc")
         iw, ib = self.effective()
-        pk = pack_weights(fld.spec, iw, ib, None, None, need_bwd=False)
+        pk = self._pack(fld.spec, iw, ib)
         xc = torch.zeros(P, 4, device=x.device)
         xc[:, :3] = x
         out = torch.empty(P, 1, device=x.device)
         wpack, bias8 = pk["fused"]
-        K.fused_sdf(xc, P, wpack, bias8, pk["w8_sdf"], float(pk["b8_sdf"]), self.embedder_obj.weights(x.device), out)
+        K.fused_sdf(xc, P, wpack, bias8, pk["w8_sdf"], pk["b8_sdf_f"], self.embedder_obj.weights(x.device), out)
         return out.view(P)
 
     def gradient(self, x, cond=None):
@@ -279,8 +295,7 @@ class _FieldFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, node, x, ppf, dfm_const, barf_w, training, tfs, pose_embed, time_code, *weights):
-        iw, ib, rw, rb = weights[0:9], weights[9:18], weights[18:23], weights[23:28]
-        pk = pack_weights(node.spec, iw, ib, rw, rb, need_bwd=training)
+        pk = node._pk  # packed by Node.render from these same weights
         P = x.shape[0]
         nb = node.spec.n_bones
         dfm = dict(dfm_const)
@@ -330,7 +345,7 @@ class _EikonalFn(torch.autograd.Function):
     def forward(ctx, inet, xc, barf_w, *weights):
         iw, ib = weights[0:9], weights[9:18]
         fld = inet._field(xc.device, "eik")
-        pk = pack_weights(fld.spec, iw, ib, None, None, need_bwd=True)
+        pk = inet._pack(fld.spec, iw, ib)
         g = fld.grad_points_forward(pk, xc, xc.shape[0], barf_w)
         ctx.fld, ctx.gen = fld, fld.gen
         return g[:, :3].clone()
@@ -349,7 +364,7 @@ class _ImplicitFn(torch.autograd.Function):
     def forward(ctx, inet, x, barf_w, *weights):
         iw, ib = weights[0:9], weights[9:18]
         fld = inet._field(x.device, "oc")
-        pk = pack_weights(fld.spec, iw, ib, None, None, need_bwd=True)
+        pk = inet._pack(fld.spec, iw, ib)
         P = x.shape[0]
         xc = fld.pool.get("xc_in", P, 4)
         xc[:, :3] = x.detach()
@@ -454,6 +469,7 @@ class Node(nn.Module):
         self.params = params
         self.field = None
         self._pk = None
+        self._pk_key = None
 
     def _field(self, device):
         if self.field is None or self.field.device != device:
@@ -500,8 +516,13 @@ class Node(nn.Module):
         weights = self._weights()
         nb = self.spec.n_bones
         N = ray_dirs.shape[0]
-        with torch.no_grad():  # one re-layout of the (constant within the call) weights for sampler + field + backward
-            self._pk = pack_weights(self.spec, weights[0:9], weights[9:18], weights[18:23], weights[23:28], training)
+        # one re-layout of the weights for sampler + field + backward, kept until a parameter changes (every chunk of a
+        # step, and every eval forward between optimiser steps, reuses it)
+        key = _pack_key((self.implicit_network, self.rendering_network), training)
+        if self._pk is None or self._pk_key != key:
+            with torch.no_grad():
+                self._pk = pack_weights(self.spec, weights[0:9], weights[9:18], weights[18:23], weights[23:28], training)
+            self._pk_key = key
         # ---- sampler (no grad; sampler toggles net.eval()/train() in the reference, a no-op for these nets) ----
         if z_override is None:
             with torch.no_grad():

@@ -20,6 +20,7 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
+from . import config
 from ._lib import call, ptr
 from .loss import reduce_workspace
 
@@ -105,6 +106,7 @@ class FlatAdam:
         call("hold_adam_step", ptr(self.flat), ptr(self.grad), ptr(self.m), ptr(self.v), self.n, self.n_low,
              self.lr * self.pose_lr_scale, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count,
              float(grad_mul), self.clip_norm, ptr(self.sumsq) if self.clip_norm > 0 else None)
+        config.bump_weights_epoch()  # parameters changed behind torch's version counters: cached weight packs are stale
 
     def grad_norm(self):
         """global L2 norm of the (reduced) gradient bucket -- a host read, for logging / tests only."""

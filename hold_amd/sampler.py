@@ -80,12 +80,11 @@ class ErrorBoundSampler:
         beta0 = density_fn.get_beta().item() if hasattr(density_fn, "get_beta") else float(density_fn)
         if sdf_fn is VU.sdf_func_with_deformer and isinstance(implicit_network, ImplicitNet):
             # fast path: KNN inverse LBS + the fused LDS-resident trunk, no [P,257] intermediate
-            from .field import pack_weights
             fld = implicit_network._field(ray_dirs.device, "sampler")
             nb = fld.spec.n_bones
             with torch.no_grad():
                 iw, ib = implicit_network.effective()
-                pk = pack_weights(fld.spec, iw, ib, None, None, need_bwd=False)
+                pk = implicit_network._pack(fld.spec, iw, ib)
                 dfm = dict(tfs=tfs.detach().reshape(B, nb, 16).contiguous().float())
                 if nb > 1:
                     dfm["verts"] = deform_info["verts"].detach().contiguous().float()

@@ -70,6 +70,10 @@ typedef struct hold_gemm_desc {
 } hold_gemm_desc;
 
 int hold_gemm_nt(const hold_gemm_desc* d, hold_stream_t stream);
+/* same contract and epilogues, split-precision arithmetic: A and W fragments are decomposed into three bf16 limbs as
+ * they leave LDS (exact 8+8+8-bit truncation split), six limb products on v_mfma_f32_32x32x16_bf16, fp32 accumulation
+ * (dropped products <= 2^-23 relative). */
+int hold_gemm_nt_x6(const hold_gemm_desc* d, hold_stream_t stream);
 
 /* Weight gradient: dW[n][k] (+)= sum_p R[p][n] * X[p][k];  db[n] (+)= sum_p R[p][n] (db may be NULL).
  * Split over P into `splits` partial tiles in `workspace` (>= hold_wgrad_workspace_floats floats),

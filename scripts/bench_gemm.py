@@ -2,7 +2,11 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import hold_amd
 from hold_amd import gemm
+if os.environ.get("HOLD_X6") == "0":
+    hold_amd.set_precision("f32")
+print("precision", hold_amd.precision())
 
 dev = torch.device("cuda:0")
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
@@ -42,6 +46,8 @@ torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 10
 print(f"wgrad P={P} 256x256: {ms:.3f} ms {2.0 * P * 65536 / ms / 1e9:.1f} TFLOP/s")
 
+if not os.environ.get("HOLD_LIB"):
+    sys.exit(0)  # the pure-MFMA loop below is a developer-build diagnostics kernel
 from hold_amd import _lib
 blocks, iters = 512 * 8, 512
 o = torch.empty(blocks * 256, device=dev)

@@ -10,13 +10,23 @@ def _dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(params=["f32x6", "f32"])
+def arith(request):
+    """run a test under both arithmetics: hold_gemm_nt_x6 / hold_gemm_nt (same tolerances)"""
+    import hold_amd
+    prev = hold_amd.precision()
+    hold_amd.set_precision(request.param)
+    yield request.param
+    hold_amd.set_precision(prev)
+
+
 def _softplus_ref(y):
     return torch.nn.functional.softplus(y, beta=100)
 
 
 @pytest.mark.parametrize("P,N,K", [(1000, 256, 256), (777, 217, 256), (130, 257, 256), (4096, 3, 256), (513, 256, 40),
                                     (300, 39, 256), (260, 256, 272), (64, 128, 316)])
-def test_gemm_nt_plain_and_softplus(P, N, K):
+def test_gemm_nt_plain_and_softplus(P, N, K, arith):
     from hold_amd import gemm
     dev = _dev()
     g = torch.Generator(device="cpu").manual_seed(P + N + K)
@@ -36,7 +46,7 @@ def test_gemm_nt_plain_and_softplus(P, N, K):
     assert (out2.double() - ref2).abs().max().item() < 2e-5
 
 
-def test_gemm_split_and_epilogues():
+def test_gemm_split_and_epilogues(arith):
     from hold_amd import gemm
     dev = _dev()
     torch.manual_seed(0)
