@@ -33,6 +33,8 @@ class GemmDesc(C.Structure):
         ("aux2", C.c_void_p), ("ldaux2", C.c_int32),
         ("out2", C.c_void_p), ("ldout2", C.c_int32),
         ("accumulate", C.c_int32),
+        ("r1_row", C.c_void_p), ("ldr1", C.c_int32),
+        ("r1_col", C.c_void_p),
     ]
 
 
@@ -116,6 +118,7 @@ SIGNATURES = {
     "hold_rowdot": [_P, _I, _P, _I, _F, _L, _P, _I, _P],
     "hold_seed_dsp": [_P, _I, _P, _I, _L, _P, _I, _P],
     "hold_colsum": [_P, _I, _I, _L, _P, _P],
+    "hold_wcolsum": [_P, _I, _I, _L, _P, _P, _I, _P, _P],
     "hold_sampler_init": [_P, _P, _L, _F, _F, _I, _F, _P, _P, _I, _P, _P, _P, _P],
     "hold_sampler_beta": [_P, _P, _I, _I, _L, _P, _P, _I, _P, _F, _F, _I, _P, _P],
     "hold_sampler_sample": [_P, _P, _I, _I, _L, _P, _I, _F, _P, _L, _I, _P, _P, _P],
@@ -158,6 +161,8 @@ def _declare(L):
     L.hold_chain_pack_floats.restype = C.c_int64
     L.hold_chain_x6_pack_bytes.argtypes = [C.c_int32, C.c_int32]
     L.hold_chain_x6_pack_bytes.restype = C.c_int64
+    L.hold_wcolsum_workspace_floats.argtypes = [C.c_int32]
+    L.hold_wcolsum_workspace_floats.restype = C.c_int64
     L.hold_silhouette_workspace_floats.argtypes = [C.c_int32, C.c_int32]
     L.hold_silhouette_workspace_floats.restype = C.c_int64
     for name, args in SIGNATURES.items():

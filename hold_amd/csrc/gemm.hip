@@ -94,7 +94,10 @@ __device__ __forceinline__ float dsp_from_h(float h) {
 // exact) as they leave LDS and 6 of the 9 limb products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
 // Staging, swizzle, tile walk and epilogues are shared; a lane's 8 consecutive k of a fragment row are the two
 // 16-byte chunks it reads anyway.
-template <int EPI, int NT, int X6 = 0>
+// NBUF: operand stages in LDS.  2 = the next stage is requested while this one is computed; 3 = two stages ahead (the
+// split-precision product spends 2.7x fewer matrix-core cycles per stage, one stage of compute no longer covers the
+// load latency) -- 3 x 24 KiB for the wide tile, still two blocks per CU.
+template <int EPI, int NT, int X6 = 0, int NBUF = 2>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(hold_gemm_desc d, int total_tiles, int stagger) {
   constexpr int BNc = 64 * NT;              // block outputs
   constexpr int BKc = (NT == 2) ? 32 : 16;  // k per stage
@@ -103,9 +106,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(hold_gemm_desc d, int t
   constexpr int KSH = (NT == 2) ? 1 : 2;    // swizzle key = (row >> KSH) & (CH - 1)
   constexpr int QN = BKc / 8;               // ds_read_b128 per fragment row per stage
   constexpr int CSTR = 68;
-  __shared__ __attribute__((aligned(16))) float smem[4 * 64 * CSTR];  // 69.6 KiB: epilogue staging >= operand stages
+  constexpr int STG = NBUF * (BM + BNc) * BKc, EPS = 4 * 64 * CSTR;  // operand stages / epilogue staging (69.6 KiB)
+  __shared__ __attribute__((aligned(16))) float smem[STG > EPS ? STG : EPS];
   float* sA = smem;
-  float* sW = smem + 2 * BM * BKc;
+  float* sW = smem + NBUF * BM * BKc;
+  constexpr int NI = BM / RPI / 4 + BNc / RPI / 4;  // DMA instructions per wave and stage
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -171,6 +176,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(hold_gemm_desc d, int t
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
+  // all stages but the most recently requested one have landed (that one is a full DMA stage: NI instructions in flight)
+  auto stage_wait_keep1 = [&]() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+    __syncthreads();
+  };
+  auto full_stage = [&](int kt) { return kt * BKc + BKc <= d.K; };
 
   // Persistent blocks: the grid is 2 blocks per CU, each walks tiles blockIdx.x, +gridDim.x, ...  The
   // second half of the grid (the blocks that share CUs with the first half) starts half a tile late, so
@@ -186,8 +197,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(hold_gemm_desc d, int t
   if (EPI == HOLD_EPI_DBWD)
     vec_ok = vec_ok && al16(d.aux1, d.ldaux1) && al16(d.aux2, d.ldaux2) && al16(d.out2, d.ldout2);
 
+  if (d.r1_row) vec_ok = vec_ok && al16(d.r1_col, 0);
+
   auto epi_scalar = [&](long p, int n, float acc_v) {
     float y = acc_v * d.alpha + (d.bias ? d.bias[n] : 0.f);
+    if (d.r1_row) y += d.r1_row[p * (long)d.ldr1] * d.r1_col[n];
     if (n >= d.n_split) {
       float* o = d.C2 + p * (long)d.ldc2 + (n - d.n_split);
       *o = d.accumulate ? *o + y : y;
@@ -234,12 +248,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(hold_gemm_desc d, int t
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     stage(m0, n0, 0, 0);
-    stage_wait();
+    if (NBUF == 3 && nk > 1) {
+      stage(m0, n0, 1, 1);
+      if (full_stage(1)) stage_wait_keep1(); else stage_wait();
+    } else {
+      stage_wait();
+    }
 
     const int rowa0 = wm * 64 + li, roww0 = wn * (32 * NT) + li;
     for (int kt = 0; kt < nk; ++kt) {
-      const int buf = kt & 1;
-      if (kt + 1 < nk && !(stagger & 256)) stage(m0, n0, kt + 1, buf ^ 1);
+      const int buf = kt % NBUF;
+      if (kt + NBUF - 1 < nk && !(stagger & 256)) stage(m0, n0, kt + NBUF - 1, (kt + NBUF - 1) % NBUF);
       const float* pa = sA + buf * (BM * BKc) + rowa0 * BKc;
       const float* pw = sW + buf * (BNc * BKc) + roww0 * BKc;
       // fragments of the next 16-byte k group are requested before this group's MFMAs (pinned with sched barriers:
@@ -282,7 +301,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(hold_gemm_desc d, int t
             }
           }
         }
-        if (!(stagger & 512)) stage_wait();
+        if (!(stagger & 512)) {
+          // stage kt + 1 must have landed; with three buffers the stage just requested (kt + 2) stays in flight
+          if (NBUF == 3 && kt + 2 < nk && full_stage(kt + 2)) stage_wait_keep1(); else stage_wait();
+        }
         continue;
       }
       f32x4 avn[2], bvn[NT];
@@ -346,6 +368,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(hold_gemm_desc d, int t
         if (vec_ok && n + 3 < d.n_split) {
           f32x4 y = v * d.alpha;
           if (d.bias) y += *reinterpret_cast<const f32x4*>(d.bias + n);
+          if (d.r1_row) y += *reinterpret_cast<const f32x4*>(d.r1_col + n) * d.r1_row[p * (long)d.ldr1];
           f32x4* o = reinterpret_cast<f32x4*>(d.C + p * (long)d.ldc + n);
           if (EPI == HOLD_EPI_NONE) {
             if (d.accumulate) y += *o;
@@ -491,7 +514,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
 // version is bound by the CU's texture-address path (64 VMEM instructions per 64 MFMAs per wave).  Fragments are
 // column reads of the row-major LDS image (ds_read_b32, consecutive lanes = consecutive banks, conflict-free).
 // KT = 32-wide k tiles per wave: 2 -> block tile 128 n x 128 k (32 rows per stage), 4 -> 128 n x 256 k (16 rows).
-template <int KT, int X6 = 0>  // X6: 0 fp32 MFMA, 1 bf16 x 6 limb products (rounded limbs), 2 (truncated limbs)
+template <int KT, int X6 = 0, int NBUF = 2>  // X6: 0 fp32 MFMA, 1 bf16 x 6 limb products (rounded limbs), 2 (truncated)
 __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restrict__ R, int ldr,
                                                            const float* __restrict__ X, int ldx, int P, int N, int K,
                                                            int splits, float* __restrict__ part,
@@ -501,9 +524,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restri
   constexpr int STEPS = PC / 2;
   constexpr int RI = PC * 128 / 256;        // DMA instructions per R stage (256 floats each)
   constexpr int XI = PC * BKW / 256;
-  __shared__ __attribute__((aligned(16))) float smem[2 * PC * (128 + BKW)];
+  __shared__ __attribute__((aligned(16))) float smem[NBUF * PC * (128 + BKW)];
   float* sR = smem;
-  float* sX = smem + 2 * PC * 128;
+  float* sX = smem + NBUF * PC * 128;
+  constexpr int NI = RI / 4 + XI / 4;  // DMA instructions per wave and stage
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;
   const int hh = lane >> 5, li = lane & 31;
@@ -572,13 +596,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restri
   float bsum[2] = {0.f, 0.f};
   const bool do_bias = (part_b != nullptr) && (tile % ntk == 0) && (wk == 0);
 
+  auto stage_wait_keep1 = [&]() {  // everything but the most recently requested (full DMA) stage has landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+    __syncthreads();
+  };
+  auto full_stage = [&](long c) { return c * PC + PC <= P; };
   if (c_begin < c_end) {
     stage(c_begin, 0);
-    stage_wait();
+    if (NBUF == 3 && c_begin + 1 < c_end) {
+      stage(c_begin + 1, 1);
+      if (full_stage(c_begin + 1)) stage_wait_keep1(); else stage_wait();
+    } else {
+      stage_wait();
+    }
   }
   for (long c = c_begin; c < c_end; ++c) {
-    const int buf = (int)((c - c_begin) & 1);
-    if (c + 1 < c_end) stage(c + 1, buf ^ 1);
+    const int buf = (int)((c - c_begin) % NBUF);
+    if (c + NBUF - 1 < c_end) stage(c + NBUF - 1, (int)((c - c_begin + NBUF - 1) % NBUF));
     const float* pr = sR + buf * PC * 128 + (hh * STEPS) * 128 + wn * 64 + li;
     const float* px = sX + buf * PC * BKW + (hh * STEPS) * BKW + wk * (32 * KT) + li;
     if constexpr (X6 != 0) {
@@ -653,7 +687,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restri
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    stage_wait();
+    if (NBUF == 3 && c + 2 < c_end && full_stage(c + 2)) stage_wait_keep1(); else stage_wait();
   }
   float* out = part + (long)split * N * K;
 #pragma unroll
@@ -713,11 +747,62 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restr
   *reinterpret_cast<f32x4*>(o) = s;
 }
 
+// weighted column sums, first pass: part[block][n] = sum over the block's rows of w[p] * X[p][n].  A wave reads one
+// 1 KiB row segment per instruction (64 lanes x 16 B); the four waves of a block take rows r, r+1, r+2, r+3 (mod 4).
+__global__ __launch_bounds__(256) void wcolsum_kernel(const float* __restrict__ X, int ldx, int N, long P,
+                                                     const float* __restrict__ w, long rows_per_block,
+                                                     float* __restrict__ part) {
+  __shared__ f32x4 red[4][64];
+  const int cg = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(P, r0 + rows_per_block);
+  for (int c0 = 0; c0 < N; c0 += 256) {
+    const int c = c0 + cg * 4;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if (c < N) {
+      long r = r0 + ph;
+      for (; r + 4 < r1; r += 8) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(X + r * ldx + c);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(X + (r + 4) * ldx + c);
+        acc0 += v0 * (w ? w[r] : 1.0f);
+        acc1 += v1 * (w ? w[r + 4] : 1.0f);
+      }
+      if (r < r1) acc0 += *reinterpret_cast<const f32x4*>(X + r * ldx + c) * (w ? w[r] : 1.0f);
+    }
+    red[ph][cg] = acc0 + acc1;
+    __syncthreads();
+    if (ph == 0 && c < N)
+      *reinterpret_cast<f32x4*>(part + (long)blockIdx.x * N + c) = (red[0][cg] + red[1][cg]) + (red[2][cg] + red[3][cg]);
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" int hold_abi_version(void) { return 1; }
 
-template <int NT, int X6 = 0>
+constexpr int WCOLSUM_BLOCKS = 2048;
+extern "C" int64_t hold_wcolsum_workspace_floats(int32_t N) { return (int64_t)WCOLSUM_BLOCKS * N; }
+
+extern "C" int hold_wcolsum(const float* X, int32_t ldx, int32_t N, int64_t P, const float* w, float* out,
+                            int32_t accumulate, float* workspace, hold_stream_t stream) {
+  if (!X || !out || !workspace || N <= 0 || N > 1024 || (N & 3) || (ldx & 3) || P < 0) return HOLD_E_ARG;
+  if (((uintptr_t)X & 15) || ((uintptr_t)out & 15) || ((uintptr_t)workspace & 15)) return HOLD_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (P == 0) {
+    if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * N, s) != hipSuccess) return HOLD_E_LAUNCH;
+    return HOLD_OK;
+  }
+  long blocks = (P + 15) / 16;
+  if (blocks > WCOLSUM_BLOCKS) blocks = WCOLSUM_BLOCKS;
+  const long rpb = (P + blocks - 1) / blocks;
+  blocks = (P + rpb - 1) / rpb;
+  hipLaunchKernelGGL(wcolsum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, ldx, N, (long)P, w, rpb, workspace);
+  hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((N / 4 + 15) / 16)), dim3(256), 0, s, workspace, (int)blocks,
+                     (long)N, N, out, N, accumulate);
+  return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+}
+
+template <int NT, int X6 = 0, int NBUF = 2>
 static int launch_gemm(const hold_gemm_desc& d, hipStream_t s) {
   constexpr int BNc = 64 * NT, BKc = (NT == 2) ? 32 : 16;
   const long mt = ((long)d.P + BM - 1) / BM;
@@ -747,7 +832,7 @@ static int launch_gemm(const hold_gemm_desc& d, hipStream_t s) {
 #endif
   switch (d.epilogue) {
 #define HOLD_CASE(E) \
-  case E: hipLaunchKernelGGL((gemm_nt_kernel<E, NT, X6>), grid, block, 0, s, d, tiles, stagger); break;
+  case E: hipLaunchKernelGGL((gemm_nt_kernel<E, NT, X6, NBUF>), grid, block, 0, s, d, tiles, stagger); break;
     HOLD_CASE(HOLD_EPI_NONE)
     HOLD_CASE(HOLD_EPI_SOFTPLUS)
     HOLD_CASE(HOLD_EPI_RELU)
@@ -773,13 +858,21 @@ static int gemm_nt_impl(const hold_gemm_desc* dp, hold_stream_t stream, int x6) 
   if ((d.epilogue == HOLD_EPI_MUL_DSP || d.epilogue == HOLD_EPI_MUL_DRELU || d.epilogue == HOLD_EPI_MUL_DSIG) && !d.aux1)
     return HOLD_E_ARG;
   if (d.epilogue == HOLD_EPI_DBWD && (!d.aux1 || !d.aux2 || !d.out2)) return HOLD_E_ARG;
+  if ((d.r1_row == nullptr) != (d.r1_col == nullptr)) return HOLD_E_ARG;
   if (d.P == 0) return HOLD_OK;
   hipStream_t s = (hipStream_t)stream;
   int wide = d.N > 128;
 #ifdef HOLD_DEV
   if (const char* w = getenv("HOLD_GEMM_TILE")) wide = atoi(w) == 256;
 #endif
-  if (x6) return wide ? launch_gemm<4, 2>(d, s) : launch_gemm<2, 2>(d, s);
+  if (x6) {
+    bool deep = false;  // three operand stages for the wide tile
+#ifdef HOLD_DEV
+    if (const char* nb = getenv("HOLD_GEMM_NBUF")) deep = atoi(nb) == 3;
+#endif
+    if (wide) return deep ? launch_gemm<4, 2, 3>(d, s) : launch_gemm<4, 2>(d, s);
+    return launch_gemm<2, 2>(d, s);
+  }
   return wide ? launch_gemm<4>(d, s) : launch_gemm<2>(d, s);
 }
 
@@ -813,8 +906,16 @@ static int wgrad_impl(const float* R, int32_t ldr, const float* X, int32_t ldx, 
     const int tiles = ((N + 127) / 128) * ((K + 255) / 256);
     const long ch = ((long)P + 15) / 16;
     if (splits > ch) splits = (int)(ch > 0 ? ch : 1);
-    hipLaunchKernelGGL((wgrad_lds_kernel<4, 2>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits,
-                       part, part_b);
+    bool deep = false;  // three operand stages
+#ifdef HOLD_DEV
+    if (const char* nb = getenv("HOLD_WGRAD_NBUF")) deep = atoi(nb) == 3;
+#endif
+    if (deep)
+      hipLaunchKernelGGL((wgrad_lds_kernel<4, 2, 3>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K,
+                         splits, part, part_b);
+    else
+      hipLaunchKernelGGL((wgrad_lds_kernel<4, 2>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits,
+                         part, part_b);
   } else if (lds_ok && mode != 0) {  // split-precision path (128 x 128 tiles)
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
     if (mode == 2)

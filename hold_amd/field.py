@@ -9,7 +9,8 @@ Nothing here computes on the CPU or with torch math beyond tiny per-layer weight
 Buffers (fp32, ray-major points p = ray*S + s):
   x      [P,4]   query points in deformed space          xc   [P,4]  canonical points
   in0    [P,K0]  embedding (+cond)                        h[l] [P,256] softplus outputs (h[3] = [h3|embed])
-  rin    [P,Kr]  render-net input [xc,n,pose8,feat256(,time32)]
+  rin    [P,Kr]  render-net input [feat256,xc,n,pose8(,time32)] -- the reference's column order with the feature block
+                 moved to the front (16-byte aligned for lin8's output / its cotangent); pack_weights permutes lin0
   t[l]   [P,256] reverse-sweep d sdf/d a_l               ge   [P,K0]  d sdf/d embed       g [P,4] d sdf/d xc
 """
 from __future__ import annotations
@@ -27,7 +28,14 @@ FEAT = 256
 FUSED_SDF = os.environ.get("HOLD_FUSED_SDF", "1") != "0"  # sampler queries through the fused LDS-resident kernel
 # training-path sweeps as LDS-resident layer chains (hold_chain) instead of one hold_gemm_nt per layer
 USE_CHAIN = os.environ.get("HOLD_CHAIN", "1") != "0"
-RIN_X, RIN_N, RIN_POSE, RIN_FEAT = 0, 3, 6, 14
+RIN_FEAT, RIN_X, RIN_N, RIN_POSE, RIN_TIME = 0, 256, 259, 262, 270
+
+
+def rin_perm(rin_dim, device=None):
+    """our rin column j holds the reference's rendering-net input column rin_perm[j]
+    (reference order: xc 0:3, normal 3:6, pose 6:14, feature 14:270, time 270:302; texture_net.py:60-83)"""
+    idx = list(range(14, 270)) + list(range(0, 14)) + list(range(270, rin_dim))
+    return torch.tensor(idx, dtype=torch.long, device=device)
 
 
 def pad4(n):
@@ -123,6 +131,7 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
         wt[:, :n] = W[l].t()
         WT.append(wt)
     pk["WT"] = WT
+    pk["WT8_feat"] = W[8][:256].t().contiguous()  # [k = 256 trunk units][n = 256 feature rows]: lin8's input gradient
     # fragment-ordered pack for the fused SDF-only kernel (hold_fused_sdf)
     parts = []
     for l in range(8):
@@ -155,7 +164,7 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
     if rw is None:  # implicit net only (ImplicitNet.forward / gradient)
         return pk
     r0 = torch.zeros(256, spec.Kr, device=dev)
-    r0[:, :spec.rin_dim] = rw[0]
+    r0[:, :spec.rin_dim] = rw[0][:, rin_perm(spec.rin_dim, dev)]
     R = [r0, rw[1].contiguous(), rw[2].contiguous(), rw[3].contiguous(), rw[4].contiguous()]
     pk["R"] = R
     pk["rb"] = [b.contiguous() for b in rb]
@@ -251,7 +260,7 @@ class NodeField:
 
     # ------------------------------------------------------------------ full forward
     def forward(self, pk, x, P, ppf, dfm, barf_w, pose_embed, time_code, training):
-        """-> dict(sdf [P,1], rgb [P,4], normal = rin[:,3:6], xc, feat = rin[:,14:270])."""
+        """-> dict(sdf [P,1], rgb [P,4], normal = rin[:, RIN_N:+3], xc, feat = rin[:, :256])."""
         sp, pool = self.spec, self.pool
         self.gen += 1
         xc, w_def = self._deform(x, P, ppf, dfm, want_w=training)
@@ -279,7 +288,7 @@ class NodeField:
         K.normal_fwd(g, w_c, dfm["tfs"], sp.n_bones, P, ppf, rin[:, RIN_N:RIN_N + 3])
         K.frame_bcast(pose_embed, P, ppf, rin, RIN_POSE)
         if sp.time:
-            K.frame_bcast(time_code, P, ppf, rin, RIN_FEAT + FEAT)
+            K.frame_bcast(time_code, P, ppf, rin, RIN_TIME)
         # ---- rendering net ----
         R, rb = pk["R"], pk["rb"]
         r = [pool.get(f"r{l}", P, 256) for l in range(4)]
@@ -438,7 +447,7 @@ class NodeField:
         K.embed_bwd2(xc, sp.L, P, sv["ge"], gb, gebar, xbar=None, barf_w=sv["barf_w"])
         a2, u7 = self._second_order_sweep(pk, h, t, gebar, dW, P)
         d_w8sdf = torch.zeros(256, device=dev)
-        K.colsum(u7, 256, P, d_w8sdf)
+        G.wcolsum(u7, d_w8sdf, N=256)
         # first-order sweep driven only by the second-order terms a2_l (out_bar = 0  =>  r_7 = a2_7)
         cur = self._first_order_sweep(pk, h, a2, a2[7], sv["in0"], dW, dWb, None, P)
         G.wgrad(cur, sv["in0"], dW[0], dWb[0], K=sp.K0, accumulate=True)
@@ -488,7 +497,7 @@ class NodeField:
         d_time = None
         if sp.time:
             d_time = torch.zeros(B, sp.time, device=dev)
-            K.frame_colsum(d_rin, RIN_FEAT + FEAT, sp.time, P, ppf, d_time)
+            K.frame_colsum(d_rin, RIN_TIME, sp.time, P, ppf, d_time)
         # ---------- normal ----------
         nbar = pool.get("nbar", P, 4)
         K.copy_cols(d_rin[:, RIN_N:RIN_N + 3], nbar, 3, P)
@@ -503,16 +512,20 @@ class NodeField:
         gebar = pool.get("gebar", P, sp.K0)
         K.embed_bwd2(xc, sp.L, P, sv["ge"], gbar, gebar, xbar=xbar, barf_w=sv["barf_w"])
         a2, u7 = self._second_order_sweep(pk, h, t, gebar, dW, P)
-        # ubar_7 -> gradient of the sdf row of W8
-        d_w8sdf = torch.zeros(256, device=dev)
-        K.colsum(u7, 256, P, d_w8sdf)
+        # gradient of the sdf row of W8: ubar_7 (second-order path) + the first-order term d_sdf^T h7, both as
+        # deterministic (weighted) column sums -- a 257th wgrad row would cost a whole 128-row tile
+        d_sdf = d_sdf.reshape(P)
+        G.wcolsum(u7, dW[8][256], N=256, accumulate=True)
+        G.wcolsum(h[7], dW[8][256], weights=d_sdf, N=256, accumulate=True)
+        dWb[8][256:257] += d_sdf.sum().reshape(1)
         # ---------- first-order backward sweep ----------
-        ob = pool.get("out_bar", P, 260)
-        K.copy_cols(d_rin[:, RIN_FEAT:RIN_FEAT + FEAT], ob, FEAT, P)
-        K.copy_cols(d_sdf.reshape(P, 1), ob[:, 256:257], 1, P)
-        G.wgrad(ob, h[7], dW[8], dWb[8], N=257, accumulate=True)
+        # cotangent of lin8's output = [d_rin's feature block | d_sdf]: the feature block is used in place (no copy),
+        # the sdf column enters the input-gradient GEMM as a rank-1 term d_sdf[p] * w8_sdf[n]
+        d_feat = d_rin[:, RIN_FEAT:RIN_FEAT + FEAT]
+        G.wgrad(d_feat, h[7], dW[8], dWb[8], N=256, accumulate=True)
         r7 = pool.get("r7", P, 256)
-        G.gemm_nt(ob, WT[8], r7, epi=G.EPI_MUL_DSP, aux1=h[7], aux2=a2[7], K=260)
+        G.gemm_nt(d_feat, pk["WT8_feat"], r7, epi=G.EPI_MUL_DSP, aux1=h[7], aux2=a2[7], K=256, r1_row=d_sdf,
+                  r1_col=pk["w8_sdf"])
         ebar = pool.get("ebar", P, sp.K0)
         cur = self._first_order_sweep(pk, h, a2, r7, sv["in0"], dW, dWb, ebar, P)
         G.wgrad(cur, sv["in0"], dW[0], dWb[0], K=sp.K0, accumulate=True)
@@ -528,8 +541,10 @@ class NodeField:
         g_iw += [dW[1], dW[2], dW[3]]
         g_iw.append(dW[4] / math.sqrt(2))
         g_iw += [dW[5], dW[6], dW[7]]
-        d8 = torch.cat([dW[8][256:257] + d_w8sdf[None], dW[8][:256]], 0)
+        d8 = torch.cat([dW[8][256:257], dW[8][:256]], 0)
         g_iw.append(d8)
         g_ib = dWb[:8] + [torch.cat([dWb[8][256:257], dWb[8][:256]])]
-        g_rw = [dR[0][:, :sp.rin_dim], dR[1], dR[2], dR[3], dR[4]]
+        g0 = torch.empty(256, sp.rin_dim, device=dev)
+        g0[:, rin_perm(sp.rin_dim, dev)] = dR[0][:, :sp.rin_dim]  # back to the reference's column order
+        g_rw = [g0, dR[1], dR[2], dR[3], dR[4]]
         return dict(iw=g_iw, ib=g_ib, rw=g_rw, rb=dRb, tfs=dtfs, pose_embed=d_pose, time_code=d_time)

@@ -37,7 +37,7 @@ def _ld(t):
 
 
 def gemm_nt(A, W, out, *, bias=None, epi=EPI_NONE, alpha=1.0, N=None, K=None, n_split=None, out_raw=None,
-            aux1=None, aux2=None, out2=None, accumulate=False):
+            aux1=None, aux2=None, out2=None, accumulate=False, r1_row=None, r1_col=None):
     """out[:, :N] = epi(alpha * A[:, :K] @ W[:N, :K].T + bias).  All tensors are 2-D fp32 CUDA views with unit
     inner stride; row strides (leading dimensions) are taken from the views, so callers can write
     straight into column slices of wider buffers."""
@@ -63,6 +63,9 @@ def gemm_nt(A, W, out, *, bias=None, epi=EPI_NONE, alpha=1.0, N=None, K=None, n_
     if out2 is not None:
         d.out2, d.ldout2 = ptr(out2), _ld(out2)
     d.accumulate = 1 if accumulate else 0
+    if r1_row is not None:  # y += r1_row[p] * r1_col[n] before the epilogue function
+        assert r1_row.numel() >= P and r1_col.numel() >= N
+        d.r1_row, d.ldr1, d.r1_col = ptr(r1_row), (r1_row.stride(0) if r1_row.dim() else 1), ptr(r1_col)
     e0 = _prof_begin()
     if config.x6():
         check(_lib.lib().hold_gemm_nt_x6(C.byref(d), stream_ptr()), "hold_gemm_nt_x6")
@@ -100,3 +103,14 @@ def wgrad(R, X, dW, db=None, *, N=None, K=None, accumulate=False, splits=None):
              splits, ptr(ws), stream_ptr()), "hold_wgrad")
     _prof_end(e0, 2.0 * P * N * K, "wgrad_kernel")
     return dW
+
+
+def wcolsum(X, out, *, weights=None, N=None, accumulate=False):
+    """out[:N] (+)= (weights[:, None] * X[:, :N]).sum(0) -- deterministic two-pass column sums (hold_wcolsum)."""
+    P = X.shape[0]
+    N = out.shape[0] if N is None else N
+    L = _lib.lib()
+    ws = _workspace(L.hold_wcolsum_workspace_floats(N), X.device)
+    check(L.hold_wcolsum(ptr(X), _ld(X), N, P, ptr(weights), ptr(out), 1 if accumulate else 0, ptr(ws), stream_ptr()),
+          "hold_wcolsum")
+    return out

@@ -67,6 +67,8 @@ typedef struct hold_gemm_desc {
   const float* aux2; int32_t ldaux2;
   float* out2;      int32_t ldout2;
   int32_t accumulate;               /* 1: C += result (HOLD_EPI_NONE / raw columns only) */
+  const float* r1_row; int32_t ldr1;/* optional rank-1 term added to y before the epilogue function:          */
+  const float* r1_col;              /*   y += r1_row[p * ldr1] * r1_col[n]   (both NULL to disable)           */
 } hold_gemm_desc;
 
 int hold_gemm_nt(const hold_gemm_desc* d, hold_stream_t stream);
@@ -164,6 +166,13 @@ int hold_seed_dsp(const float* h, int32_t ldh, const float* w, int32_t N, int64_
                   hold_stream_t stream);
 /* out[n] += sum_p X[p][n] */
 int hold_colsum(const float* X, int32_t ldx, int32_t N, int64_t P, float* out, hold_stream_t stream);
+/* weighted column sums, deterministic (two passes, fixed grid): out[n] (+)= sum_p w[p] * X[p][n]  (w NULL: plain sums).
+ * N % 4 == 0, N <= 1024, X 16-byte aligned rows; workspace >= hold_wcolsum_workspace_floats(N) floats.  The rank-1
+ * companion of hold_wgrad: the gradient of a single weight row whose cotangent is a [P] vector (the sdf row of lin8,
+ * code/src/networks/shape_net.py:118-130). */
+int64_t hold_wcolsum_workspace_floats(int32_t N);
+int hold_wcolsum(const float* X, int32_t ldx, int32_t N, int64_t P, const float* w, float* out, int32_t accumulate,
+                 float* workspace, hold_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * VolSDF error-bound sampler (hold_amd/csrc/sampler.hip) -- ErrorBoundSampler.get_z_vals,
