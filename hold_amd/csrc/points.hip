@@ -113,7 +113,7 @@ __global__ void embed_bwd2_kernel(const float* __restrict__ x, int ldx, int L, c
 
 // ---------------------------------------------------------------------------------------------
 // KNN(K=15) skinning weights (+ fused inverse LBS)      (mano/deformer.py:84-105, 145-170)
-// one thread per query point; the frame's 778 vertices (SoA) and the 778x16 skinning table sit in LDS.
+// one thread per query point; the frame's 778 vertices (SoA) sit in LDS.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void inv3(const float* A, float* Ai) {
   const float c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
@@ -143,13 +143,46 @@ __device__ __forceinline__ void blend_tf(const float* w, const float* T /*[nb][1
   }
 }
 
+// Squared distance with a FIXED operation order: the threshold pass, the filter pass and the selection pass below must
+// produce the same bits for the same (point, vertex) pair.
+__device__ __forceinline__ float knn_d2(float px, float py, float pz, float vx, float vy, float vz) {
+  const float dx = px - vx, dy = py - vy, dz = pz - vz;
+  return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
+}
+
+// insertion into the ascending (distance, index) list, strict '<' in visiting order: of equal distances the vertex
+// visited first (lower index) stays in front -- pytorch3d knn_points' order for the K smallest
+__device__ __forceinline__ void knn_insert(float (&bd)[KNN], int (&bi)[KNN], float dist, int i) {
+  bd[KNN - 1] = dist;
+  bi[KNN - 1] = i;
+#pragma unroll
+  for (int k = KNN - 1; k > 0; --k) {
+    const bool sw_ = bd[k] < bd[k - 1];
+    const float d0 = bd[k - 1], d1 = bd[k];
+    const int i0 = bi[k - 1], i1 = bi[k];
+    bd[k - 1] = sw_ ? d1 : d0;
+    bd[k] = sw_ ? d0 : d1;
+    bi[k - 1] = sw_ ? i1 : i0;
+    bi[k] = sw_ ? i0 : i1;
+  }
+}
+
+// K = 15 nearest vertices per point, three passes (one thread per point, the frame's vertices in LDS):
+//   1. threshold: the 15 smallest distances to every 4th vertex, kept by a branch-free min/max chain (no indices).  The
+//      15th of them, tau, is an upper bound of the 15th smallest distance to ALL vertices.
+//   2. filter: one bit per vertex, d <= tau (~8 % of the vertices pass), 32 vertices per mask word in LDS.
+//   3. selection: the insertion sort with indices over the set bits only, in index order -- the same result as
+//      running it over all vertices (every vertex of the true K set passes the filter, order and tie rule unchanged).
+// A lane-divergent insertion over all 778 vertices executes its ~70-instruction body for nearly every vertex (some lane
+// of the 64 always needs it); here it runs ~100 times per wave instead of ~750.
+constexpr int KNN_SUB = 4, KNN_WORDS = (MAXV + 31) / 32;
 __global__ __launch_bounds__(256) void knn_invlbs_kernel(const float* __restrict__ x, int ldx, long P, long ppf,
                                                         const float* __restrict__ verts, long vstride, int nv,
                                                         const float* __restrict__ skin, const float* __restrict__ tfs,
                                                         float* __restrict__ w_out, float* __restrict__ xc_out,
                                                         int ldxc) {
   __shared__ float sv[3][MAXV];
-  __shared__ __attribute__((aligned(16))) float sw[MAXV * NB];
+  __shared__ uint32_t smask[KNN_WORDS][256];
   __shared__ float st[NB * 16];
   const long blocks_per_frame = (ppf + 255) / 256;
   const long frame = blockIdx.x / blocks_per_frame;
@@ -160,7 +193,6 @@ __global__ __launch_bounds__(256) void knn_invlbs_kernel(const float* __restrict
     sv[1][i] = v[i * 3 + 1];
     sv[2][i] = v[i * 3 + 2];
   }
-  for (int i = threadIdx.x; i < nv * NB; i += 256) sw[i] = skin[i];
   if (tfs && threadIdx.x < NB * 16) st[threadIdx.x] = tfs[frame * NB * 16 + threadIdx.x];
   __syncthreads();
   if (off >= ppf) return;
@@ -170,26 +202,56 @@ __global__ __launch_bounds__(256) void knn_invlbs_kernel(const float* __restrict
 
   float bd[KNN];
   int bi[KNN];
+  // ---- pass 1: tau ----
+#pragma unroll
+  for (int k = 0; k < KNN; ++k) bd[k] = 3.0e38f;
+  for (int i = 0; i < nv; i += KNN_SUB) {
+    float d = knn_d2(px, py, pz, sv[0][i], sv[1][i], sv[2][i]);
+#pragma unroll
+    for (int k = 0; k < KNN; ++k) {
+      const float lo = fminf(bd[k], d);
+      d = fmaxf(bd[k], d);
+      bd[k] = lo;
+    }
+  }
+  const float tau = bd[KNN - 1];  // nv >= 4 * KNN is checked by the host entry: 15 subset vertices exist
+  // ---- pass 2: filter ----
+  const int nwords = (nv + 31) >> 5;
+  for (int w = 0; w < nwords; ++w) {
+    uint32_t m = 0;
+    const int i0 = w * 32;
+#pragma unroll 8
+    for (int b = 0; b < 32; ++b) {
+      const int i = i0 + b;
+      if (i < nv) {
+        const float d = knn_d2(px, py, pz, sv[0][i], sv[1][i], sv[2][i]);
+        m |= (d <= tau) ? (1u << b) : 0u;
+      }
+    }
+    smask[w][threadIdx.x] = m;
+  }
+  // ---- pass 3: selection over the set bits, each lane walking its own words ----
 #pragma unroll
   for (int k = 0; k < KNN; ++k) {
     bd[k] = 3.0e38f;
     bi[k] = 0;
   }
-  for (int i = 0; i < nv; ++i) {
-    const float dx = px - sv[0][i], dy = py - sv[1][i], dz = pz - sv[2][i];
-    const float dist = dx * dx + dy * dy + dz * dz;
-    if (dist < bd[KNN - 1]) {
-      bd[KNN - 1] = dist;
-      bi[KNN - 1] = i;
-#pragma unroll
-      for (int k = KNN - 1; k > 0; --k) {
-        const bool sw_ = bd[k] < bd[k - 1];
-        const float d0 = bd[k - 1], d1 = bd[k];
-        const int i0 = bi[k - 1], i1 = bi[k];
-        bd[k - 1] = sw_ ? d1 : d0;
-        bd[k] = sw_ ? d0 : d1;
-        bi[k - 1] = sw_ ? i1 : i0;
-        bi[k] = sw_ ? i0 : i1;
+  {
+    int w = -1;
+    uint32_t m = 0;
+    for (;;) {
+      if (m == 0 && w < nwords - 1) {
+        ++w;
+        m = smask[w][threadIdx.x];
+      }
+      const bool more = (m != 0) || (w < nwords - 1);
+      if (!__any(more)) break;
+      if (m != 0) {
+        const int b = __ffs(m) - 1;
+        m &= m - 1;
+        const int i = w * 32 + b;
+        const float dist = knn_d2(px, py, pz, sv[0][i], sv[1][i], sv[2][i]);
+        if (dist < bd[KNN - 1]) knn_insert(bd, bi, dist, i);
       }
     }
   }
@@ -206,7 +268,7 @@ __global__ __launch_bounds__(256) void knn_invlbs_kernel(const float* __restrict
 #pragma unroll
   for (int k = 0; k < KNN; ++k) {
     const float c = conf[k] / csum;
-    const float4* row = reinterpret_cast<const float4*>(sw + bi[k] * NB);
+    const float4* row = reinterpret_cast<const float4*>(skin + bi[k] * NB);  // 50 KB table, L1 / L2 resident
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float4 r = row[q];
@@ -558,7 +620,8 @@ extern "C" int hold_embed_bwd2(const float* x, int32_t ldx, int32_t L, const flo
 extern "C" int hold_knn_invlbs_fwd(const float* x, int32_t ldx, int64_t P, int64_t pts_per_frame, const float* verts,
                                    int64_t verts_frame_stride, int32_t n_verts, const float* skin_w, const float* tfs,
                                    float* w_out, float* xc_out, int32_t ldxc, hold_stream_t st) {
-  if (!x || !verts || !skin_w || n_verts < KNN || n_verts > MAXV || pts_per_frame <= 0) return HOLD_E_ARG;
+  if (!x || !verts || !skin_w || n_verts < KNN_SUB * KNN || n_verts > MAXV || pts_per_frame <= 0) return HOLD_E_ARG;
+  if ((uintptr_t)skin_w & 15) return HOLD_E_ARG;
   if (xc_out && !tfs) return HOLD_E_ARG;
   if (P == 0) return HOLD_OK;
   const long frames = (P + pts_per_frame - 1) / pts_per_frame;
