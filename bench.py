@@ -293,7 +293,8 @@ def main():
             "metric": metric, "value": total_rays / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("f32 (3-limb bf16 split, fp32 accumulate, on the sampler trunk + weight gradients; fp32 MFMA elsewhere)"
+            "dtype": ("f32x6 (fp32 results; every MFMA product = exact 3-limb bf16 split of both fp32 operands, 6 of 9 limb "
+                      "products on v_mfma_f32_32x32x16_bf16, fp32 accumulate; --fp32-mfma for true-fp32 operands)"
                       if x6 else "f32"),
             "data": "synthetic",
             "config": {"workload": workload, "chunk_rays": args.chunk if args.mode != "c3" else 1280,
@@ -311,9 +312,12 @@ def main():
                 a[2] += 1
             if args.shape_report:
                 json.dump(gemm_shapes(prof), open(args.shape_report, "w"), indent=1)
-            split = {"fused_sdf_kernel", "wgrad_kernel"} if x6 else set()
-            labels = {"gemm_nt_kernel": "gemm_nt_kernel (one layer per launch, v_mfma_f32_32x32x2_f32)",
-                      "chain_kernel": "chain_kernel (7-8 trunk layers per launch, LDS-resident, v_mfma_f32_32x32x2_f32)",
+            split = {"fused_sdf_kernel", "wgrad_kernel", "chain_kernel", "gemm_nt_kernel"} if x6 else set()
+            labels = {"gemm_nt_kernel": ("gemm_nt_kernel<x6> (one layer per launch, 3-limb split on v_mfma_f32_32x32x16_bf16)"
+                                         if x6 else "gemm_nt_kernel (one layer per launch, v_mfma_f32_32x32x2_f32)"),
+                      "chain_kernel": ("chain_x6_kernel (7-8 trunk layers per launch, LDS-resident, 3-limb split on "
+                                       "v_mfma_f32_32x32x16_bf16)" if x6 else
+                                       "chain_kernel (7-8 trunk layers per launch, LDS-resident, v_mfma_f32_32x32x2_f32)"),
                       "fused_sdf_kernel": ("fused_sdf_x6p_kernel (sampler SDF queries, 3-limb split on v_mfma_f32_32x32x16_bf16)"
                                            if x6 else "fused_sdf_pipe_kernel (sampler SDF queries, v_mfma_f32_32x32x2_f32)"),
                       "wgrad_kernel": ("wgrad_lds_kernel<x6> (weight gradients, 3-limb split on v_mfma_f32_32x32x16_bf16)"

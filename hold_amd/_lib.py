@@ -119,6 +119,8 @@ SIGNATURES = {
     "hold_seed_dsp": [_P, _I, _P, _I, _L, _P, _I, _P],
     "hold_colsum": [_P, _I, _I, _L, _P, _P],
     "hold_wcolsum": [_P, _I, _I, _L, _P, _P, _I, _P, _P],
+    "hold_head3_fwd": [_P, _I, _P, _I, _P, _I, _L, _P, _I, _I, _P],
+    "hold_head3_bwd": [_P, _I, _P, _I, _P, _I, _I, _L, _P, _I, _P, _I, _P, _I, _P, _P],
     "hold_sampler_init": [_P, _P, _L, _F, _F, _I, _F, _P, _P, _I, _P, _P, _P, _P],
     "hold_sampler_beta": [_P, _P, _I, _I, _L, _P, _P, _I, _P, _F, _F, _I, _P, _P],
     "hold_sampler_sample": [_P, _P, _I, _I, _L, _P, _I, _F, _P, _L, _I, _P, _P, _P],
@@ -161,6 +163,8 @@ def _declare(L):
     L.hold_chain_pack_floats.restype = C.c_int64
     L.hold_chain_x6_pack_bytes.argtypes = [C.c_int32, C.c_int32]
     L.hold_chain_x6_pack_bytes.restype = C.c_int64
+    L.hold_head3_workspace_floats.argtypes = [C.c_int32]
+    L.hold_head3_workspace_floats.restype = C.c_int64
     L.hold_wcolsum_workspace_floats.argtypes = [C.c_int32]
     L.hold_wcolsum_workspace_floats.restype = C.c_int64
     L.hold_silhouette_workspace_floats.argtypes = [C.c_int32, C.c_int32]

@@ -256,6 +256,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(hold_gemm_desc d, int t
     }
 
     const int rowa0 = wm * 64 + li, roww0 = wn * (32 * NT) + li;
+    // 32-wide output tiles of this wave that hold any column < N (wave-uniform): the products of the others are
+    // skipped (N = 40 / 48-column tail tiles would otherwise run 4 - 8x their useful MFMAs)
+    const int nbv_raw = (d.N - (n0 + wn * (32 * NT)) + 31) / 32;
+    const int nbv = nbv_raw < 0 ? 0 : (nbv_raw > NT ? NT : nbv_raw);
     for (int kt = 0; kt < nk; ++kt) {
       const int buf = kt % NBUF;
       if (kt + NBUF - 1 < nk && !(stagger & 256)) stage(m0, n0, kt + NBUF - 1, (kt + NBUF - 1) % NBUF);
@@ -279,6 +283,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(hold_gemm_desc d, int t
           // output tiles two at a time (4 accumulators in rotation, 12 + 24 limb registers live)
 #pragma unroll
           for (int bp = 0; bp < NT; bp += 2) {
+            if (bp >= nbv) break;
             Limbs3 lb[2];
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
@@ -616,6 +621,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restri
     const float* pr = sR + buf * PC * 128 + (hh * STEPS) * 128 + wn * 64 + li;
     const float* px = sX + buf * PC * BKW + (hh * STEPS) * BKW + wk * (32 * KT) + li;
     if constexpr (X6 != 0) {
+      const int kbv_raw = (K - (k0 + wk * (32 * KT)) + 31) / 32;
+      const int kbv = kbv_raw < 0 ? 0 : (kbv_raw > KT ? KT : kbv_raw);
       // split precision (hold_wgrad_x6): both operands are split into three bf16 limbs as they leave LDS, six limb
       // products per 16 reduction rows on v_mfma_f32_32x32x16_bf16.
       // Lane (hh, li) supplies rows 16 step + 8 hh .. + 7 of column li of its n / k tile to both operands.
@@ -632,9 +639,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restri
           bsum[a] += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
           la[a] = (X6 == 2) ? split8s_trunc(x) : split8s(x);
         }
-        // k tiles two at a time: 4 accumulators in rotation, 24 + 24 limb registers live
+        // k tiles two at a time: 4 accumulators in rotation, 24 + 24 limb registers live; tiles entirely beyond K
+        // (wave-uniform) are skipped -- the K = 40 embedding layers would otherwise run 3x their useful MFMAs
 #pragma unroll
         for (int bp = 0; bp < KT; bp += 2) {
+          if (bp >= kbv) break;
           Limbs3 lb[2];
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
@@ -776,6 +785,100 @@ __global__ __launch_bounds__(256) void wcolsum_kernel(const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The 3-output colour head (last Linear + sigmoid of the rendering nets, code/src/networks/texture_net.py:95-101):
+// HBM-streaming kernels instead of GEMM tiles that would be 3 / 128 full.
+// ---------------------------------------------------------------------------------------------
+// out[p][c] = act(sum_k A[p][k] W[c][k] + b[c]), c < 3.  16 lanes per row (4 rows per wave): lane l reads the 16-byte
+// chunks l, l + 16, ... of the row, so 16 lanes cover 256 contiguous bytes per load.
+__global__ __launch_bounds__(256) void head3_fwd_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W,
+                                                       int ldw, const float* __restrict__ bias, int K, long P,
+                                                       float* __restrict__ out, int ldo, int sigmoid) {
+  const int l = threadIdx.x & 15;
+  const long p = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  if (p < P) {
+    for (int k = l * 4; k < K; k += 64) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(A + p * lda + k);
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(W + k);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(W + ldw + k);
+      const f32x4 w2 = *reinterpret_cast<const f32x4*>(W + 2 * ldw + k);
+      a0 += (a[0] * w0[0] + a[1] * w0[1]) + (a[2] * w0[2] + a[3] * w0[3]);
+      a1 += (a[0] * w1[0] + a[1] * w1[1]) + (a[2] * w1[2] + a[3] * w1[3]);
+      a2 += (a[0] * w2[0] + a[1] * w2[1]) + (a[2] * w2[2] + a[3] * w2[3]);
+    }
+  }
+#pragma unroll
+  for (int d = 8; d > 0; d >>= 1) {
+    a0 += __shfl_xor(a0, d);
+    a1 += __shfl_xor(a1, d);
+    a2 += __shfl_xor(a2, d);
+  }
+  if (p < P && l < 3) {
+    float y = (l == 0 ? a0 : (l == 1 ? a1 : a2)) + (bias ? bias[l] : 0.f);
+    if (sigmoid) y = 1.0f / (1.0f + __expf(-y));
+    out[p * ldo + l] = y;
+  }
+}
+
+// backward of the head given dy[p][c] = cotangent of the pre-activation (3 columns):
+//   rr[p][k]  = (R[p][k] > 0) ? sum_c dy[p][c] W[c][k] : 0      (input gradient through the ReLU that produced R)
+//   part[blk][c][k] = sum over the block's rows of dy[p][c] R[p][k];  part_b[blk][c] = sum dy[p][c]
+// one pass over R; the partials are reduced deterministically by wgrad_reduce4_kernel.
+__global__ __launch_bounds__(256) void head3_bwd_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ R,
+                                                       int ldr, const float* __restrict__ W, int ldw, int K, long P,
+                                                       long rows_per_block, float* __restrict__ rr, int ldrr,
+                                                       float* __restrict__ part, float* __restrict__ part_b) {
+  __shared__ f32x4 red[4][3][64];
+  __shared__ float redb[4][4];
+  const int cg = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(P, r0 + rows_per_block);
+  for (int c0 = 0; c0 < K; c0 += 256) {
+    const int c = c0 + cg * 4;
+    const bool on = c < K;
+    f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0, w2 = w0, acc0 = w0, acc1 = w0, acc2 = w0;
+    float sb0 = 0.f, sb1 = 0.f, sb2 = 0.f;
+    if (on) {
+      w0 = *reinterpret_cast<const f32x4*>(W + c);
+      w1 = *reinterpret_cast<const f32x4*>(W + ldw + c);
+      w2 = *reinterpret_cast<const f32x4*>(W + 2 * ldw + c);
+    }
+    for (long r = r0 + ph; r < r1; r += 4) {
+      const float d0 = dy[r * ldy], d1 = dy[r * ldy + 1], d2 = dy[r * ldy + 2];
+      sb0 += d0;
+      sb1 += d1;
+      sb2 += d2;
+      if (on) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(R + r * ldr + c);
+        acc0 += x * d0;
+        acc1 += x * d1;
+        acc2 += x * d2;
+        f32x4 g = w0 * d0 + w1 * d1 + w2 * d2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = x[j] > 0.f ? g[j] : 0.f;
+        *reinterpret_cast<f32x4*>(rr + r * ldrr + c) = g;
+      }
+    }
+    red[ph][0][cg] = acc0;
+    red[ph][1][cg] = acc1;
+    red[ph][2][cg] = acc2;
+    if (c0 == 0 && cg == 0) {
+      redb[ph][0] = sb0;
+      redb[ph][1] = sb1;
+      redb[ph][2] = sb2;
+      redb[ph][3] = 0.f;
+    }
+    __syncthreads();
+    if (ph < 3 && on)
+      *reinterpret_cast<f32x4*>(part + ((long)blockIdx.x * 3 + ph) * K + c) =
+          (red[0][ph][cg] + red[1][ph][cg]) + (red[2][ph][cg] + red[3][ph][cg]);
+    if (c0 == 0 && threadIdx.x < 4)
+      part_b[(long)blockIdx.x * 4 + threadIdx.x] =
+          (redb[0][threadIdx.x] + redb[1][threadIdx.x]) + (redb[2][threadIdx.x] + redb[3][threadIdx.x]);
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" int hold_abi_version(void) { return 1; }
@@ -866,12 +969,11 @@ static int gemm_nt_impl(const hold_gemm_desc* dp, hold_stream_t stream, int x6) 
   if (const char* w = getenv("HOLD_GEMM_TILE")) wide = atoi(w) == 256;
 #endif
   if (x6) {
-    bool deep = false;  // three operand stages for the wide tile
-#ifdef HOLD_DEV
-    if (const char* nb = getenv("HOLD_GEMM_NBUF")) deep = atoi(nb) == 3;
+#ifdef HOLD_DEV  // three operand stages: measured equal to two (134 vs 133 TF-eq), kept as a developer-build A/B only
+    if (const char* nb = getenv("HOLD_GEMM_NBUF"))
+      if (wide && atoi(nb) == 3) return launch_gemm<4, 2, 3>(d, s);
 #endif
-    if (wide) return deep ? launch_gemm<4, 2, 3>(d, s) : launch_gemm<4, 2>(d, s);
-    return launch_gemm<2, 2>(d, s);
+    return wide ? launch_gemm<4, 2>(d, s) : launch_gemm<2, 2>(d, s);
   }
   return wide ? launch_gemm<4>(d, s) : launch_gemm<2>(d, s);
 }
@@ -906,14 +1008,14 @@ static int wgrad_impl(const float* R, int32_t ldr, const float* X, int32_t ldx, 
     const int tiles = ((N + 127) / 128) * ((K + 255) / 256);
     const long ch = ((long)P + 15) / 16;
     if (splits > ch) splits = (int)(ch > 0 ? ch : 1);
-    bool deep = false;  // three operand stages
-#ifdef HOLD_DEV
+    bool deep = false;
+#ifdef HOLD_DEV  // three operand stages: measured slower than two (150 vs 154 TF-eq), developer-build A/B only
     if (const char* nb = getenv("HOLD_WGRAD_NBUF")) deep = atoi(nb) == 3;
-#endif
     if (deep)
       hipLaunchKernelGGL((wgrad_lds_kernel<4, 2, 3>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K,
                          splits, part, part_b);
-    else
+#endif
+    if (!deep)
       hipLaunchKernelGGL((wgrad_lds_kernel<4, 2>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits,
                          part, part_b);
   } else if (lds_ok && mode != 0) {  // split-precision path (128 x 128 tiles)
@@ -946,9 +1048,14 @@ static int wgrad_impl(const float* R, int32_t ldr, const float* X, int32_t ldx, 
   else
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((NK + 255) / 256)), dim3(256), 0, s, part, splits, NK, K, dW,
                        lddw, accumulate);
-  if (db)
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, part_b, splits,
-                       (long)N, N, db, N, accumulate);
+  if (db) {
+    if (!(N & 3) && !((uintptr_t)db & 15) && !((uintptr_t)part_b & 15))
+      hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((N / 4 + 15) / 16)), dim3(256), 0, s, part_b, splits,
+                         (long)N, N, db, N, accumulate);
+    else
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, part_b, splits,
+                         (long)N, N, db, N, accumulate);
+  }
   return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
 }
 
@@ -966,4 +1073,50 @@ extern "C" int hold_wgrad_x6(const float* R, int32_t ldr, const float* X, int32_
   if (const char* sp = getenv("HOLD_X6_SPLIT")) mode = sp[0] == 'r' ? 1 : 2;
 #endif
   return wgrad_impl(R, ldr, X, ldx, P, N, K, dW, lddw, db, accumulate, splits, workspace, stream, mode);
+}
+
+
+constexpr int HEAD3_BLOCKS = 2048;
+extern "C" int64_t hold_head3_workspace_floats(int32_t K) { return (int64_t)HEAD3_BLOCKS * (3 * (int64_t)K + 4); }
+
+extern "C" int hold_head3_fwd(const float* A, int32_t lda, const float* W, int32_t ldw, const float* bias, int32_t K,
+                              int64_t P, float* out, int32_t ldo, int32_t sigmoid, hold_stream_t stream) {
+  if (!A || !W || !out || K <= 0 || (K & 3) || (lda & 3) || (ldw & 3) || ldo < 3 || P < 0) return HOLD_E_ARG;
+  if (((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return HOLD_E_ARG;
+  if (P == 0) return HOLD_OK;
+  hipLaunchKernelGGL(head3_fwd_kernel, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, (hipStream_t)stream, A, lda, W, ldw,
+                     bias, K, (long)P, out, ldo, sigmoid);
+  return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+}
+
+extern "C" int hold_head3_bwd(const float* dy, int32_t ldy, const float* R, int32_t ldr, const float* W, int32_t ldw,
+                              int32_t K, int64_t P, float* rr, int32_t ldrr, float* dW, int32_t lddw, float* db4,
+                              int32_t accumulate, float* workspace, hold_stream_t stream) {
+  if (!dy || !R || !W || !rr || !dW || !db4 || !workspace || K <= 0 || (K & 3) || ldy < 3 || P < 0) return HOLD_E_ARG;
+  if ((ldr & 3) || (ldw & 3) || (ldrr & 3) || (lddw & 3)) return HOLD_E_ARG;
+  if (((uintptr_t)R & 15) || ((uintptr_t)W & 15) || ((uintptr_t)rr & 15) || ((uintptr_t)dW & 15) || ((uintptr_t)db4 & 15) ||
+      ((uintptr_t)workspace & 15))
+    return HOLD_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (P == 0) {
+    if (!accumulate) {
+      for (int c = 0; c < 3; ++c)
+        if (hipMemsetAsync(dW + (long)c * lddw, 0, sizeof(float) * K, s) != hipSuccess) return HOLD_E_LAUNCH;
+      if (hipMemsetAsync(db4, 0, sizeof(float) * 4, s) != hipSuccess) return HOLD_E_LAUNCH;
+    }
+    return HOLD_OK;
+  }
+  long blocks = (P + 15) / 16;
+  if (blocks > HEAD3_BLOCKS) blocks = HEAD3_BLOCKS;
+  const long rpb = (P + blocks - 1) / blocks;
+  blocks = (P + rpb - 1) / rpb;
+  float* part = workspace;
+  float* part_b = workspace + (long)HEAD3_BLOCKS * 3 * K;
+  hipLaunchKernelGGL(head3_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dy, ldy, R, ldr, W, ldw, K, (long)P, rpb,
+                     rr, ldrr, part, part_b);
+  const long NK = 3L * K;
+  hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((NK / 4 + 15) / 16)), dim3(256), 0, s, part, (int)blocks, NK, K,
+                     dW, lddw, accumulate);
+  hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(1), dim3(256), 0, s, part_b, (int)blocks, 4L, 4, db4, 4, accumulate);
+  return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
 }

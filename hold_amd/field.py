@@ -297,7 +297,7 @@ class NodeField:
         G.gemm_nt(r[1], R[2], r[2], bias=rb[2], epi=G.EPI_RELU)
         G.gemm_nt(r[2], R[3], r[3], bias=rb[3], epi=G.EPI_RELU)
         rgb = pool.get("rgb", P, 4)
-        G.gemm_nt(r[3], R[4], rgb, bias=rb[4], epi=G.EPI_SIGMOID, N=3)
+        G.head3_fwd(r[3], R[4], rb[4], rgb)  # 3-output head: a streaming kernel, not a 3/256-full GEMM tile
         self.saved = dict(P=P, ppf=ppf, xc=xc, w_def=w_def, w_c=w_c, in0=in0, h=h, t=t, ge=ge, g=g, rin=rin, r=r,
                           rgb=rgb, sdf=sdf, dfm=dfm, barf_w=barf_w, pk=pk)
         return dict(sdf=sdf, rgb=rgb, normal=rin[:, RIN_N:RIN_N + 3], xc=xc, feat=rin[:, RIN_FEAT:RIN_FEAT + FEAT],
@@ -479,9 +479,10 @@ class NodeField:
         dy = pool.get("dy4", P, 4)
         sg = rgb[:, :3]
         dy[:, :3] = d_rgb * sg * (1.0 - sg)  # sigmoid'  (3 columns, elementwise)
-        G.wgrad(dy, r[3], dR[4], dRb[4], N=3, K=256)
         rr = [pool.get(f"rr{i}", P, 256) for i in range(2)]
-        G.gemm_nt(dy, RT[4], rr[1], epi=G.EPI_MUL_DRELU, aux1=r[3], K=4)
+        db4 = torch.zeros(4, device=dev)
+        G.head3_bwd(dy, r[3], R[4], rr[1], dR[4], db4)  # input gradient + weight / bias gradients in one pass over r3
+        dRb[4] = db4[:3]
         cur = rr[1]
         for l in (3, 2, 1):
             G.wgrad(cur, r[l - 1], dR[l], dRb[l])

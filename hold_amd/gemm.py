@@ -114,3 +114,24 @@ def wcolsum(X, out, *, weights=None, N=None, accumulate=False):
     check(L.hold_wcolsum(ptr(X), _ld(X), N, P, ptr(weights), ptr(out), 1 if accumulate else 0, ptr(ws), stream_ptr()),
           "hold_wcolsum")
     return out
+
+
+def head3_fwd(A, W, bias, out, *, K=None, sigmoid=True):
+    """out[:, :3] = act(A[:, :K] @ W[:3, :K].T + bias) -- the colour head as a streaming kernel (hold_head3_fwd)."""
+    P = A.shape[0]
+    K = W.shape[1] if K is None else K
+    check(_lib.lib().hold_head3_fwd(ptr(A), _ld(A), ptr(W), _ld(W), ptr(bias), K, P, ptr(out), _ld(out),
+                                    1 if sigmoid else 0, stream_ptr()), "hold_head3_fwd")
+    return out
+
+
+def head3_bwd(dy, R, W, rr, dW, db4, *, K=None, accumulate=False):
+    """one pass over R: rr = (R > 0) * (dy[:, :3] @ W[:3, :K]); dW[:3, :K] (+)= dy[:, :3].T @ R; db4[:3] (+)= dy.sum(0)."""
+    P = R.shape[0]
+    K = W.shape[1] if K is None else K
+    assert db4.numel() >= 4
+    L = _lib.lib()
+    ws = _workspace(L.hold_head3_workspace_floats(K), R.device)
+    check(L.hold_head3_bwd(ptr(dy), _ld(dy), ptr(R), _ld(R), ptr(W), _ld(W), K, P, ptr(rr), _ld(rr), ptr(dW), _ld(dW),
+                           ptr(db4), 1 if accumulate else 0, ptr(ws), stream_ptr()), "hold_head3_bwd")
+    return rr

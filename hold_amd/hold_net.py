@@ -748,7 +748,7 @@ class Background(nn.Module):
         r0 = pool.get("r0", P, 128)
         G.gemm_nt(rin, R0, r0, bias=rb[0].contiguous(), epi=G.EPI_RELU, K=self.Kr)
         rgb = pool.get("rgb", P, 4)
-        G.gemm_nt(r0, R1, rgb, bias=rb[1].contiguous(), epi=G.EPI_SIGMOID, N=3)
+        G.head3_fwd(r0, R1, rb[1].contiguous(), rgb, K=128)
         out = torch.empty(N, 3, device=dev)
         K.bg_composite_fwd(zf, sdf, rgb, S, N, out)
         self.saved = dict(P=P, N=N, S=S, ppf=ppf, zf=zf, in0=in0, h=h, rin=rin, sdf=sdf, r0=r0, rgb=rgb, W=W, R0=R0,
@@ -766,12 +766,10 @@ class Background(nn.Module):
         dy = pool.get("dy", P, 4)
         sg = sv["rgb"][:, :3]
         dy[:, :3] = d_rgb * sg * (1 - sg)
-        dR1, dR1b = torch.zeros(3, 128, device=dev), torch.zeros(3, device=dev)
-        G.wgrad(dy, sv["r0"], dR1, dR1b, N=3, K=128)
-        RT1 = torch.zeros(128, 4, device=dev)
-        RT1[:, :3] = sv["R1"].t()
+        dR1, db4 = torch.zeros(3, 128, device=dev), torch.zeros(4, device=dev)
         rr0 = pool.get("rr0", P, 128)
-        G.gemm_nt(dy, RT1, rr0, epi=G.EPI_MUL_DRELU, aux1=sv["r0"], K=4)
+        G.head3_bwd(dy, sv["r0"], sv["R1"], rr0, dR1, db4, K=128)
+        dR1b = db4[:3]
         dR0, dR0b = torch.zeros(128, self.Kr, device=dev), torch.zeros(128, device=dev)
         G.wgrad(rr0, rin, dR0, dR0b, K=self.Kr)
         d_rin = pool.get("d_rin", P, self.Kr)

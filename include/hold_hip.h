@@ -171,6 +171,19 @@ int hold_colsum(const float* X, int32_t ldx, int32_t N, int64_t P, float* out, h
  * companion of hold_wgrad: the gradient of a single weight row whose cotangent is a [P] vector (the sdf row of lin8,
  * code/src/networks/shape_net.py:118-130). */
 int64_t hold_wcolsum_workspace_floats(int32_t N);
+/* The 3-output colour head of the rendering nets (last Linear + sigmoid, code/src/networks/texture_net.py:95-101;
+ * background: code/src/model/renderables/background.py:62-70) as HBM-streaming kernels:
+ *   fwd: out[p][c] = act(sum_k A[p][k] W[c][k] + bias[c]), c < 3 (act = sigmoid if `sigmoid`, else identity)
+ *   bwd: given dy[p][c] (cotangent of the pre-activation), in ONE pass over R (= the ReLU output that fed the head):
+ *        rr[p][k] = (R[p][k] > 0) ? sum_c dy[p][c] W[c][k] : 0,  dW[c][k] (+)= sum_p dy[p][c] R[p][k],
+ *        db4[c] (+)= sum_p dy[p][c]  (db4 has room for 4 floats; element 3 is written as 0 / left unchanged)
+ * K % 4 == 0, 16-byte aligned rows; workspace >= hold_head3_workspace_floats(K); deterministic reductions. */
+int64_t hold_head3_workspace_floats(int32_t K);
+int hold_head3_fwd(const float* A, int32_t lda, const float* W, int32_t ldw, const float* bias, int32_t K, int64_t P,
+                   float* out, int32_t ldo, int32_t sigmoid, hold_stream_t stream);
+int hold_head3_bwd(const float* dy, int32_t ldy, const float* R, int32_t ldr, const float* W, int32_t ldw, int32_t K,
+                   int64_t P, float* rr, int32_t ldrr, float* dW, int32_t lddw, float* db4, int32_t accumulate,
+                   float* workspace, hold_stream_t stream);
 int hold_wcolsum(const float* X, int32_t ldx, int32_t N, int64_t P, const float* w, float* out, int32_t accumulate,
                  float* workspace, hold_stream_t stream);
 

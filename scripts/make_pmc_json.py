@@ -1,0 +1,39 @@
+"""profiles/r02_pmc_traffic.json from the two --pmc passes of scripts/prof_r02.sh (gpurun_out/prof_r02/{FETCH,WRITE}_SIZE.json).
+Unit / correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB; on gfx950 FETCH_SIZE
+reports half of wide coalesced reads, so read bytes = 2 * FETCH_SIZE * 1024."""
+import json, os, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "prof_r02")
+F = json.load(open(os.path.join(src, "FETCH_SIZE.json")))
+W = json.load(open(os.path.join(src, "WRITE_SIZE.json")))
+groups = {"fused_sdf_kernel": ["fused_sdf_x6p_kernel", "fused_sdf_pipe_kernel", "fused_sdf_kernel"],
+          "chain_kernel": ["chain_x6_kernel", "chain_kernel"],
+          "gemm_nt_kernel": ["gemm_nt_kernel"],
+          "wgrad_kernel": ["wgrad_lds_kernel", "wgrad_kernel"]}
+notes = {
+    "fused_sdf_kernel": "sampler queries: 16 B in (xc row) + 4 B out per point; the 2.8 MiB limb pack stays in L2",
+    "chain_kernel": "average over the four sweeps of one node-chunk (P = 1.61 M points): per point and layer SOFTPLUS writes 1 KiB, "
+                    "DSP reads 1 + writes 1, DSP+a2 reads 2 + writes 1, DBWD reads 2 + writes 2 KiB -> (5 reads + 5 writes) KiB "
+                    "x 7-8 layers / 4 launches ~ 15.7 GB read + 15.2 GB written per launch",
+    "gemm_nt_kernel": "per-layer GEMMs (rendering net fwd+bwd, lin8 features, d/d embedding, background): (K + N) * 4 B per "
+                      "point (+ N * 4 B per aux operand of the MUL_DSP / DRELU epilogues)",
+    "wgrad_kernel": "dW[N,K] = R^T X over P = 1.61 M points: (N + K) * 4 B per point = 2 KiB (3.3 GB) for the 256x256 layers; "
+                    "split-K partials (<= 256 x 256 KiB) are written here and reduced by wgrad_reduce4_kernel"}
+out = {"command": "rocprofv3 --kernel-trace --pmc <C> -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile "
+                  "(one pass per counter; scripts/prof_r02.sh), chunk 16384 rays, default precision (f32x6)",
+       "correction": "gfx950 FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md HBM section): read bytes = "
+                     "2*FETCH_SIZE*1024; WRITE_SIZE taken as KiB", "kernels": {}}
+for g, names in groups.items():
+    nf = sum(F[n]["launches"] for n in names if n in F)
+    sf = sum(F[n]["sum"] for n in names if n in F)
+    nw = sum(W[n]["launches"] for n in names if n in W)
+    sw = sum(W[n]["sum"] for n in names if n in W)
+    if not nf or not nw:
+        continue
+    out["kernels"][g] = {"pmc_kernel_names": [n for n in names if n in F], "launches_in_pass": nf,
+                         "FETCH_SIZE_KB_avg_per_launch": sf / nf, "WRITE_SIZE_KB_avg_per_launch": sw / nw,
+                         "hbm_read_bytes_per_launch": 2 * 1024 * sf / nf, "hbm_write_bytes_per_launch": 1024 * sw / nw,
+                         "hbm_bytes_per_launch": 2 * 1024 * sf / nf + 1024 * sw / nw, "algorithmic_note": notes[g]}
+dst = os.path.join(root, "profiles", "r02_pmc_traffic.json")
+json.dump(out, open(dst, "w"), indent=1)
+print("wrote", dst, {k: round(v["hbm_bytes_per_launch"] / 1e9, 3) for k, v in out["kernels"].items()}, "GB/launch")

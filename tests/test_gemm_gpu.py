@@ -187,3 +187,68 @@ def test_wgrad_matches_fp64_in_both_precisions(P, N, K, mode):
         hold_amd.set_precision(prev)
     assert float((dW.double() - ref).abs().max()) < 3e-5 * max(1.0, float(ref.abs().max()))
     assert float((db.double() - refb).abs().max()) < 3e-5 * max(1.0, float(refb.abs().max()))
+
+
+def test_rank1_epilogue_term_and_weighted_colsum(arith):
+    """y += r1_row[p] * r1_col[n] before the epilogue function (lin8's sdf column in the input-gradient GEMM), and the
+    deterministic weighted column sums that give the sdf row's weight gradient"""
+    from hold_amd import gemm
+    dev = _dev()
+    torch.manual_seed(3)
+    P, N, K = 3001, 256, 256
+    A = torch.randn(P, K + 16, device=dev)[:, :K]  # a strided view (lda = K + 16) like d_rin's feature block
+    W = torch.randn(N, K, device=dev) / 16
+    H = torch.nn.functional.softplus(torch.randn(P, N, device=dev) * 0.05, beta=100)
+    add = torch.randn(P, N, device=dev)
+    row, col = torch.randn(P, device=dev), torch.randn(N, device=dev)
+    out = torch.empty(P, N, device=dev)
+    gemm.gemm_nt(A, W, out, epi=gemm.EPI_MUL_DSP, aux1=H, aux2=add, r1_row=row, r1_col=col)
+    y = A.double() @ W.double().t() + row.double()[:, None] * col.double()[None]
+    ref = y * (-torch.expm1(-100 * H.double())) + add.double()
+    assert (out.double() - ref).abs().max().item() < 3e-5
+    out2 = torch.empty(P, N, device=dev)
+    gemm.gemm_nt(A, W, out2, r1_row=row, r1_col=col)
+    assert (out2.double() - y).abs().max().item() < 3e-5
+    for PP in (P, 70001, 5):
+        X = torch.randn(PP, 256, device=dev)
+        w = torch.randn(PP, device=dev)
+        o = torch.full((256,), 2.0, device=dev)
+        gemm.wcolsum(X, o, weights=w, accumulate=True)
+        r = (X.double() * w.double()[:, None]).sum(0) + 2
+        assert (o.double() - r).abs().max().item() < 1e-4 * max(1.0, r.abs().max().item())
+        o2 = torch.empty(256, device=dev)
+        gemm.wcolsum(X, o2)
+        o3 = torch.empty(256, device=dev)
+        gemm.wcolsum(X, o3)
+        assert torch.equal(o2, o3)  # deterministic
+        assert (o2.double() - X.double().sum(0)).abs().max().item() < 1e-4 * PP ** 0.5
+
+
+@pytest.mark.parametrize("P,K", [(4099, 256), (1000, 128), (70000, 256), (3, 256)])
+def test_colour_head_kernels(P, K):
+    """hold_head3_fwd / hold_head3_bwd against torch fp64 of the same op (Linear(K, 3) + sigmoid after a ReLU layer)"""
+    from hold_amd import gemm
+    dev = _dev()
+    g = torch.Generator().manual_seed(P + K)
+    R = torch.relu(torch.randn(P, K, generator=g)).to(dev)
+    W = (torch.randn(3, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(3, generator=g).to(dev)
+    out = torch.full((P, 4), -7.0, device=dev)
+    gemm.head3_fwd(R, W, b, out, K=K)
+    ref = torch.sigmoid(R.double() @ W.double().t() + b.double())
+    assert (out[:, :3].double() - ref).abs().max().item() < 2e-6
+    assert torch.all(out[:, 3] == -7.0)
+    dy = torch.zeros(P, 4, device=dev)
+    dy[:, :3] = torch.randn(P, 3, generator=g).to(dev)
+    rr = torch.empty(P, K, device=dev)
+    dW = torch.ones(3, K, device=dev)
+    db4 = torch.ones(4, device=dev)
+    gemm.head3_bwd(dy, R, W, rr, dW, db4, K=K, accumulate=True)
+    d3 = dy[:, :3].double()
+    assert (rr.double() - (d3 @ W.double()) * (R > 0)).abs().max().item() < 1e-5
+    rW = d3.t() @ R.double() + 1
+    assert (dW.double() - rW).abs().max().item() < 2e-5 * max(1.0, rW.abs().max().item())
+    assert (db4[:3].double() - (d3.sum(0) + 1)).abs().max().item() < 1e-4 * max(1.0, P ** 0.5)
+    dW2, db42 = torch.empty(3, K, device=dev), torch.empty(4, device=dev)
+    gemm.head3_bwd(dy, R, W, rr, dW2, db42, K=K)
+    assert (dW2.double() - (rW - 1)).abs().max().item() < 2e-5 * max(1.0, rW.abs().max().item())

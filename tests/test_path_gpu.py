@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+from hold_amd import field as F
 from parity_common import hip_input, hip_net, ho, oracle_input, rel_err, setup
 
 pytestmark = pytest.mark.gpu
@@ -36,7 +37,7 @@ def test_eval_forward_matches_oracle_given_z(ctx):
         assert rel_err(fac[n]["canonical_pts"], ex[n]["x_c"]) < 1e-5
         assert rel_err(fac[n]["sdf"].view(-1, 1), ex[n]["sdf"]) < 1e-4
         assert rel_err(net.nodes[n].field.saved["g"][:, :3], ex[n]["grad"]) < 1e-4
-        assert rel_err(net.nodes[n].field.saved["rin"][:, 14:270], ex[n]["feat"]) < 1e-4
+        assert rel_err(net.nodes[n].field.saved["rin"][:, F.RIN_FEAT:F.RIN_FEAT + 256], ex[n]["feat"]) < 1e-4
 
 
 def test_eval_forward_matches_reference_golden(ctx, gold_dir):
