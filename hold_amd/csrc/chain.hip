@@ -286,24 +286,24 @@ constexpr int X6_UNITS = 3 * 512;  // 16-byte units per 16-wide k step
 
 struct Limbs3 { bf16x8 l[3]; };
 
+// Two values at a time: the compiler selects v_pk_add_f32 for the two remainders, so 8 values cost 16 v_and + 8 v_pk_add
+// + 12 v_perm = 36 VALU issue slots (44 with scalar subtractions) -- this split is what bounds the kernel.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ Limbs3 split8_trunc(const f32x4& x0, const f32x4& x1) {
-  uint32_t h1[8], h2[8], h3[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float x = e < 4 ? x0[e] : x1[e - 4];
-    h1[e] = __builtin_bit_cast(uint32_t, x) & 0xffff0000u;
-    const float r1 = x - __builtin_bit_cast(float, h1[e]);
-    h2[e] = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
-    h3[e] = __builtin_bit_cast(uint32_t, r1 - __builtin_bit_cast(float, h2[e]));
-  }
-  Limbs3 o;
   u32x4 p1, p2, p3;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {  // dword j = bf16 elements 2j (low half) and 2j + 1 (high half)
-    p1[j] = __builtin_amdgcn_perm(h1[2 * j + 1], h1[2 * j], 0x07060302u);
-    p2[j] = __builtin_amdgcn_perm(h2[2 * j + 1], h2[2 * j], 0x07060302u);
-    p3[j] = __builtin_amdgcn_perm(h3[2 * j + 1], h3[2 * j], 0x07060302u);
+    const f32x2 x = j < 2 ? f32x2{x0[2 * j], x0[2 * j + 1]} : f32x2{x1[2 * j - 4], x1[2 * j - 3]};
+    const u32x2 xb = __builtin_bit_cast(u32x2, x);
+    const f32x2 r1 = x - __builtin_bit_cast(f32x2, xb & 0xffff0000u);
+    const u32x2 r1b = __builtin_bit_cast(u32x2, r1);
+    const u32x2 r2b = __builtin_bit_cast(u32x2, r1 - __builtin_bit_cast(f32x2, r1b & 0xffff0000u));
+    p1[j] = __builtin_amdgcn_perm(xb[1], xb[0], 0x07060302u);   // the high halves = the truncated limbs
+    p2[j] = __builtin_amdgcn_perm(r1b[1], r1b[0], 0x07060302u);
+    p3[j] = __builtin_amdgcn_perm(r2b[1], r2b[0], 0x07060302u);
   }
+  Limbs3 o;
   o.l[0] = __builtin_bit_cast(bf16x8, p1);
   o.l[1] = __builtin_bit_cast(bf16x8, p2);
   o.l[2] = __builtin_bit_cast(bf16x8, p3);
@@ -479,210 +479,6 @@ __global__ __launch_bounds__(512, 2) void chain_x6_kernel(hold_chain_desc d) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// hold_chain_x6, product kernel: the limb split done ONCE per activation.  chain_x6_kernel above splits the fp32
-// activations as they are fetched -- by all 8 waves, every k step: ~88 of its ~140 VALU issue slots per 12 MFMAs are
-// that split, and the kernel is VALU-bound (MFMA pipe ~33 % busy).  Here LDS holds the three bf16 limb planes of the
-// running activation ([3][64 points][264] bf16 = 99 KiB; a workgroup owns 64 points), written by the producing epilogue;
-// the layer loop is ds_read_b128 + MFMA only.  Accumulator orientation D[i = feature][j = point] (weights are the A
-// operand): lane (hh, li) of wave w holds, for point tile m, point 32 m + li and features 32 w + 8 g + 4 hh + c in
-// register 4 g + c -- four CONSECUTIVE features per register quad, so side inputs / results move as 16-byte buffer
-// accesses and limbs as 8-byte LDS writes.  The side inputs of a layer are requested before its MFMA loop.
-constexpr int XP_PTS = 64, XP_ROW = 264, XP_PLANE = XP_PTS * XP_ROW;  // bf16 elements
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f32x4 ldb4(rsrc_t r, uint32_t voff, uint32_t soff) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-__device__ __forceinline__ void stb4(rsrc_t r, uint32_t voff, uint32_t soff, const f32x4& v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
-}
-// exact truncation split of four values into the three limb planes (8-byte writes)
-__device__ __forceinline__ void put_limbs4(__bf16* dst, const f32x4& v) {
-  uint32_t h1[4], h2[4], h3[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    h1[c] = __builtin_bit_cast(uint32_t, v[c]) & 0xffff0000u;
-    const float r1 = v[c] - __builtin_bit_cast(float, h1[c]);
-    h2[c] = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
-    h3[c] = __builtin_bit_cast(uint32_t, r1 - __builtin_bit_cast(float, h2[c]));
-  }
-  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-  u32x2 p1, p2, p3;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    p1[j] = __builtin_amdgcn_perm(h1[2 * j + 1], h1[2 * j], 0x07060302u);
-    p2[j] = __builtin_amdgcn_perm(h2[2 * j + 1], h2[2 * j], 0x07060302u);
-    p3[j] = __builtin_amdgcn_perm(h3[2 * j + 1], h3[2 * j], 0x07060302u);
-  }
-  *reinterpret_cast<u32x2*>(dst) = p1;
-  *reinterpret_cast<u32x2*>(dst + XP_PLANE) = p2;
-  *reinterpret_cast<u32x2*>(dst + 2 * XP_PLANE) = p3;
-}
-
-template <int STEPS>
-__device__ __forceinline__ void xp_layer(const bf16x8* __restrict__ wq, const bf16x8* __restrict__ nxt,
-                                         const __bf16* __restrict__ prow, f32x16 (&acc)[2], bf16x8 (&bn)[3]) {
-  // prow: plane 0, row of point li, column 8 hh; tile m adds 32 rows, limb t adds a plane, step s adds 16 columns
-  auto rd = [&](int s, bf16x8 (&al)[2][3]) {
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-        al[m][t] = *reinterpret_cast<const bf16x8*>(prow + t * XP_PLANE + m * 32 * XP_ROW + s * 16);
-  };
-  bf16x8 an[2][3], b[3];
-  rd(0, an);
-#pragma unroll
-  for (int s = 0; s < STEPS; ++s) {
-    bf16x8 a[2][3];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int t = 0; t < 3; ++t) a[m][t] = an[m][t];
-    if (s + 1 < STEPS) rd(s + 1, an);
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      b[t] = bn[t];
-      if (s + 1 < STEPS) {
-        bn[t] = wq[(s + 1) * X6_UNITS + t * 512];
-      } else if (nxt) {
-        bn[t] = nxt[t * 512];
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int pr = 0; pr < 6; ++pr) {
-      const int wl = (pr == 2 || pr == 3) ? 1 : (pr == 5 ? 2 : 0);  // (w limb, a limb): 00 01 10 11 02 20
-      const int al = (pr == 1 || pr == 3) ? 1 : (pr == 4 ? 2 : 0);
-#pragma unroll
-      for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[wl], a[m][al], acc[m], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-template <int MODE, bool A2, int FIRST_STEPS>
-__global__ __launch_bounds__(512, 2) void chain_x6p_kernel(hold_chain_desc d) {
-  constexpr int NTHR = 512;
-  constexpr int KIN = (FIRST_STEPS == 3) ? 40 : 256, KPAD = 16 * FIRST_STEPS;
-  constexpr bool LOAD1 = MODE != HOLD_CHAIN_SOFTPLUS;                 // aux1 (stored softplus outputs)
-  constexpr bool LOAD2 = (MODE == HOLD_CHAIN_DBWD) || A2;             // aux2 (t_l / the additive term)
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  __bf16* planes = reinterpret_cast<__bf16*>(smem);                   // [3][64][264] bf16
-  float* side = smem + 3 * XP_PLANE / 2;                              // [64][40] fp32
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int hh = lane >> 5, li = lane & 31;
-  const int nb = wave * 32 + 4 * hh;
-  const bf16x8* w0 = reinterpret_cast<const bf16x8*>(d.wpack) + wave * 64 + lane;
-  constexpr long LAYER0 = (long)FIRST_STEPS * X6_UNITS, LAYERK = 16L * X6_UNITS;  // 16-byte units
-  const int NL = d.n_layers;
-  const uint32_t ldb_ = (uint32_t)d.ld * 4u;
-  const uint32_t nbytes = (uint32_t)(d.P * d.ld * 4);
-
-  for (long blk = blockIdx.x; blk * XP_PTS < d.P; blk += gridDim.x) {
-    const long p0 = blk * XP_PTS;
-    bf16x8 bn[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) bn[t] = w0[t * 512];
-    // ---- initial activations (zero-padded to a multiple of 16 columns) -> limb planes; the 40-wide side matrix ----
-    for (int e = tid; e < XP_PTS * (KPAD / 4); e += NTHR) {
-      const int p = e / (KPAD / 4), j4 = (e % (KPAD / 4)) * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (j4 < KIN && p0 + p < d.P) v = *reinterpret_cast<const f32x4*>(d.in + (p0 + p) * d.ld_in + j4);
-      put_limbs4(planes + p * XP_ROW + j4, v);
-    }
-    if (d.side) {
-      for (int e = tid; e < XP_PTS * (ESTR / 4); e += NTHR) {
-        const int p = e / (ESTR / 4), j4 = (e % (ESTR / 4)) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (p0 + p < d.P) v = *reinterpret_cast<const f32x4*>(d.side + (p0 + p) * d.ld_side + j4);
-        *reinterpret_cast<f32x4*>(side + p * ESTR + j4) = v;
-      }
-    }
-    __syncthreads();
-
-    const __bf16* prow = planes + li * XP_ROW + hh * 8;
-    const uint32_t soff = (uint32_t)(p0 * d.ld * 4);                     // block base (wave-uniform)
-    const uint32_t voff0 = (uint32_t)li * ldb_ + (uint32_t)nb * 4u;      // (point li, feature nb); m adds 32 rows, g 32 B
-    const bf16x8* wl = w0;
-    for (int layer = 0; layer < NL; ++layer) {
-      // ---- side inputs of this layer's epilogue: requested now, they land under the MFMA loop ----
-      f32x4 v1[2][4], v2[2][4];
-      const rsrc_t ra1 = make_rsrc(d.aux1[layer], nbytes), ra2 = make_rsrc(d.aux2[layer], nbytes);
-      if (LOAD1 || LOAD2) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const uint32_t vo = voff0 + (uint32_t)m * 32u * ldb_ + (uint32_t)g * 32u;
-            if (LOAD1) v1[m][g] = ldb4(ra1, vo, soff);
-            if (LOAD2) v2[m][g] = ldb4(ra2, vo, soff);
-          }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      f32x16 acc[2];
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-      const bool last = layer + 1 >= NL;
-      if (layer == 0) {
-        xp_layer<FIRST_STEPS>(wl, last ? nullptr : wl + LAYER0, prow, acc, bn);
-        wl += LAYER0;
-      } else {
-        xp_layer<16>(wl, last ? nullptr : wl + LAYERK, prow, acc, bn);
-        wl += LAYERK;
-      }
-      __syncthreads();  // every wave has finished READING this layer's input planes
-      const rsrc_t ro1 = make_rsrc(d.out[layer], nbytes), ro2 = make_rsrc(d.out2[layer], nbytes);
-      const bool skip = layer == d.skip_layer;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n4 = nb + 8 * g;
-        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-        if (MODE == HOLD_CHAIN_SOFTPLUS) bias = *reinterpret_cast<const f32x4*>(d.bias[layer] + n4);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const int p = m * 32 + li;
-          const uint32_t vo = voff0 + (uint32_t)m * 32u * ldb_ + (uint32_t)g * 32u;
-          f32x4 r, r2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float y = acc[m][4 * g + c];
-            if (MODE == HOLD_CHAIN_SOFTPLUS) {
-              r[c] = softplus100(y + bias[c]);
-            } else if (MODE == HOLD_CHAIN_DSP) {
-              r[c] = y * dsp_from_h(v1[m][g][c]);
-              if (A2) r[c] += v2[m][g][c];
-            } else {
-              const float e = __expf(-100.0f * v1[m][g][c]);
-              r[c] = y * dsp_from_h(v1[m][g][c]);
-              r2[c] = 100.0f * y * v2[m][g][c] * e;
-            }
-          }
-          if (skip && n4 + 3 >= SKIP_OUT) {  // the 217 | 39 split (wave-uniform test; only the last two waves' tiles hit it)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-              if (n4 + c >= SKIP_OUT) {
-                if (MODE == HOLD_CHAIN_DSP) {
-                  r[c] = acc[m][4 * g + c];  // raw product = d / d(skip input)
-                } else {
-                  r[c] = side[p * ESTR + (n4 + c - SKIP_OUT)];
-                  r2[c] = 0.f;
-                }
-              }
-          }
-          stb4(ro1, vo, soff, r);
-          if (MODE == HOLD_CHAIN_DBWD) stb4(ro2, vo, soff, r2);
-          if (!last) put_limbs4(planes + p * XP_ROW + n4, r);
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
-
 bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 template <int MODE, bool A2, int FIRST>
@@ -713,22 +509,6 @@ int launch_x6(const hold_chain_desc& d, int n_cu, hipStream_t s) {
   const long blocks = (d.P + 127) / 128;
   hipLaunchKernelGGL((chain_x6_kernel<MODE, A2, FIRST_STEPS>), dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(512), sh,
                      s, d);
-  return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
-}
-
-template <int MODE, bool A2, int FIRST_STEPS>
-int launch_x6p(const hold_chain_desc& d, int n_cu, hipStream_t s) {
-  const size_t sh = (size_t)3 * XP_PLANE * 2 + (size_t)XP_PTS * ESTR * sizeof(float);  // 111 616 B, one block per CU
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)chain_x6p_kernel<MODE, A2, FIRST_STEPS>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
-      return HOLD_E_LAUNCH;
-    attr_set = true;
-  }
-  const long blocks = (d.P + XP_PTS - 1) / XP_PTS;
-  hipLaunchKernelGGL((chain_x6p_kernel<MODE, A2, FIRST_STEPS>), dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(512),
-                     sh, s, d);
   return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
 }
 
@@ -780,17 +560,6 @@ static int chain_impl(const hold_chain_desc* dp, hold_stream_t st, bool x6) {
   }
   hipStream_t s = (hipStream_t)st;
   if (x6) {
-    bool planes = true;  // limb planes in LDS (chain_x6p_kernel); the split-on-fetch kernel is the developer-build A/B
-#ifdef HOLD_DEV
-    if (const char* v = getenv("HOLD_CHAIN_X6_VARIANT")) planes = atoi(v) != 0;
-#endif
-    if (planes) {
-      if (d.mode == HOLD_CHAIN_SOFTPLUS && d.first_chunks == 5) return launch_x6p<HOLD_CHAIN_SOFTPLUS, false, 3>(d, n_cu, s);
-      if (d.mode == HOLD_CHAIN_DSP && d.first_chunks == 32)
-        return has2 ? launch_x6p<HOLD_CHAIN_DSP, true, 16>(d, n_cu, s) : launch_x6p<HOLD_CHAIN_DSP, false, 16>(d, n_cu, s);
-      if (d.mode == HOLD_CHAIN_DBWD && d.first_chunks == 5) return launch_x6p<HOLD_CHAIN_DBWD, true, 3>(d, n_cu, s);
-      return HOLD_E_ARG;
-    }
     if (d.mode == HOLD_CHAIN_SOFTPLUS && d.first_chunks == 5) return launch_x6<HOLD_CHAIN_SOFTPLUS, false, 3>(d, n_cu, s);
     if (d.mode == HOLD_CHAIN_DSP && d.first_chunks == 32)
       return has2 ? launch_x6<HOLD_CHAIN_DSP, true, 16>(d, n_cu, s) : launch_x6<HOLD_CHAIN_DSP, false, 16>(d, n_cu, s);

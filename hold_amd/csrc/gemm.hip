@@ -46,21 +46,20 @@ __device__ __forceinline__ Limbs3 split8s(const float (&x)[8]) {
 }
 // the same by truncation (v_and / v_sub / v_perm only), see fused_sdf.hip:split8_trunc
 __device__ __forceinline__ Limbs3 split8s_trunc(const float (&x)[8]) {
-  uint32_t h1[8], h2[8], h3[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    h1[e] = __builtin_bit_cast(uint32_t, x[e]) & 0xffff0000u;
-    const float r1 = x[e] - __builtin_bit_cast(float, h1[e]);
-    h2[e] = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
-    h3[e] = __builtin_bit_cast(uint32_t, r1 - __builtin_bit_cast(float, h2[e]));
-  }
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   u32x4 p1, p2, p3;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    p1[j] = __builtin_amdgcn_perm(h1[2 * j + 1], h1[2 * j], 0x07060302u);
-    p2[j] = __builtin_amdgcn_perm(h2[2 * j + 1], h2[2 * j], 0x07060302u);
-    p3[j] = __builtin_amdgcn_perm(h3[2 * j + 1], h3[2 * j], 0x07060302u);
+  for (int j = 0; j < 4; ++j) {  // two values at a time: v_pk_add_f32 for the remainders (36 VALU slots per 8 values)
+    const f32x2 v = {x[2 * j], x[2 * j + 1]};
+    const u32x2 xb = __builtin_bit_cast(u32x2, v);
+    const f32x2 r1 = v - __builtin_bit_cast(f32x2, xb & 0xffff0000u);
+    const u32x2 r1b = __builtin_bit_cast(u32x2, r1);
+    const u32x2 r2b = __builtin_bit_cast(u32x2, r1 - __builtin_bit_cast(f32x2, r1b & 0xffff0000u));
+    p1[j] = __builtin_amdgcn_perm(xb[1], xb[0], 0x07060302u);
+    p2[j] = __builtin_amdgcn_perm(r1b[1], r1b[0], 0x07060302u);
+    p3[j] = __builtin_amdgcn_perm(r2b[1], r2b[0], 0x07060302u);
   }
   Limbs3 o;
   o.l[0] = __builtin_bit_cast(bf16x8, p1);

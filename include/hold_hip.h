@@ -339,8 +339,7 @@ typedef struct {
 int64_t hold_chain_pack_floats(int32_t first_chunks, int32_t n_layers);
 int hold_chain(const hold_chain_desc* d, hold_stream_t stream);
 /* Split-precision variant: the same descriptor and semantics, the layer products as three-limb bf16 splits on
- * v_mfma_f32_32x32x16_bf16 (six limb products, fp32 accumulation; the running activation lives in LDS as three bf16 limb
- * planes written by the producing epilogue, 64 points per workgroup).
+ * v_mfma_f32_32x32x16_bf16 (six limb products, fp32 accumulation; activations split from fp32 LDS as they are fetched).
  * d->wpack then points at hold_chain_x6_pack_bytes(first_chunks, n_layers) bytes of bf16 limbs: layer j, K_j = 48 for
  * first_chunks = 5 (columns 40..47 zero) else 256,
  *   [K_j/16 steps][3 limbs t][8 n-tiles][2 halves h][32 rows i][8] = limb_t(M_j)[32*nt + i][16*step + 8*h + e]
