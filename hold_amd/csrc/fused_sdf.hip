@@ -578,7 +578,8 @@ constexpr int XP_PTS = 64, XP_ROW = 264, XP_PLANE = XP_PTS * XP_ROW;   // bf16 e
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 // NOSTREAM (developer build only): every step re-reads the first weight fragment -- a timing ablation that removes the
-// L2 -> CU weight stream while keeping every instruction (results are wrong)
+// L2 -> CU weight stream while keeping every instruction (results are wrong): 226 vs 180 TF-equivalent.  It is not a
+// latency effect: requesting the weight limbs TWO steps ahead instead of one measured 186.2 vs 187.4.
 template <int STEPS, bool NOSTREAM = false>
 __device__ __forceinline__ void xp_layer(const bf16x8* __restrict__ wq, const bf16x8* __restrict__ nxt,
                                          const __bf16* __restrict__ prow, f32x16 (&acc)[2], bf16x8 (&bn)[3]) {
@@ -632,49 +633,7 @@ __device__ __forceinline__ void xp_layer(const bf16x8* __restrict__ wq, const bf
     for (int r = 0; r < 16; ++r) acc[m][r] = part[m][0][r] + part[m][1][r];
 }
 
-// PF2 variant of the layer loop: weight limbs requested TWO steps ahead (one step = 12 MFMAs ~ 400 matrix-pipe cycles per
-// wave is about the L2 latency, the NOSTREAM ablation prices the stream at ~20 %), and two accumulation chains instead
-// of four to pay for the extra 12 registers.
-template <int STEPS>
-__device__ __forceinline__ void xp_layer_pf2(const bf16x8* __restrict__ wq, const bf16x8* __restrict__ nxt,
-                                             const __bf16* __restrict__ prow, f32x16 (&acc)[2], bf16x8 (&bn)[3],
-                                             bf16x8 (&bn2)[3]) {
-  auto rd = [&](int s, bf16x8 (&al)[2][3]) {
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-        al[m][t] = *reinterpret_cast<const bf16x8*>(prow + t * XP_PLANE + m * 32 * XP_ROW + s * 16);
-  };
-  bf16x8 an[2][3], b[3];
-  rd(0, an);
-#pragma unroll
-  for (int s = 0; s < STEPS; ++s) {
-    bf16x8 a[2][3];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int t = 0; t < 3; ++t) a[m][t] = an[m][t];
-    if (s + 1 < STEPS) rd(s + 1, an);
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      b[t] = bn[t];
-      bn[t] = bn2[t];
-      bn2[t] = (s + 2 < STEPS) ? wq[(s + 2) * X6_STEP_UNITS + t * 512] : nxt[(s + 2 - STEPS) * X6_STEP_UNITS + t * 512];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int pr = 0; pr < 6; ++pr) {
-      const int wl = (pr == 2 || pr == 3) ? 1 : (pr == 5 ? 2 : 0);   // (w limb, a limb): 00 01 10 11 02 20
-      const int al = (pr == 1 || pr == 3) ? 1 : (pr == 4 ? 2 : 0);
-#pragma unroll
-      for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[wl], a[m][al], acc[m], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-template <bool NOSTREAM, bool PF2 = false>
+template <bool NOSTREAM>
 __global__ __launch_bounds__(512, 2) void fused_sdf_x6p_kernel(FusedArgs a, const bf16x8* __restrict__ wx6) {
   constexpr int NTHR = 512;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -688,12 +647,9 @@ __global__ __launch_bounds__(512, 2) void fused_sdf_x6p_kernel(FusedArgs a, cons
 
   for (long blk = blockIdx.x; blk * XP_PTS < a.P; blk += gridDim.x) {
     const long p0 = blk * XP_PTS;
-    bf16x8 bn[3], bn2[3];
+    bf16x8 bn[3];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      bn[t] = w0[t * 512];
-      if (PF2) bn2[t] = w0[X6_STEP_UNITS + t * 512];
-    }
+    for (int t = 0; t < 3; ++t) bn[t] = w0[t * 512];
     for (int e = tid; e < XP_PTS * 48; e += NTHR) {   // embedding, zero-padded to K = 48, split into limbs
       const int p = e / 48, j = e % 48;
       float v = 0.f;
@@ -727,15 +683,7 @@ __global__ __launch_bounds__(512, 2) void fused_sdf_x6p_kernel(FusedArgs a, cons
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-      if (PF2) {
-        if (layer == 0) {
-          xp_layer_pf2<X6_L0_STEPS>(wl, wl + X6_L0_STEPS * X6_STEP_UNITS, prow, acc, bn, bn2);
-          wl += X6_L0_STEPS * X6_STEP_UNITS;
-        } else {
-          xp_layer_pf2<X6_LK_STEPS>(wl, layer < 7 ? wl + X6_LK_STEPS * X6_STEP_UNITS : w0, prow, acc, bn, bn2);
-          wl += X6_LK_STEPS * X6_STEP_UNITS;
-        }
-      } else if (layer == 0) {
+      if (layer == 0) {
         xp_layer<X6_L0_STEPS, NOSTREAM>(wl, wl + X6_L0_STEPS * X6_STEP_UNITS, prow, acc, bn);
         if (!NOSTREAM) wl += X6_L0_STEPS * X6_STEP_UNITS;
       } else {
@@ -917,18 +865,6 @@ extern "C" int hold_fused_sdf_x6(const float* xc, int32_t ldx, int64_t P, const 
     }
     const long blocks = (P + XP_PTS - 1) / XP_PTS;
 #ifdef HOLD_DEV
-    if (getenv("HOLD_X6P_PF2")) {  // A/B: weights two steps ahead, two accumulation chains
-      static bool attr_q = false;
-      if (!attr_q) {
-        if (hipFuncSetAttribute((const void*)fused_sdf_x6p_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)shp) != hipSuccess)
-          return HOLD_E_LAUNCH;
-        attr_q = true;
-      }
-      hipLaunchKernelGGL((fused_sdf_x6p_kernel<false, true>), dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(512), shp,
-                         (hipStream_t)st, a, reinterpret_cast<const bf16x8*>(wpack_x6));
-      return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
-    }
     if (getenv("HOLD_X6P_NOSTREAM")) {
       static bool warned = false;
       if (!warned) fprintf(stderr, "libholdhip: HOLD_X6P_NOSTREAM -- timing ablation, hold_fused_sdf_x6 results are WRONG\n");

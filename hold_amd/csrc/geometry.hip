@@ -121,6 +121,78 @@ __global__ __launch_bounds__(256) void mesh_sdf_kernel(const float* __restrict__
   }
 }
 
+// Few query points (the 10 x 307 samples of compute_mano_cano_sdf in a training step): one thread per point would put
+// 20 blocks on 256 CUs.  Here a wavefront owns WPP points and its 64 lanes share the faces of a tile (lane j takes
+// triangles j, j + 64, ...), min / sum reduced by a fixed butterfly: the same minimum, the winding sum in another
+// (deterministic) order.
+constexpr int WPP = 2;
+__global__ __launch_bounds__(256) void mesh_sdf_wave_kernel(const float* __restrict__ pts, long P,
+                                                            const float* __restrict__ verts, long vstride, int V,
+                                                            const int* __restrict__ faces, int F, float cull,
+                                                            const float* __restrict__ aabb, float* __restrict__ sd) {
+  __shared__ float tri[TILE * 9];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* vb = verts + (long)b * vstride;
+  V3 x[WPP];
+  float far_d[WPP], best[WPP], omega[WPP];
+  bool active[WPP];
+#pragma unroll
+  for (int i = 0; i < WPP; ++i) {
+    const long p = ((long)blockIdx.x * 4 + wave) * WPP + i;
+    active[i] = p < P;
+    x[i] = {0.f, 0.f, 0.f};
+    far_d[i] = 0.f;
+    best[i] = 3.0e38f;
+    omega[i] = 0.f;
+    if (active[i]) {
+      const float* q = pts + ((long)b * P + p) * 3;
+      x[i] = {q[0], q[1], q[2]};
+      if (cull > 0.f && aabb) {
+        const float* bb = aabb + b * 6;
+        const float dx = fmaxf(fmaxf(bb[0] - x[i].x, x[i].x - bb[3]), 0.f),
+                    dy = fmaxf(fmaxf(bb[1] - x[i].y, x[i].y - bb[4]), 0.f),
+                    dz = fmaxf(fmaxf(bb[2] - x[i].z, x[i].z - bb[5]), 0.f);
+        far_d[i] = sqrtf(dx * dx + dy * dy + dz * dz);
+        if (far_d[i] > cull) active[i] = false;
+      }
+    }
+  }
+  for (int f0 = 0; f0 < F; f0 += TILE) {
+    const int nt = min(TILE, F - f0);
+    for (int e = threadIdx.x; e < nt * 3; e += 256) {
+      const int vid = faces[(long)(f0 + e / 3) * 3 + (e % 3)];
+      const float* v = vb + (long)(vid < V ? (vid < 0 ? 0 : vid) : V - 1) * 3;
+      float* t = tri + (e / 3) * 9 + (e % 3) * 3;
+      t[0] = v[0];
+      t[1] = v[1];
+      t[2] = v[2];
+    }
+    __syncthreads();
+    for (int j = lane; j < nt; j += 64) {
+      const float* t = tri + j * 9;  // stride 9 floats: conflict-free over the 32 banks
+      const V3 a = {t[0], t[1], t[2]}, bb = {t[3], t[4], t[5]}, c = {t[6], t[7], t[8]};
+#pragma unroll
+      for (int i = 0; i < WPP; ++i)
+        if (active[i]) {
+          best[i] = fminf(best[i], tri_d2(x[i], a, bb, c));
+          omega[i] += solid_angle(x[i], a, bb, c);
+        }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < WPP; ++i) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      best[i] = fminf(best[i], __shfl_xor(best[i], d));
+      omega[i] += __shfl_xor(omega[i], d);
+    }
+    const long p = ((long)blockIdx.x * 4 + wave) * WPP + i;
+    if (lane == 0 && p < P)
+      sd[(long)b * P + p] = active[i] ? sqrtf(best[i]) * (fabsf(omega[i]) > 6.2831853f ? -1.f : 1.f) : far_d[i];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Per-ray off-surface test of check_off_in_surface_points_cano_mesh (volsdf_utils.py:189-217) without visiting every
 // face for every sample: off(ray) <=> min over the ray's samples of the signed distance > thr.  Built on two structures
@@ -212,6 +284,12 @@ extern "C" int hold_mesh_sdf(const float* pts, int32_t B, int64_t P, const float
   if (!pts || !verts || !faces || !sd || B < 0 || P < 0 || V <= 0 || F <= 0) return HOLD_E_ARG;
   if (cull_dist > 0.f && !aabb) return HOLD_E_ARG;
   if (B == 0 || P == 0) return HOLD_OK;
+  if ((long)B * P <= 32768) {  // too few points to fill the chip one thread per point: lanes over faces instead
+    const dim3 grid((unsigned)((P + 4 * WPP - 1) / (4 * WPP)), (unsigned)B);
+    hipLaunchKernelGGL(mesh_sdf_wave_kernel, grid, dim3(256), 0, (hipStream_t)st, pts, (long)P, verts,
+                       verts_shared ? 0L : (long)V * 3, V, faces, F, cull_dist, aabb, sd);
+    return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+  }
   const dim3 grid((unsigned)((P + 255) / 256), (unsigned)B);
   hipLaunchKernelGGL(mesh_sdf_kernel, grid, dim3(256), 0, (hipStream_t)st, pts, (long)P, verts,
                      verts_shared ? 0L : (long)V * 3, V, faces, F, cull_dist, aabb, sd);

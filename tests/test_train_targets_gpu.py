@@ -79,6 +79,11 @@ def test_mesh_sdf_kernel_matches_oracle(ctx):
     p = ((torch.rand(2, 3000, 3, generator=g) * 2 - 1) * 0.8)
     sd = geo.mesh_sdf(p.cuda(), v.float().cuda(), f.cuda())
     assert float((sd.cpu().double() - go.box_sdf(p.double(), h)).abs().max()) < 2e-6
+    # > 32 768 points take the one-thread-per-point kernel, fewer the lanes-over-faces kernel: same values
+    pl = ((torch.rand(1, 40000, 3, generator=g) * 2 - 1) * 0.8)
+    sdl = geo.mesh_sdf(pl.cuda(), v.float().cuda(), f.cuda())
+    assert float((sdl.cpu().double() - go.box_sdf(pl.double(), h)).abs().max()) < 2e-6
+    assert torch.equal(geo.mesh_sdf(pl[:, :3000].contiguous().cuda(), v.float().cuda(), f.cuda()), sdl[:, :3000])
     m = syn.make_mano_model(True)
     verts = torch.tensor(m["v_template"], dtype=torch.float32)[None].cuda()
     faces = torch.tensor(m["f"]).cuda()
