@@ -63,8 +63,8 @@ def parse():
 
 def cpu_baseline(sc, sd_np, threads=32, repeats=3):
     """The CPU oracle (torch restatement of the reference's PyTorch path, oracle/hold_oracle.py) timed on the host:
-    the reference's own training batch -- 10 frames x 128 random pixels = 1 280 rays (general.yaml:82, tempo_dataset.py
-    :27-36) -- fwd + loss + backward, median of `repeats` steps."""
+    the reference's own training batch shape -- up to 10 frames (the synthetic scene has 8) x 128 random pixels
+    (general.yaml:82, tempo_dataset.py:27-36) -- fwd + loss + backward, median of `repeats` steps."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from hold_amd import synthetic as syn
     from hold_amd.train import pixel_losses
@@ -109,7 +109,7 @@ def cpu_baseline(sc, sd_np, threads=32, repeats=3):
         times.append(time.time() - t0)
     med = float(np.median(times))
     return {"value": N / med, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"{repeats} training steps of the reference's batch (10 frames x 128 pixels = {N} rays), fwd + rgb/sem "
+            "sample": f"{repeats} training steps of the reference's batch shape ({len(frames)} frames x 128 pixels = {N} rays), fwd + rgb/sem "
                       f"loss + backward, median step {med:.2f} s; oracle/hold_oracle.py (torch CPU restatement of the "
                       f"reference, pinned to it by tests/golden), {cores} of {os.cpu_count()} host threads"}
 
