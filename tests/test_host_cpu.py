@@ -194,3 +194,24 @@ def test_chain_weight_packs_follow_the_header_layout():
         assert torch.equal(m, ref), j
     # the skip folding: layer 4 carries the 1/sqrt(2) of cat([x, input]) / sqrt(2)  (shape_net.py:122-123)
     assert torch.allclose(pk["W"][4], iw[4] / 2 ** 0.5)
+
+
+def test_render_input_column_permutation_is_a_bijection_onto_the_reference_order():
+    """hold_amd.field.rin_perm: our rendering-net input = the reference's columns with the 256 feature columns first"""
+    import torch
+    from hold_amd import field as F
+    for rin_dim in (270, 302):
+        perm = F.rin_perm(rin_dim)
+        assert sorted(perm.tolist()) == list(range(rin_dim))
+        ref_cols = torch.arange(rin_dim)
+        ours = ref_cols[perm]  # column j of our layout holds reference column perm[j]
+        assert ours[F.RIN_FEAT:F.RIN_FEAT + 256].tolist() == list(range(14, 270))        # feature_vectors
+        assert ours[F.RIN_X:F.RIN_X + 3].tolist() == [0, 1, 2]                           # canonical points
+        assert ours[F.RIN_N:F.RIN_N + 3].tolist() == [3, 4, 5]                           # normals
+        assert ours[F.RIN_POSE:F.RIN_POSE + 8].tolist() == list(range(6, 14))            # pose embedding
+        if rin_dim > 270:
+            assert ours[F.RIN_TIME:].tolist() == list(range(270, rin_dim))               # frame encoding
+        g = torch.randn(4, rin_dim)
+        back = torch.empty_like(g)
+        back[:, perm] = g[:, perm][:, torch.arange(rin_dim)]
+        assert torch.equal(back, g)
