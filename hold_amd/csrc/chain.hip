@@ -287,7 +287,8 @@ constexpr int X6_UNITS = 3 * 512;  // 16-byte units per 16-wide k step
 struct Limbs3 { bf16x8 l[3]; };
 
 // Two values at a time: the compiler selects v_pk_add_f32 for the two remainders, so 8 values cost 16 v_and + 8 v_pk_add
-// + 12 v_perm = 36 VALU issue slots (44 with scalar subtractions) -- this split is what bounds the kernel.
+// + 12 v_perm = 36 VALU issue slots (44 with scalar subtractions).  Measured neutral: neither this nor halving the number
+// of splits (a four-wave variant, 64 features per wave) moved the kernel -- it is not VALU-issue-bound.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ Limbs3 split8_trunc(const f32x4& x0, const f32x4& x1) {
@@ -480,198 +481,6 @@ __global__ __launch_bounds__(512, 2) void chain_x6_kernel(hold_chain_desc d) {
 
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// hold_chain_x6 with FOUR waves per workgroup (one per SIMD): wave w owns 64 features (n-tiles 2w, 2w + 1) of both point
-// tiles of a half, so one split of an activation fragment feeds 24 MFMAs instead of 12 -- the split (which every wave of
-// chain_x6_kernel repeats and which makes it VALU-bound) is replicated 4x instead of 8x and costs half as many issue
-// slots per MFMA.  Same LDS layout, pipeline, epilogue units (16 per step: 8 per n-tile) and buffer I/O; the 2 x 64
-// accumulator registers of the two pipeline stages live in AGPRs.
-template <int CH>
-__device__ constexpr int exec_at16(int U) {
-  return ((U + 1) * CH + 15) / 16 - 1 < CH - 1 ? ((U + 1) * CH + 15) / 16 - 1 : CH - 1;
-}
-template <int CH>
-__device__ constexpr int load_at16(int U) { return U < 2 ? 0 : exec_at16<CH>(U - 2) + 1; }
-
-template <int MODE, bool A2, int STEPS, bool EPI>
-__device__ __forceinline__ void chain_step_x6w(const bf16x8* __restrict__ wq, const bf16x8* __restrict__ nxt,
-                                               const float* __restrict__ arow, f32x16 (&accC)[2][2],
-                                               bf16x8 (&bn)[2][3], const f32x16 (&accP)[2][2], const EpiCtx (&x)[2]) {
-  constexpr int CH = 2 * STEPS;
-  f32x4 s1[2], s2[2], xn[4];
-#pragma unroll
-  for (int n = 0; n < 2; ++n)
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) accC[n][m][r] = 0.f;
-  auto rd = [&](int s) {
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      xn[2 * m] = *reinterpret_cast<const f32x4*>(arow + m * 32 * ASTR + s * 16);
-      xn[2 * m + 1] = *reinterpret_cast<const f32x4*>(arow + m * 32 * ASTR + s * 16 + 4);
-    }
-  };
-  auto prod = [&](const Limbs3 (&la)[2], const bf16x8 (&b)[2][3], int il, int jl) {
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
-        accC[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la[m].l[il], b[n][jl], accC[n][m], 0, 0, 0);
-  };
-  rd(0);
-  Limbs3 la[2];
-  la[0] = split8_trunc(xn[0], xn[1]);
-  la[1] = split8_trunc(xn[2], xn[3]);
-#pragma unroll
-  for (int s = 0; s < STEPS; ++s) {
-    bf16x8 b[2][3];
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        b[n][t] = bn[n][t];
-        if (s + 1 < STEPS) {
-          bn[n][t] = wq[(s + 1) * X6_UNITS + t * 512 + n * 64];
-        } else if (nxt) {
-          bn[n][t] = nxt[t * 512 + n * 64];
-        }
-      }
-    if (EPI) {
-#pragma unroll
-      for (int U = 0; U < 16; ++U)
-        if (load_at16<CH>(U) == 2 * s) epi_load<MODE, A2>(x[U >> 3], U & 7, s1[U & 1], s2[U & 1]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    prod(la, b, 0, 0);
-    prod(la, b, 1, 0);
-    prod(la, b, 0, 1);
-    if (EPI) {
-#pragma unroll
-      for (int U = 0; U < 16; ++U)
-        if (exec_at16<CH>(U) == 2 * s) epi_exec<MODE, A2>(x[U >> 3], U & 7, accP[U >> 3], s1[U & 1], s2[U & 1]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (EPI) {
-#pragma unroll
-      for (int U = 0; U < 16; ++U)
-        if (load_at16<CH>(U) == 2 * s + 1) epi_load<MODE, A2>(x[U >> 3], U & 7, s1[U & 1], s2[U & 1]);
-    }
-    if (s + 1 < STEPS) rd(s + 1);  // next step's fp32 fragments: needed by the split at the end of this phase
-    __builtin_amdgcn_sched_barrier(0);
-    prod(la, b, 1, 1);
-    prod(la, b, 2, 0);
-    prod(la, b, 0, 2);
-    if (s + 1 < STEPS) {
-      la[0] = split8_trunc(xn[0], xn[1]);
-      la[1] = split8_trunc(xn[2], xn[3]);
-    }
-    if (EPI) {
-#pragma unroll
-      for (int U = 0; U < 16; ++U)
-        if (exec_at16<CH>(U) == 2 * s + 1) epi_exec<MODE, A2>(x[U >> 3], U & 7, accP[U >> 3], s1[U & 1], s2[U & 1]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-template <int MODE, bool A2, int FIRST_STEPS>
-__global__ __launch_bounds__(256) void chain_x6w_kernel(hold_chain_desc d) {
-  constexpr int PTS = 128, NTHR = 256;
-  constexpr int KIN = (FIRST_STEPS == 3) ? 40 : 256, KPAD = 16 * FIRST_STEPS;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* act = smem;                   // [128][260]
-  float* side = smem + PTS * ASTR;     // [128][40]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int hh = lane >> 5, li = lane & 31;
-  const bf16x8* w0 = reinterpret_cast<const bf16x8*>(d.wpack) + (2 * wave) * 64 + lane;
-  constexpr long LAYER0 = (long)FIRST_STEPS * X6_UNITS, LAYERK = 16L * X6_UNITS;  // 16-byte units
-  const int NL = d.n_layers;
-  const long ld = d.ld;
-  const uint32_t nbytes = (uint32_t)(d.P * ld * 4);
-
-  for (long blk = blockIdx.x; blk * PTS < d.P; blk += gridDim.x) {
-    const long p0 = blk * PTS;
-    bf16x8 bn[2][3];
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int t = 0; t < 3; ++t) bn[n][t] = w0[t * 512 + n * 64];
-    for (int e = tid; e < PTS * (KPAD / 4); e += NTHR) {
-      const int p = e / (KPAD / 4), j4 = (e % (KPAD / 4)) * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (j4 < KIN && p0 + p < d.P) v = *reinterpret_cast<const f32x4*>(d.in + (p0 + p) * d.ld_in + j4);
-      *reinterpret_cast<f32x4*>(act + p * ASTR + j4) = v;
-    }
-    if (d.side) {
-      for (int e = tid; e < PTS * (ESTR / 4); e += NTHR) {
-        const int p = e / (ESTR / 4), j4 = (e % (ESTR / 4)) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (p0 + p < d.P) v = *reinterpret_cast<const f32x4*>(d.side + (p0 + p) * d.ld_side + j4);
-        *reinterpret_cast<f32x4*>(side + p * ESTR + j4) = v;
-      }
-    }
-    __syncthreads();
-
-    float* row[2] = {act + li * ASTR, act + (64 + li) * ASTR};
-    auto ctx1 = [&](int layer, int half, int n) {
-      EpiCtx x;
-      const int col = (2 * wave + n) * 32 + li;
-      const long prow = p0 + half * 64 + 4 * hh;
-      x.bias = (MODE == HOLD_CHAIN_SOFTPLUS) ? d.bias[layer][col] : 0.f;
-      x.a1 = make_rsrc(d.aux1[layer], nbytes);
-      x.a2 = make_rsrc(d.aux2[layer], nbytes);
-      x.o1 = make_rsrc(d.out[layer], nbytes);
-      x.o2 = make_rsrc(d.out2[layer], nbytes);
-      x.goff = (uint32_t)((prow * ld + col) * 4);
-      x.rowb = (uint32_t)(ld * 4);
-      x.lcol = act + (half * 64 + 4 * hh) * ASTR + col;
-      x.scol = side + (half * 64 + 4 * hh) * ESTR + (col - SKIP_OUT);
-      x.skip = layer == d.skip_layer;
-      x.special = x.skip && col >= SKIP_OUT;
-      x.wr_lds = layer + 1 < NL;
-      return x;
-    };
-    f32x16 accA[2][2], accB[2][2];
-    {
-      const EpiCtx none[2] = {ctx1(0, 0, 0), ctx1(0, 0, 1)};
-      chain_step_x6w<MODE, A2, FIRST_STEPS, false>(w0, w0, row[0] + hh * 8, accA, bn, accB, none);
-    }
-    __syncthreads();
-    {
-      const EpiCtx x[2] = {ctx1(0, 0, 0), ctx1(0, 0, 1)};
-      chain_step_x6w<MODE, A2, FIRST_STEPS, true>(w0, NL > 1 ? w0 + LAYER0 : nullptr, row[1] + hh * 8, accB, bn, accA, x);
-    }
-    __syncthreads();
-    const bf16x8* wl = w0 + LAYER0;
-    for (int layer = 1; layer < NL; ++layer) {
-      {
-        const EpiCtx x[2] = {ctx1(layer - 1, 1, 0), ctx1(layer - 1, 1, 1)};
-        chain_step_x6w<MODE, A2, 16, true>(wl, wl, row[0] + hh * 8, accA, bn, accB, x);
-      }
-      __syncthreads();
-      {
-        const EpiCtx x[2] = {ctx1(layer, 0, 0), ctx1(layer, 0, 1)};
-        chain_step_x6w<MODE, A2, 16, true>(wl, layer + 1 < NL ? wl + LAYERK : nullptr, row[1] + hh * 8, accB, bn, accA, x);
-      }
-      __syncthreads();
-      wl += LAYERK;
-    }
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {  // epilogue of (last layer, H1): nothing left to hide it under
-      const EpiCtx x = ctx1(NL - 1, 1, n);
-      f32x4 s1[2], s2[2];
-      epi_load<MODE, A2>(x, 0, s1[0], s2[0]);
-      epi_load<MODE, A2>(x, 1, s1[1], s2[1]);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        epi_exec<MODE, A2>(x, u, accB[n], s1[u & 1], s2[u & 1]);
-        if (u + 2 < 8) epi_load<MODE, A2>(x, u + 2, s1[u & 1], s2[u & 1]);
-      }
-    }
-  }
-}
-
 bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 template <int MODE, bool A2, int FIRST>
@@ -702,22 +511,6 @@ int launch_x6(const hold_chain_desc& d, int n_cu, hipStream_t s) {
   const long blocks = (d.P + 127) / 128;
   hipLaunchKernelGGL((chain_x6_kernel<MODE, A2, FIRST_STEPS>), dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(512), sh,
                      s, d);
-  return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
-}
-
-template <int MODE, bool A2, int FIRST_STEPS>
-int launch_x6w(const hold_chain_desc& d, int n_cu, hipStream_t s) {
-  const size_t sh = (size_t)(128 * ASTR + 128 * ESTR) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)chain_x6w_kernel<MODE, A2, FIRST_STEPS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)sh) != hipSuccess)
-      return HOLD_E_LAUNCH;
-    attr_set = true;
-  }
-  const long blocks = (d.P + 127) / 128;
-  hipLaunchKernelGGL((chain_x6w_kernel<MODE, A2, FIRST_STEPS>), dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(256),
-                     sh, s, d);
   return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
 }
 
@@ -769,17 +562,6 @@ static int chain_impl(const hold_chain_desc* dp, hold_stream_t st, bool x6) {
   }
   hipStream_t s = (hipStream_t)st;
   if (x6) {
-    bool wide = false;  // four waves x 64 features (chain_x6w_kernel)
-#ifdef HOLD_DEV
-    if (const char* v = getenv("HOLD_CHAIN_X6_WIDE")) wide = atoi(v) != 0;
-#endif
-    if (wide) {
-      if (d.mode == HOLD_CHAIN_SOFTPLUS && d.first_chunks == 5) return launch_x6w<HOLD_CHAIN_SOFTPLUS, false, 3>(d, n_cu, s);
-      if (d.mode == HOLD_CHAIN_DSP && d.first_chunks == 32)
-        return has2 ? launch_x6w<HOLD_CHAIN_DSP, true, 16>(d, n_cu, s) : launch_x6w<HOLD_CHAIN_DSP, false, 16>(d, n_cu, s);
-      if (d.mode == HOLD_CHAIN_DBWD && d.first_chunks == 5) return launch_x6w<HOLD_CHAIN_DBWD, true, 3>(d, n_cu, s);
-      return HOLD_E_ARG;
-    }
     if (d.mode == HOLD_CHAIN_SOFTPLUS && d.first_chunks == 5) return launch_x6<HOLD_CHAIN_SOFTPLUS, false, 3>(d, n_cu, s);
     if (d.mode == HOLD_CHAIN_DSP && d.first_chunks == 32)
       return has2 ? launch_x6<HOLD_CHAIN_DSP, true, 16>(d, n_cu, s) : launch_x6<HOLD_CHAIN_DSP, false, 16>(d, n_cu, s);
