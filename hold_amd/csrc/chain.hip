@@ -481,6 +481,7 @@ __global__ __launch_bounds__(512, 2) void chain_x6_kernel(hold_chain_desc d) {
 
 
 
+
 bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 template <int MODE, bool A2, int FIRST>
