@@ -77,6 +77,23 @@ class FieldSpec:
         self.n_bones = 1 if kind == "object" else 16
 
 
+def zeros_like_many(*lists):
+    """zero tensors shaped like the given ones, carved out of ONE zero-filled buffer (256-byte aligned pieces): one fill
+    launch instead of one per tensor.  Returns one list per input list."""
+    ts = [t for lst in lists for t in lst]
+    sizes = [(t.numel() + 63) // 64 * 64 for t in ts]
+    flat = torch.zeros(sum(sizes), device=ts[0].device)
+    out, off = [], 0
+    for t, n in zip(ts, sizes):
+        out.append(flat[off:off + t.numel()].view(t.shape))
+        off += n
+    res, i = [], 0
+    for lst in lists:
+        res.append(out[i:i + len(lst)])
+        i += len(lst)
+    return res
+
+
 def split_limbs(w, n=3):
     """exact bf16 limb decomposition w = sum_t limb_t (limb_t = bf16 rounding of the residual), as fp32 values"""
     out, r = [], w.float()
@@ -101,21 +118,37 @@ def pack_x6(W8, first_k=48):
     return torch.cat(parts).contiguous()
 
 
+def pack_x6_stack(S):
+    """pack_x6 of L zero-padded [256, 256] matrices given as one [L, 256, 256] tensor (same layout, a dozen device ops
+    for all of them instead of a dozen per matrix)"""
+    L = S.shape[0]
+    limbs = torch.stack(split_limbs(S))  # [3, L, 256, 256] bf16: (t, L, 32 nt + i, 16 step + 8 h + e)
+    return limbs.reshape(3, L, 8, 32, 16, 2, 8).permute(1, 4, 0, 2, 5, 3, 6).reshape(-1)
+
+
+def frag_pack_stack(S):
+    """fp32 MFMA-fragment order of hold_fused_sdf / hold_chain for L [256, 256] matrices:
+    per matrix [K/8 chunks][8 n-tiles][2 h][32 i][4]"""
+    L = S.shape[0]
+    return S.reshape(L, 8, 32, 32, 2, 4).permute(0, 3, 1, 4, 2, 5).reshape(-1)
+
+
 def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
     """iw/ib: 9 effective ImplicitNet weights/biases ([out,in] as nn.Linear); rw/rb: 5 RenderingNet ones (or None).
     Returns the re-laid-out (and, for sweeps that contract over the output index, transposed) copies the
-    kernels read.  Tiny (<= 256x304) device ops once per step."""
+    kernels read.  The seven 256-wide trunk layers are handled as ONE [7, 256, 256] tensor (the per-layer entries of
+    pk["W"] / pk["WT"] are views of it): ~70 small device ops per pack instead of ~290 -- what a 1 280-ray training
+    step, which packs once per step, spends its host time on."""
     dev = iw[0].device
     pk = {}
-    W = []
     w0 = torch.zeros(256, spec.K0, device=dev)
     w0[:, :spec.E] = iw[0][:, :spec.E]  # the 45 MANO pose-cond columns multiply zeros (shape_net.py:104-106)
-    W.append(w0)
-    W += [iw[1].contiguous(), iw[2].contiguous(), iw[3].contiguous()]
-    W.append((iw[4] / math.sqrt(2)).contiguous())  # cat([x, input]) / sqrt(2) folded into the weight
-    W += [iw[5].contiguous(), iw[6].contiguous(), iw[7].contiguous()]
+    S = torch.zeros(7, 256, 256, device=dev)  # trunk layers 1..7, rows zero-padded to 256 (layer 3 has 217)
+    for l in range(1, 8):
+        src = iw[l] / math.sqrt(2) if l == 4 else iw[l]  # cat([x, input]) / sqrt(2) folded into the weight
+        S[l - 1, :src.shape[0]] = src
     w8 = torch.cat([iw[8][1:], iw[8][:1]], 0).contiguous()  # rows: feat(256) then sdf
-    W.append(w8)
+    W = [w0] + [S[l - 1][:iw[l].shape[0]] for l in range(1, 8)] + [w8]
     pk["W"] = W
     pk["b"] = [b.contiguous() for b in ib[:8]] + [torch.cat([ib[8][1:], ib[8][:1]]).contiguous()]
     pk["iw0_cols"] = iw[0].shape[1]
@@ -124,43 +157,28 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
     pk["b8_sdf_f"] = float(ib[8][0])  # the one host read of a pack (kernel scalar argument)
     pk["W8_feat"], pk["b8_feat"] = w8[:256], pk["b"][8][:256]  # lin8 without its sdf row (a 257th column costs a whole tile)
     # transposes [K_l][pad4(N_l)] for the sweeps that contract over the output index
-    WT = []
-    for l in range(9):
-        n, k = W[l].shape
-        wt = torch.zeros(k, pad4(n), device=dev)
-        wt[:, :n] = W[l].t()
-        WT.append(wt)
-    pk["WT"] = WT
-    pk["WT8_feat"] = W[8][:256].t().contiguous()  # [k = 256 trunk units][n = 256 feature rows]: lin8's input gradient
+    ST = S.transpose(1, 2).contiguous()  # [7][k][n], columns n >= N_l zero
+    wt8 = torch.zeros(256, pad4(257), device=dev)
+    wt8[:, :257] = w8.t()
+    pk["WT"] = [w0.t().contiguous()] + [ST[l - 1][:, :pad4(iw[l].shape[0])] for l in range(1, 8)] + [wt8]
+    pk["WT8_feat"] = w8[:256].t().contiguous()  # [k = 256 trunk units][n = 256 feature rows]: lin8's input gradient
     # fragment-ordered pack for the fused SDF-only kernel (hold_fused_sdf)
-    parts = []
-    for l in range(8):
-        wl = W[l]
-        if wl.shape[0] < 256:
-            wl = torch.cat([wl, torch.zeros(256 - wl.shape[0], wl.shape[1], device=dev)], 0)
-        ch = wl.shape[1] // 8
-        parts.append(wl.reshape(8, 32, ch, 2, 4).permute(2, 0, 3, 1, 4).reshape(-1))
+    frag0 = w0.reshape(8, 32, spec.K0 // 8, 2, 4).permute(2, 0, 3, 1, 4).reshape(-1)
     bias8 = torch.zeros(8, 256, device=dev)
+    full = [l for l in range(8) if pk["b"][l].shape[0] == 256]
+    bias8[full] = torch.stack([pk["b"][l] for l in full])
     for l in range(8):
-        bias8[l, :pk["b"][l].shape[0]] = pk["b"][l]
-    pk["fused"] = (torch.cat(parts).contiguous(), bias8.contiguous())
+        if l not in full:
+            bias8[l, :pk["b"][l].shape[0]] = pk["b"][l]
+    pk["fused"] = (torch.cat([frag0, frag_pack_stack(S)]), bias8)
     if config.x6():
-        pk["fused_x6"] = pack_x6(W[:8])
+        pk["fused_x6"] = torch.cat([pack_x6([w0]), pack_x6_stack(S)])
     # descending sweeps (hold_chain DSP): layer j contracts over the outputs of trunk layer l = 7 - j, M_j = W_l^T
-    parts = []
-    for l in range(7, 0, -1):
-        m = torch.zeros(256, 256, device=dev)
-        m[:W[l].shape[1], :W[l].shape[0]] = W[l].t()
-        parts.append(m.reshape(8, 32, 32, 2, 4).permute(2, 0, 3, 1, 4).reshape(-1))
-    pk["chain_bwd"] = torch.cat(parts).contiguous()
+    STf = ST.flip(0)
+    pk["chain_bwd"] = frag_pack_stack(STf)
     if config.x6():  # limb packs of the same matrices for hold_chain_x6 (the forward-type sweeps share the sampler trunk's)
         pk["chain_fwd_x6"] = pk["fused_x6"]
-        mats = []
-        for l in range(7, 0, -1):
-            m = torch.zeros(256, 256, device=dev)
-            m[:W[l].shape[1], :W[l].shape[0]] = W[l].t()
-            mats.append(m)
-        pk["chain_bwd_x6"] = pack_x6(mats, first_k=256)
+        pk["chain_bwd_x6"] = pack_x6_stack(STf)
     if rw is None:  # implicit net only (ImplicitNet.forward / gradient)
         return pk
     r0 = torch.zeros(256, spec.Kr, device=dev)
@@ -169,13 +187,8 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
     pk["R"] = R
     pk["rb"] = [b.contiguous() for b in rb]
     if need_bwd:
-        RT = []
-        for l in range(5):
-            n, k = R[l].shape
-            rt = torch.zeros(k, pad4(n), device=dev)
-            rt[:, :n] = R[l].t()
-            RT.append(rt)
-        pk["RT"] = RT
+        RT123 = torch.stack(R[1:4]).transpose(1, 2).contiguous()
+        pk["RT"] = [r0.t().contiguous(), RT123[0], RT123[1], RT123[2], None]  # the head's input gradient: hold_head3_bwd
     return pk
 
 
@@ -398,8 +411,7 @@ class NodeField:
         P, pk, h, xc = sv["P"], sv["pk"], sv["h"], sv["xc"]
         dev = self.device
         W, WT = pk["W"], pk["WT"]
-        dW = [torch.zeros_like(m) for m in W]
-        dWb = [torch.zeros_like(b) for b in pk["b"]]
+        dW, dWb = zeros_like_many(W, pk["b"])
         G.wgrad(ob, h[7], dW[8], dWb[8], N=257, accumulate=True)
         r7 = pool.get("r7", P, 256)
         G.gemm_nt(ob, WT[8], r7, epi=G.EPI_MUL_DSP, aux1=h[7], K=260)
@@ -439,8 +451,7 @@ class NodeField:
         P, pk, h, t, xc = sv["P"], sv["pk"], sv["h"], sv["t"], sv["xc"]
         dev = self.device
         W, WT = pk["W"], pk["WT"]
-        dW = [torch.zeros_like(m) for m in W]
-        dWb = [torch.zeros_like(b) for b in pk["b"]]
+        dW, dWb = zeros_like_many(W, pk["b"])
         gb = pool.get("gbar", P, 4)
         K.copy_cols(gbar.contiguous(), gb, 3, P)
         gebar = pool.get("gebar", P, sp.K0)
@@ -471,10 +482,7 @@ class NodeField:
         h, t, rin, r, rgb, xc = sv["h"], sv["t"], sv["rin"], sv["r"], sv["rgb"], sv["xc"]
         dev = self.device
         W, WT, R, RT = pk["W"], pk["WT"], pk["R"], pk["RT"]
-        dR = [torch.zeros_like(m) for m in R]
-        dRb = [torch.zeros_like(b) for b in pk["rb"]]
-        dW = [torch.zeros_like(m) for m in W]
-        dWb = [torch.zeros_like(b) for b in pk["b"]]
+        dR, dRb, dW, dWb = zeros_like_many(R, pk["rb"], W, pk["b"])
         # ---------- rendering net ----------
         dy = pool.get("dy4", P, 4)
         sg = rgb[:, :3]

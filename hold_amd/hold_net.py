@@ -20,7 +20,7 @@ import torch.nn.functional as F
 from . import config
 from . import gemm as G
 from . import kernels as K
-from .field import FEAT, FieldSpec, NodeField, Pool, pack_weights, pad4
+from .field import FEAT, FieldSpec, NodeField, Pool, pack_weights, pad4, zeros_like_many
 from .fitting import seal_mano_mesh
 from .geometry import MeshIndex, PointInSpace, compute_mano_cano_sdf, sample_on_barycentric_mesh, subdivide_loop
 from .mano import MANOServer, ObjectServer
@@ -780,8 +780,7 @@ class Background(nn.Module):
         ob = pool.get("out_bar", P, 260)
         K.copy_cols(d_rin[:, 59:59 + FEAT], ob, FEAT, P)
         K.copy_cols(d_sdf, ob[:, 256:257], 1, P)
-        dW = [torch.zeros_like(w) for w in W]
-        dWb = [torch.zeros(w.shape[0], device=dev) for w in W]
+        dW, dWb = zeros_like_many(W, [w[:, 0] for w in W])
         WT = []
         for l in range(9):
             n, k = W[l].shape

@@ -1,0 +1,57 @@
+"""CPU: hold_amd.field.pack_weights (stacked, few device ops) against the matrix-by-matrix construction of the same
+layouts (tests/pack_reference.py) -- every entry bit-identical, for both node kinds and both arithmetics."""
+import pytest
+import torch
+
+import hold_amd
+from hold_amd import field as F
+
+import pack_reference as ref
+
+
+def _weights(kind, seed):
+    g = torch.Generator().manual_seed(seed)
+    spec = F.FieldSpec(kind)
+    dims = [(256, 84)] + [(256, 256)] * 2 + [(217, 256)] + [(256, 256)] * 4 + [(257, 256)]
+    iw = [torch.randn(n, k, generator=g) / k ** 0.5 for n, k in dims]
+    ib = [torch.randn(n, generator=g) * 0.1 for n, _ in dims]
+    rdims = [(256, spec.rin_dim)] + [(256, 256)] * 3 + [(3, 256)]
+    rw = [torch.randn(n, k, generator=g) / k ** 0.5 for n, k in rdims]
+    rb = [torch.randn(n, generator=g) * 0.1 for n, _ in rdims]
+    return spec, iw, ib, rw, rb
+
+
+def _same(a, b, path):
+    if a is None or b is None:
+        return  # RT[4] is no longer built (the colour head has its own kernels)
+    if torch.is_tensor(a):
+        assert a.shape == b.shape and a.dtype == b.dtype, (path, a.shape, b.shape, a.dtype, b.dtype)
+        assert torch.equal(a, b), path
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b), path
+        for i, (x, y) in enumerate(zip(a, b)):
+            _same(x, y, f"{path}[{i}]")
+    else:
+        assert a == b, path
+
+
+@pytest.mark.parametrize("kind", ["hand", "object"])
+@pytest.mark.parametrize("mode", ["f32x6", "f32"])
+@pytest.mark.parametrize("with_render", [True, False])
+def test_pack_weights_matches_the_matrix_by_matrix_layouts(kind, mode, with_render):
+    prev = hold_amd.precision()
+    hold_amd.set_precision(mode)
+    try:
+        spec, iw, ib, rw, rb = _weights(kind, 3)
+        args = (spec, iw, ib, rw if with_render else None, rb if with_render else None, True)
+        new, old = F.pack_weights(*args), ref.pack_weights(*args)
+        assert set(new) == set(old)
+        for k in old:
+            _same(new[k], old[k], k)
+        # what the kernels require of the per-layer views: unit inner stride, 16-byte aligned rows
+        for k in ("W", "WT") + (("R", "RT") if with_render else ()):
+            for t in new[k]:
+                if t is not None:
+                    assert t.stride(-1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0, k
+    finally:
+        hold_amd.set_precision(prev)
