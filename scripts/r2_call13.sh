@@ -1,5 +1,7 @@
 #!/bin/bash
-# Round-2 GPU call 13: ping-pong layer chains (chain_x6pp_kernel, developer library switch) against the product kernel
+# Round-2 GPU call 13 (provenance): A/B harness used for the wide / ping-pong / full-height layer-chain variants against the
+# product kernel (developer-library switch HOLD_CHAIN_X6_PP, variants since removed -- DESIGN.md section 4 has the numbers;
+# with the current library both legs time the product kernel)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 F='Warning\|warnings.warn\|WeightNorm\|kaiming'
