@@ -119,8 +119,10 @@ int hold_embed_bwd2(const float* x, int32_t ldx, int32_t L, const float* barf_w,
  * with inverse LBS when xc_out != NULL:  w = sum_k softmax-like conf_k * W[idx_k]  (detached),
  * x_c = (sum_j w_j T_j)^-1 [x;1].   Replaces pytorch3d.ops.knn_points + KNNDeformer.forward /
  * query_skinning_weights_multi / skinning (code/src/model/mano/deformer.py:34-68, :84-105, :145-170).
- * verts: [B][n_verts][3] with frame stride verts_frame_stride floats (0 = shared canonical verts);
- * skin_w [n_verts][16]; tfs [B][16][4][4]; w_out [P][16] (nullable); xc_out [P][ldxc] (nullable). */
+ * verts: [B][n_verts][3] with frame stride verts_frame_stride floats (0 = shared canonical verts), 60 <= n_verts <= 800;
+ * skin_w [n_verts][16] (16-byte aligned); tfs [B][16][4][4]; w_out [P][16] (nullable); xc_out [P][ldxc] (nullable).
+ * The K smallest distances are selected exactly as a full insertion scan in vertex order would (ties: lower index first);
+ * internally a threshold from every 4th vertex and a one-bit-per-vertex filter cut the insertions to ~100 per point. */
 int hold_knn_invlbs_fwd(const float* x, int32_t ldx, int64_t P, int64_t pts_per_frame, const float* verts,
                         int64_t verts_frame_stride, int32_t n_verts, const float* skin_w, const float* tfs,
                         float* w_out, float* xc_out, int32_t ldxc, hold_stream_t stream);
