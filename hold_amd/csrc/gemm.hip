@@ -1,19 +1,22 @@
-// fp32 matrix-core GEMMs for the HOLD MLPs (gfx950 / CDNA4 only).
+// Matrix-core GEMMs for the HOLD MLPs (gfx950 / CDNA4 only).
 //
-//   hold_gemm_nt : C[P][N] = epi(alpha * A[P][K] . W[N][K]^T + bias)   (layer forward, input-gradient,
-//                  backward-data and double-backward sweeps; the caller passes W or W^T)
-//   hold_wgrad   : dW[N][K] = R[P][N]^T . X[P][K]                        (weight gradients, reduction over points)
+//   hold_gemm_nt[_x6] : C[P][N] = epi(alpha * A[P][K] . W[N][K]^T + bias [+ row[p] * col[n]])   (layer forward, input
+//                       gradient, backward-data and double-backward sweeps; the caller passes W or W^T)
+//   hold_wgrad[_x6]   : dW[N][K] = R[P][N]^T . X[P][K]                      (weight gradients, reduction over points)
+//   hold_wcolsum      : out[n] = sum_p w[p] X[p][n]                         (rank-1 companion of wgrad, HBM streaming)
+//   hold_head3_fwd/bwd: the 3-output colour head and its backward           (HBM streaming)
 //
-// Both run on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TFLOP/s peak).  Roofline: MFMA-bound;
-// algorithmic work 2*P*N*K flop per launch, HBM traffic (P*(K+N) + N*K)*4 bytes.
+// Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 operands, 157 TFLOP/s peak) or, in the _x6 entry points, both operands
+// split exactly into three bf16 limbs as their fragments leave LDS and 6 of the 9 limb products on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Roofline: MFMA-bound; algorithmic work 2*P*N*K flop per launch, HBM
+// traffic (P*(K+N) + N*K)*4 bytes.
 //
-// Tiling (hold_gemm_nt): 256 threads = 4 waves as 2(points) x 2(outputs); block tile 128 points x 128
-// outputs, wave tile 64x64 = 2x2 MFMA tiles (64 accumulator VGPRs), K stepped by 32 through a
-// double-buffered LDS stage (2 x (128+128) x 36 floats = 72 KiB -> two blocks per CU, 2 waves/SIMD).
-// The k index is permuted inside a 32-chunk so that each lane fetches 16 contiguous floats with four
-// ds_read_b128 (lane half h supplies k = 16h + s to MFMA step s); A and W use the same permutation,
-// so products pair up and only the fp32 summation order differs from a sequential dot product.
-// LDS row stride 36 floats makes the b128 fragment reads and the b128 staging writes conflict-free.
+// Tiling (hold_gemm_nt): 256 threads = 4 waves as 2(points) x 2(outputs); block tile 128 points x 256 outputs (128 x 128
+// for N <= 128), wave tile 64 x 128 = 2 x 4 MFMA tiles, K stepped by 16 (32 for the narrow tile) through a
+// double-buffered LDS stage filled by global_load_lds (69.6 KiB -> two blocks per CU, 2 waves/SIMD).
+// The k index is permuted inside a stage so that each lane fetches contiguous 16-byte chunks with ds_read_b128; A and W
+// use the same permutation, so products pair up and only the fp32 summation order differs from a sequential dot product.
+// The 16-byte chunk index is XOR-swizzled by the row (on the DMA source address and on the fragment reads): conflict-free.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
