@@ -366,6 +366,80 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(hold_gemm_desc d, int t
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const int n = n0 + wn * (32 * NT) + half * 64 + c4;
+      // Fast path (wave-uniform): the wave's 64 x 64 sub-tile lies inside the matrix and every access is a 16-byte one.
+      // Branch-free, eight rows at a time: the side inputs of eight rows are requested together, then consumed -- the
+      // generic loop below waits out one memory latency per row (load, s_waitcnt, store), 16 times per sub-tile.
+      const int nlim = d.N < d.n_split ? d.N : d.n_split;
+      const bool fast = vec_ok && (m0 + wm * 64 + 64 <= (long)d.P) && (n0 + wn * (32 * NT) + half * 64 + 64 <= nlim);
+      if (fast) {
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, r1c = {0.f, 0.f, 0.f, 0.f};
+        if (d.bias) bias4 = *reinterpret_cast<const f32x4*>(d.bias + n);
+        if (d.r1_row) r1c = *reinterpret_cast<const f32x4*>(d.r1_col + n);
+        constexpr bool AUX1 = EPI == HOLD_EPI_MUL_DSP || EPI == HOLD_EPI_MUL_DRELU || EPI == HOLD_EPI_DBWD ||
+                              EPI == HOLD_EPI_MUL_DSIG;
+        const bool aux2 = (EPI == HOLD_EPI_DBWD) || (EPI == HOLD_EPI_MUL_DSP && d.aux2 != nullptr);
+        const bool prev = (EPI == HOLD_EPI_NONE) && d.accumulate;
+        // rows per group: 8 with at most one side input, 4 with two (the other half's accumulators are still live)
+        constexpr int GR = (EPI == HOLD_EPI_NONE || EPI == HOLD_EPI_MUL_DSP || EPI == HOLD_EPI_DBWD) ? 4 : 8;
+#pragma unroll
+        for (int it0 = 0; it0 < 16; it0 += GR) {
+          f32x4 v[GR], a1[GR], a2[GR];
+          float r1r[GR];
+#pragma unroll
+          for (int j = 0; j < GR; ++j) {
+            const int row = (it0 + j) * 4 + (lane >> 4);
+            const long p = m0 + wm * 64 + row;
+            v[j] = *reinterpret_cast<const f32x4*>(sc + row * CSTR + c4);
+            if (AUX1) a1[j] = *reinterpret_cast<const f32x4*>(d.aux1 + p * (long)d.ldaux1 + n);
+            if (aux2) a2[j] = *reinterpret_cast<const f32x4*>(d.aux2 + p * (long)d.ldaux2 + n);
+            if (prev) a2[j] = *reinterpret_cast<const f32x4*>(d.C + p * (long)d.ldc + n);
+            if (d.r1_row) r1r[j] = d.r1_row[p * (long)d.ldr1];
+          }
+#pragma unroll
+          for (int j = 0; j < GR; ++j) {
+            const int row = (it0 + j) * 4 + (lane >> 4);
+            const long p = m0 + wm * 64 + row;
+            f32x4 y = v[j] * d.alpha + bias4;
+            if (d.r1_row) y += r1c * r1r[j];
+            f32x4 r = y;
+            if (EPI == HOLD_EPI_NONE) {
+              if (prev) r += a2[j];
+            } else if (EPI == HOLD_EPI_SOFTPLUS) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) r[c] = softplus100(y[c]);
+            } else if (EPI == HOLD_EPI_RELU) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) r[c] = fmaxf(y[c], 0.f);
+            } else if (EPI == HOLD_EPI_SIGMOID) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) r[c] = 1.0f / (1.0f + __expf(-y[c]));
+            } else if (EPI == HOLD_EPI_MUL_DSP) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) r[c] = y[c] * dsp_from_h(a1[j][c]);
+              if (aux2) r += a2[j];
+            } else if (EPI == HOLD_EPI_MUL_DRELU) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) r[c] = a1[j][c] > 0.f ? y[c] : 0.f;
+            } else if (EPI == HOLD_EPI_DBWD) {
+              f32x4 r2;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const float e = __expf(-100.0f * a1[j][c]);
+                r[c] = y[c] * dsp_from_h(a1[j][c]);
+                r2[c] = 100.0f * y[c] * a2[j][c] * e;
+              }
+              *reinterpret_cast<f32x4*>(d.out2 + p * (long)d.ldout2 + n) = r2;
+            } else if (EPI == HOLD_EPI_MUL_DSIG) {
+              r = y * a1[j] * (1.0f - a1[j]);
+            }
+            *reinterpret_cast<f32x4*>(d.C + p * (long)d.ldc + n) = r;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        continue;
+      }
 #pragma unroll 4
       for (int it = 0; it < 16; ++it) {
         const int row = it * 4 + (lane >> 4);
