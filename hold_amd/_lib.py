@@ -147,6 +147,8 @@ SIGNATURES = {
     "hold_mt_vertices": [_P, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P],
     "hold_mt_triangles": [_P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P],
     "hold_fused_sdf_x6": [_P, _I, _L, _P, _P, _P, _F, _P, _P, _I, _P],
+    "hold_fused_sdf_r6": [_P, _I, _L, _P, _P, _P, _F, _P, _P, _I, _P],
+    "hold_trunk_r6": [_P, _I, _L, _P, _P, _P, C.POINTER(C.c_void_p), _I, _P],
     "hold_mano_lbs_fwd": [C.POINTER(ManoModel), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "hold_mano_lbs_bwd": [C.POINTER(ManoModel), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
 }
@@ -159,6 +161,7 @@ def _declare(L):
     L.hold_reduce_workspace_floats.restype = C.c_int64
     L.hold_fused_sdf_pack_floats.restype = C.c_int64
     L.hold_fused_sdf_x6_pack_bytes.restype = C.c_int64
+    L.hold_trunk_r6_pack_bytes.restype = C.c_int64
     L.hold_chain_pack_floats.argtypes = [C.c_int32, C.c_int32]
     L.hold_chain_pack_floats.restype = C.c_int64
     L.hold_chain_x6_pack_bytes.argtypes = [C.c_int32, C.c_int32]

@@ -1,0 +1,470 @@
+// Register-resident trunk of the ImplicitNet (gfx950): lin0..lin7 of ImplicitNet.forward (code/src/networks/shape_net.py:84-130)
+// for 128 points per workgroup with NO activation traffic through LDS or HBM between layers.
+//
+// Structure (one wave per SIMD, 4 waves = 256 threads, one workgroup per CU, persistent over point blocks):
+//   * a wave owns 32 points for the whole network.  Every layer is D[feature][point] = W (A operand, rows = output
+//     features) x act (B operand, columns = points) on v_mfma_f32_32x32x16_bf16 with the exact three-limb bf16 split of
+//     both operands (six limb products, fp32 accumulation -- the arithmetic of hold_fused_sdf_x6 / hold_chain_x6).
+//   * the 256 x 32 fp32 outputs of a layer stay in the wave's registers (8 accumulator tiles): lane (hh, li) holds, for
+//     point li, features 32 nt + 8 g + 4 hh + k in register 4 g + k of tile nt.  Registers 8 q .. 8 q + 7 of tile nt are
+//     therefore 8 values of ONE point -- exactly what a B-operand lane holds for one 16-wide k step -- so the next layer
+//     contracts over the "virtual" k order  k-step j = (nt, q) = (j / 2, j % 2),  element e of lane half hh  <->
+//     feature 32 nt + 16 q + 8 (e / 4) + 4 hh + e % 4,  and the host packs the weight limbs in that same order
+//     (hold_amd/field.py:pack_r6).  No transpose, no cross-lane traffic: softplus + limb split of the previous layer's
+//     accumulators (pure VALU) is interleaved with the MFMAs of the current k step ("input stationary": each k step's
+//     B limbs feed 48 MFMAs into the 8 accumulator tiles of the layer being computed).
+//   * the weight limbs are the only stream: 24 KiB per k step (8 n-tiles x 3 limbs x 1 KiB fragments), brought into a
+//     5-slot LDS ring by LDS-DMA (global_load_lds_dwordx4, six 1 KiB pieces per wave and k step, issued four steps
+//     ahead) and read by all four waves with conflict-free lane-linear ds_read_b128 -- one L2 read of each weight byte
+//     per 128 points (the 8-wave kernels read it twice per 128 points), one raw s_barrier per k step, counted vmcnt.
+//
+// Entry points: hold_fused_sdf_r6 (the sampler's SDF query: embedding in-kernel, sdf = w8 . h7 + b8 out) and
+// hold_trunk_r6 (training forward: additionally stores h_0..h_7, the skip layer's columns 217.. = the embedding).
+// Roofline: bf16 MFMA pipe (6 limb products issued per algorithmic product); algorithmic HBM bytes per point:
+// 16 in + 4 out (sdf) / + 8 KiB of h stores (trunk).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "../../include/hold_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int NW = 4;                 // waves per workgroup (one per SIMD)
+constexpr int BPTS = 32 * NW;         // points per workgroup pass
+constexpr int PIECE = 1024;           // one MFMA A fragment for a wave: 64 lanes x 16 B
+constexpr int SLOT = 24 * PIECE;      // one k step: [8 n-tiles][3 limbs] fragments
+constexpr int RING = 5;               // LDS slots; NSTEP % RING == 0 keeps slot = step % RING across blocks
+constexpr int L0S = 3, LKS = 16;      // k steps of layer 0 (K = 48, 39 used) and of the 256-wide layers
+constexpr int NSTEP = L0S + 7 * LKS;  // 115 k steps per block of points
+constexpr int NE = 39, EMB_STR = 52, SKIP_OUT = 217;
+constexpr int OFF_BIAS = RING * SLOT;               // [8][256] fp32
+constexpr int OFF_W8 = OFF_BIAS + 8 * 256 * 4;      // [256] fp32
+constexpr int OFF_EMB = OFF_W8 + 256 * 4;           // [4 waves][32 points][EMB_STR] fp32 (wave-private)
+constexpr int OFF_BARF = OFF_EMB + NW * 32 * EMB_STR * 4;  // [64] fp32: BARF weights of the 39 embedding columns (or 1)
+constexpr int LDS_BYTES = OFF_BARF + 64 * 4;
+static_assert(NSTEP % RING == 0, "slot index must not depend on the block iteration");
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+
+struct R6Args {
+  const float* xc; int ldx; long P;
+  const char* wpack;    // hold_trunk_r6_pack_bytes() bytes, [NSTEP][24 pieces][64 lanes][8 bf16]
+  const float* bias;    // [8][256]
+  const float* w8;      // [256] sdf row of lin8 (HEAD)
+  float b8;
+  const float* barf;    // [39] or null
+  float* sdf; int lds;  // HEAD output
+  float* h[8]; int ldh; // STORE outputs ([P][ldh], columns 0..255)
+};
+
+__device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ float bitsf(uint32_t x) { return __builtin_bit_cast(float, x); }
+
+// max(y, 0) as ONE v_max_i32 (fmaxf costs a canonicalising v_max y,y first)
+__device__ __forceinline__ float relu1(float y) {  // sign bit set <=> negative as an integer
+  const int b = __builtin_bit_cast(int, y);
+  return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
+// value-only softplus (sampler queries): max(y,0) + ln2/100 * log2(1 + 2^(-100 log2e |y|)), abs error <= 6e-10
+__device__ __forceinline__ float sp_fast(float y) {
+  const float e = __builtin_amdgcn_exp2f(-144.26950408889634f * fabsf(y));
+  return fmaf(0.0069314718056f, __builtin_amdgcn_logf(1.0f + e), relu1(y));
+}
+// training softplus: log1p by series where 1 + e would round e away (the backward sweeps recover softplus' from the
+// stored h, so small h need relative accuracy); y > 0.2 returns y as the reference's threshold branch does
+__device__ __forceinline__ float sp_train(float y) {
+  const float e = __builtin_amdgcn_exp2f(-144.26950408889634f * fabsf(y));
+  const float lg = 0.0069314718056f * __builtin_amdgcn_logf(1.0f + e);
+  const float ser = (0.01f * e) * fmaf(e, fmaf(e, 0.33333334f, -0.5f), 1.0f);
+  const float l = (e > 1e-3f) ? lg : ser;
+  const float r = relu1(y) + l;
+  return (y > 0.2f) ? y : r;
+}
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const float* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, p ? bytes : 0u, 0x00020000);
+}
+
+struct Limbs { u32x4 l[3]; };  // three bf16x8 B fragments, as dwords (dword d = elements 2 d, 2 d + 1)
+
+// exact truncation split of two fp32 values into one dword of each of the three bf16 limb fragments
+struct Split3 { uint32_t p1, p2, p3; };
+__device__ __forceinline__ Split3 split2(float x0, float x1) {
+  const uint32_t b0 = fbits(x0), b1 = fbits(x1);
+  const float r0 = x0 - bitsf(b0 & 0xffff0000u), r1 = x1 - bitsf(b1 & 0xffff0000u);
+  const uint32_t c0 = fbits(r0), c1 = fbits(r1);
+  const float s0 = r0 - bitsf(c0 & 0xffff0000u), s1 = r1 - bitsf(c1 & 0xffff0000u);
+  Split3 o;
+  o.p1 = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+  o.p2 = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
+  o.p3 = __builtin_amdgcn_perm(fbits(s1), fbits(s0), 0x07060302u);
+  return o;
+}
+// the three dwords are made opaque HERE: pure VALU code has no side effects, so without the pin LLVM sinks the whole
+// next-step epilogue to its first use (the end of the k step) instead of leaving a quarter of it in each MFMA group
+__device__ __forceinline__ void put_limbs(Limbs& out, int c, Split3 s) {
+  asm volatile("" : "+v"(s.p1), "+v"(s.p2), "+v"(s.p3));
+  out.l[0][c] = s.p1;
+  out.l[1][c] = s.p2;
+  out.l[2][c] = s.p3;
+}
+
+// Six 1 KiB pieces of k step `step` into ring slot `slot` (pieces 6 w .. 6 w + 5 are wave w's) by LDS-DMA.
+// Issued from inline assembly on purpose: hipcc models the global_load_lds builtin as a FLAT access that may touch LDS,
+// which makes it wait lgkmcnt(0) at every later ds_read use -- the fragment prefetch of the next MFMA group would be
+// waited for together with the current one's.  The DMA is invisible to the compiler's counters; its completion is
+// counted by hand (R6_WAIT_VM before the rendezvous barrier).  M0 = LDS destination of lane 0; the instruction offset
+// advances BOTH the global and the LDS address (pieces 0..3), pieces 4..5 take a second base pair.
+template <int DMAV>
+__device__ __forceinline__ void dma_step(const char* wpack, uint32_t lane16, int step, int slot, int wave) {
+  const char* src = wpack + (long)step * SLOT + wave * (6 * PIECE);  // wave-uniform
+  const uint32_t dst = (uint32_t)(slot * SLOT + wave * (6 * PIECE));  // dynamic LDS starts at byte 0 of the allocation
+  uint32_t keep;
+  if (DMAV == 1) {  // developer-build cross-check: no instruction offsets, M0 and the base pair advanced per piece
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %8\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %4\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %5\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %6\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %7\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane16), "s"(src), "s"(src + PIECE), "s"(src + 2 * PIECE), "s"(src + 3 * PIECE), "s"(src + 4 * PIECE),
+          "s"(src + 5 * PIECE), "s"(dst)
+        : "memory");
+    return;
+  }
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %4\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+      "s_mov_b32 m0, %5\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %3\n\t"
+      "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(lane16), "s"(src), "s"(src + 4 * PIECE), "s"(dst), "s"(dst + 4 * PIECE)
+      : "memory");
+}
+
+#define R6_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+template <bool HEAD, bool STORE, int DMAV = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rmlp_kernel(R6Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, li = lane & 31;
+  const uint32_t lane16 = lane * 16;
+  float* embw = reinterpret_cast<float*>(smem + OFF_EMB) + wave * (32 * EMB_STR);
+  const char* ring_lane = smem + lane * 16;
+
+  // ---- once per workgroup: biases (+ the sdf row) into LDS, the first four k steps into the ring ----
+  for (int i = tid; i < 8 * 256; i += 256) reinterpret_cast<float*>(smem + OFF_BIAS)[i] = a.bias[i];
+  if (HEAD) reinterpret_cast<float*>(smem + OFF_W8)[tid] = a.w8[tid];
+  if (tid < 64) reinterpret_cast<float*>(smem + OFF_BARF)[tid] = (a.barf && tid < NE) ? a.barf[tid] : 1.0f;
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 4; ++s) dma_step<DMAV>(a.wpack, lane16, s, s, wave);
+
+  constexpr int VPER = HEAD ? 2 : 4;  // VALU instructions of the next step's epilogue per MFMA (12 MFMAs per group)
+  f32x16 P[8], Q[8];
+  u32x4 A[2][6];  // weight fragments of two n-tiles x three limbs, double-buffered
+  Limbs Bc, Bn;
+
+  auto read_pair = [&](int slot, int pair, u32x4 (&dst)[6]) {
+    const char* base = ring_lane + slot * SLOT + pair * (6 * PIECE);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dst[i] = *reinterpret_cast<const u32x4*>(base + i * PIECE);
+  };
+  auto mfma12 = [&](int pair, const u32x4 (&af)[6], const Limbs& b) {
+#pragma unroll
+    for (int pr = 0; pr < 6; ++pr) {
+      const int wl = (pr == 2 || pr == 3) ? 1 : (pr == 5 ? 2 : 0);  // (w limb, act limb): 00 01 10 11 02 20
+      const int al = (pr == 1 || pr == 3) ? 1 : (pr == 4 ? 2 : 0);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        Q[2 * pair + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[3 * t + wl]),
+                                                                 __builtin_bit_cast(bf16x8, b.l[al]), Q[2 * pair + t],
+                                                                 0, 0, 0);
+    }
+  };
+  auto init_bias = [&](int layer) {
+    const float* bl = reinterpret_cast<const float*>(smem + OFF_BIAS) + layer * 256 + 4 * hh;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bl + 32 * nt + 8 * g);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Q[nt][4 * g + k] = b[k];
+      }
+  };
+
+  int first = 1;
+  for (long blk = blockIdx.x; blk * BPTS < a.P; blk += gridDim.x) {
+    const long p0 = blk * BPTS + wave * 32;  // this wave's first point
+    long prow = p0 + li;
+    const bool prow_ok = prow < a.P;
+    prow = prow_ok ? prow : a.P - 1;
+    // ---- embedding of this wave's 32 points -> wave-private LDS [32][EMB_STR] (embedders.py:18-50): lane half hh takes
+    // the frequencies 3 hh .. 3 hh + 2 of its point (9 sincosf), half 0 also the raw coordinates, half 1 the zero padding
+    {
+      const float* xr = a.xc + prow * a.ldx;
+      const float x3[3] = {xr[0], xr[1], xr[2]};
+      float* er = embw + li * EMB_STR;
+      const float* bw = reinterpret_cast<const float*>(smem + OFF_BARF);
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        const int k = 3 * hh + kk;
+        const float f = (float)(1 << k);
+#pragma unroll
+        for (int dim = 0; dim < 3; ++dim) {
+          float sn, cs;
+          sincosf(x3[dim] * f, &sn, &cs);
+          const int j = 3 + 6 * k + dim;
+          er[j] = sn * bw[j];
+          er[j + 3] = cs * bw[j + 3];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) er[hh ? NE + i : i] = hh ? 0.f : x3[i] * bw[i];
+#pragma unroll
+      for (int i = 3; i < 9; ++i)
+        if (hh) er[NE + i] = 0.f;
+    }
+    if (first) {  // step 0 of the very first block: everybody's pieces landed
+      R6_WAIT_VM(18);
+      __builtin_amdgcn_s_barrier();
+      read_pair(0, 0, A[0]);
+      first = 0;
+    }
+
+    // One k step of the layer being accumulated into Q.  `t` = step index in the block's stream (slot t % RING).
+    // nextB(c) produces dword c (two values) of the NEXT step's limbs into Bn; it is spread over the four MFMA groups.
+    auto kstep = [&](int t, auto&& nextB) {
+      const int slot = t % RING;
+#pragma unroll
+      for (int pair = 0; pair < 4; ++pair) {
+        if (pair < 3) {
+          read_pair(slot, pair + 1, A[(pair + 1) & 1]);
+        } else {
+          read_pair((t + 1) % RING, 0, A[0]);  // landed: this step's mid barrier
+        }
+        if (pair == 2) {  // mid-step rendezvous: step t + 1 complete in LDS, slot of step t - 1 free
+          R6_WAIT_VM(12);
+          __builtin_amdgcn_s_barrier();
+          dma_step<DMAV>(a.wpack, lane16, (t + 4) % NSTEP, (t + 4) % RING, wave);
+        }
+        mfma12(pair, A[pair & 1], Bc);
+        nextB(pair);
+        // placement inside the group: the fragment reads for the next group first (their latency runs under this group's
+        // MFMAs), then one MFMA / a few VALU of the next step's epilogue alternating; the six DMA issues of the
+        // rendezvous group go between MFMAs as well
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x2, VPER, 0);
+          if (pair == 2 && (i & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      Bc = Bn;
+    };
+    auto no_next = [](int) {};
+
+    // ---- layer 0: B limbs straight from the embedding (natural k order 16 j + 8 hh + e) ----
+    auto emb_limbs = [&](int j, int c, Limbs& out) {
+      const float* er = embw + li * EMB_STR + 16 * j + 8 * hh + 2 * c;
+      put_limbs(out, c, split2(er[0], er[1]));
+    };
+    init_bias(0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) emb_limbs(0, c, Bc);
+#pragma unroll
+    for (int j = 0; j < L0S; ++j) {
+      if (j + 1 < L0S)
+        kstep(j, [&](int c) { emb_limbs(j + 1, c, Bn); });
+      else
+        kstep(j, no_next);
+    }
+
+    // ---- layers 1..7: input = softplus of the previous layer's accumulators ----
+    float part = 0.f;  // HEAD: this lane's share of w8 . h7
+    // STORE: h rows through a buffer descriptor (rows >= P fall outside num_records: the hardware drops those stores)
+    rsrc_t hrs = make_rsrc(nullptr, 0);
+    const uint32_t hbytes = (uint32_t)(a.P * a.ldh * 4);
+    const uint32_t hvoff = (uint32_t)(((p0 + li) * a.ldh + 4 * hh) * 4);
+    // dword c of k step j = (nt, q): values P[nt][8 q + 2 c], +1 = features 32 nt + 16 q + 8 (c / 2) + 4 hh + 2 (c % 2), +1
+    auto act_limbs = [&](int layer, int j, int c, Limbs& out, f32x4& keep) {
+      const int nt = j >> 1, q = j & 1;
+      const int f0 = 32 * nt + 16 * q + 8 * (c >> 1) + 4 * hh + 2 * (c & 1);
+      float v0 = HEAD ? sp_fast(P[nt][8 * q + 2 * c]) : sp_train(P[nt][8 * q + 2 * c]);
+      float v1 = HEAD ? sp_fast(P[nt][8 * q + 2 * c + 1]) : sp_train(P[nt][8 * q + 2 * c + 1]);
+      if (j >= 13) {  // skip connection: columns 217.. of layer 3's output are the embedding (shape_net.py:122-123)
+        const bool sk = layer == 4;
+        const int m0 = f0 - SKIP_OUT;
+        const float e0 = embw[li * EMB_STR + (m0 < 0 ? 0 : m0)], e1 = embw[li * EMB_STR + (m0 + 1 < 0 ? 0 : m0 + 1)];
+        v0 = (sk && m0 >= 0) ? e0 : v0;
+        v1 = (sk && m0 + 1 >= 0) ? e1 : v1;
+      }
+      put_limbs(out, c, split2(v0, v1));
+      if (STORE) {
+        keep[2 * (c & 1)] = v0;
+        keep[2 * (c & 1) + 1] = v1;
+        if (c & 1)  // four consecutive features of this lane's point: one 16-byte store of h_{layer-1}
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, keep), hrs, hvoff,
+                                                 (32 * nt + 16 * q + 8 * (c >> 1)) * 4, 0);
+      }
+    };
+    for (int layer = 1; layer < 8; ++layer) {
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        P[nt] = Q[nt];
+        // the finished layer stays in the ACCUMULATOR half of the register file (the epilogue reads each value once,
+        // through v_accvgpr_read): the 256 VALU-addressable registers are left to fragments, limbs and temporaries
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+a"(P[nt][r]));
+      }
+      init_bias(layer);
+      const int t0 = L0S + (layer - 1) * LKS;
+      f32x4 keep;
+      if (STORE) hrs = make_rsrc(a.h[layer - 1], hbytes);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) act_limbs(layer, 0, c, Bc, keep);
+#pragma unroll
+      for (int j = 0; j < LKS; ++j) {
+        if (j + 1 < LKS)
+          kstep(t0 + j, [&](int c) { act_limbs(layer, j + 1, c, Bn, keep); });
+        else
+          kstep(t0 + j, no_next);
+      }
+    }
+    // ---- output of layer 7 ----
+    {
+      const float* w8l = reinterpret_cast<const float*>(smem + OFF_W8);
+      const rsrc_t h7rs = make_rsrc(STORE ? a.h[7] : nullptr, STORE ? hbytes : 0);
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int f0 = 32 * nt + 8 * g + 4 * hh;
+          f32x4 v;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = HEAD ? sp_fast(Q[nt][4 * g + k]) : sp_train(Q[nt][4 * g + k]);
+          if (HEAD) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(w8l + f0);
+            part += v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+          }
+          if (STORE)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), h7rs, hvoff, (32 * nt + 8 * g) * 4, 0);
+        }
+      if (HEAD) {
+        const float s = part + __shfl_xor(part, 32) + a.b8;
+        if (hh == 0 && prow_ok) a.sdf[prow * a.lds] = s;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t hold_trunk_r6_pack_bytes(void) { return (int64_t)NSTEP * SLOT; }
+
+static int rmlp_launch(const R6Args& a, bool head, bool store, hipStream_t s) {
+  static int n_cu = 0;
+  static bool attr_set = false;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return HOLD_E_LAUNCH;
+    n_cu = prop.multiProcessorCount;
+  }
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)rmlp_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)rmlp_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LDS_BYTES) != hipSuccess)
+      return HOLD_E_LAUNCH;
+    attr_set = true;
+  }
+  const long blocks = (a.P + BPTS - 1) / BPTS;
+  const dim3 grid((unsigned)(blocks < n_cu ? blocks : n_cu));
+#ifdef HOLD_DEV
+  if (const char* v = getenv("HOLD_R6_DMA")) {
+    if (v[0] == '1' && head && !store) {
+      static bool set1 = false;
+      if (!set1 && hipFuncSetAttribute((const void*)rmlp_kernel<true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       LDS_BYTES) != hipSuccess)
+        return HOLD_E_LAUNCH;
+      set1 = true;
+      hipLaunchKernelGGL((rmlp_kernel<true, false, 1>), grid, dim3(256), LDS_BYTES, s, a);
+      return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+    }
+  }
+#endif
+  if (head && !store)
+    hipLaunchKernelGGL((rmlp_kernel<true, false>), grid, dim3(256), LDS_BYTES, s, a);
+  else if (store && !head)
+    hipLaunchKernelGGL((rmlp_kernel<false, true>), grid, dim3(256), LDS_BYTES, s, a);
+  else
+    return HOLD_E_ARG;
+  return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+}
+
+// SDF-only query of the sampler (the contract of hold_fused_sdf_x6 with the register-resident trunk).
+extern "C" int hold_fused_sdf_r6(const float* xc, int32_t ldx, int64_t P, const void* wpack_r6, const float* bias,
+                                 const float* w8, float b8, const float* barf_w, float* sdf, int32_t ld_sdf,
+                                 hold_stream_t st) {
+  if (!xc || !wpack_r6 || !bias || !w8 || !sdf || ldx < 3 || ld_sdf < 1 || P < 0) return HOLD_E_ARG;
+  if (((uintptr_t)wpack_r6 & 15) || ((uintptr_t)w8 & 15) || ((uintptr_t)bias & 15)) return HOLD_E_ARG;
+  if (P == 0) return HOLD_OK;
+  R6Args a = {};
+  a.xc = xc; a.ldx = ldx; a.P = (long)P; a.wpack = (const char*)wpack_r6; a.bias = bias; a.w8 = w8; a.b8 = b8;
+  a.barf = barf_w; a.sdf = sdf; a.lds = ld_sdf;
+  return rmlp_launch(a, true, false, (hipStream_t)st);
+}
+
+// Training forward trunk: h[l] [P][ldh] (l = 0..7) = softplus outputs of lin0..lin7; columns 217..255 of h[3] receive
+// the embedding (the skip concat of shape_net.py:122-123, 1/sqrt2 folded into the packed lin4).
+extern "C" int hold_trunk_r6(const float* xc, int32_t ldx, int64_t P, const void* wpack_r6, const float* bias,
+                             const float* barf_w, float* const* h, int32_t ldh, hold_stream_t st) {
+  if (!xc || !wpack_r6 || !bias || !h || ldx < 3 || ldh < 256 || (ldh & 3) || P < 0) return HOLD_E_ARG;
+  if (((uintptr_t)wpack_r6 & 15) || ((uintptr_t)bias & 15)) return HOLD_E_ARG;
+  R6Args a = {};
+  for (int l = 0; l < 8; ++l) {
+    if (!h[l] || ((uintptr_t)h[l] & 15)) return HOLD_E_ARG;
+    a.h[l] = h[l];
+  }
+  if (P == 0) return HOLD_OK;
+  if (((uint64_t)P + 128) * (uint64_t)ldh * 4 >= (1ull << 32)) return HOLD_E_ARG;  // 32-bit buffer offsets: split by rows
+  a.xc = xc; a.ldx = ldx; a.P = (long)P; a.wpack = (const char*)wpack_r6; a.bias = bias; a.barf = barf_w; a.ldh = ldh;
+  return rmlp_launch(a, false, true, (hipStream_t)st);
+}

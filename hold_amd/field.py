@@ -126,6 +126,29 @@ def pack_x6_stack(S):
     return limbs.reshape(3, L, 8, 32, 16, 2, 8).permute(1, 4, 0, 2, 5, 3, 6).reshape(-1)
 
 
+def r6_kmap(device=None):
+    """virtual k order of hold_trunk_r6 for the 256-wide layers: kmap[j, h, e] = input feature that element e of lane half h
+    holds in k step j = the register order of the previous layer's v_mfma_f32_32x32x16_bf16 outputs (csrc/rmlp.hip)"""
+    j = torch.arange(16, device=device).view(16, 1, 1)
+    h = torch.arange(2, device=device).view(1, 2, 1)
+    e = torch.arange(8, device=device).view(1, 1, 8)
+    return 32 * (j // 2) + 16 * (j % 2) + 8 * (e // 4) + 4 * h + e % 4
+
+
+def pack_r6(w0, S):
+    """limb pack of hold_fused_sdf_r6 / hold_trunk_r6 (include/hold_hip.h): w0 [256, <=48] (layer 0, zero-padded to K = 48),
+    S [7, 256, 256] (layers 1..7, rows zero-padded, lin4 pre-scaled) -> bf16 [115 steps][8 nt][3 t][2 h][32 i][8 e]"""
+    dev = S.device
+    m0 = torch.zeros(256, 48, device=dev)
+    m0[:, :w0.shape[1]] = w0
+    l0 = torch.stack(split_limbs(m0))  # [3, 256, 48] = (t, 32 nt + i, 16 j + 8 h + e)
+    p0 = l0.reshape(3, 8, 32, 3, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(-1)
+    lk = torch.stack(split_limbs(S))  # [3, 7, 256, 256]
+    g = lk[:, :, :, r6_kmap(dev)]  # [3 t, 7 L, 256 out, 16 j, 2 h, 8 e]
+    pk = g.reshape(3, 7, 8, 32, 16, 2, 8).permute(1, 4, 2, 0, 5, 3, 6).reshape(-1)
+    return torch.cat([p0, pk]).contiguous()
+
+
 def frag_pack_stack(S):
     """fp32 MFMA-fragment order of hold_fused_sdf / hold_chain for L [256, 256] matrices:
     per matrix [K/8 chunks][8 n-tiles][2 h][32 i][4]"""
@@ -173,6 +196,7 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
     pk["fused"] = (torch.cat([frag0, frag_pack_stack(S)]), bias8)
     if config.x6():
         pk["fused_x6"] = torch.cat([pack_x6([w0]), pack_x6_stack(S)])
+        pk["trunk_r6"] = pack_r6(w0, S)
     # descending sweeps (hold_chain DSP): layer j contracts over the outputs of trunk layer l = 7 - j, M_j = W_l^T
     STf = ST.flip(0)
     pk["chain_bwd"] = frag_pack_stack(STf)

@@ -118,6 +118,34 @@ def fused_sdf_x6(xc, P, wpack_x6, bias8, w8, b8, barf_w, out_sdf):
     _g._prof_end(e0, 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256), "fused_sdf_kernel")
 
 
+def fused_sdf_r6(xc, P, wpack_r6, bias8, w8, b8, barf_w, out_sdf):
+    """register-resident trunk (csrc/rmlp.hip) with the contract of fused_sdf_x6; wpack_r6 from field.pack_r6."""
+    assert wpack_r6.numel() * wpack_r6.element_size() == _lib.lib().hold_trunk_r6_pack_bytes()
+    from . import gemm as _g
+    e0 = _g._prof_begin()
+    call("hold_fused_sdf_r6", ptr(xc), _ld(xc), P, ptr(wpack_r6), ptr(bias8), ptr(w8), float(b8), ptr(barf_w),
+         ptr(out_sdf), _ld(out_sdf))
+    _g._prof_end(e0, 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256), "fused_sdf_kernel")
+
+
+_TRUNK_MAX_ROWS = ((1 << 32) // 1024 - 1) // 128 * 128
+
+
+def trunk_r6(xc, P, wpack_r6, bias8, barf_w, h):
+    """training forward trunk: h[0..7] [P,256] = softplus outputs of lin0..lin7 (h[3][:, 217:] = the embedding)."""
+    import ctypes as C
+    assert wpack_r6.numel() * wpack_r6.element_size() == _lib.lib().hold_trunk_r6_pack_bytes()
+    from . import gemm as _g
+    ld = h[0].stride(0)
+    assert all(t.stride(0) == ld and t.stride(1) == 1 for t in h)
+    for r0 in range(0, P, _TRUNK_MAX_ROWS):
+        n = min(_TRUNK_MAX_ROWS, P - r0)
+        arr = (C.c_void_p * 8)(*[t[r0:].data_ptr() for t in h])
+        e0 = _g._prof_begin()
+        call("hold_trunk_r6", ptr(xc[r0:]), _ld(xc), n, ptr(wpack_r6), ptr(bias8), ptr(barf_w), arr, ld)
+        _g._prof_end(e0, 2.0 * n * (40 * 256 + 6 * 65536 + 217 * 256), "chain_kernel")
+
+
 CHAIN_SOFTPLUS, CHAIN_DSP, CHAIN_DBWD = 0, 1, 2
 
 

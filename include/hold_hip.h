@@ -307,6 +307,27 @@ int hold_fused_sdf_x6(const float* xc, int32_t ldx, int64_t P, const void* wpack
                       float b8, const float* barf_w, float* sdf, int32_t ld_sdf, hold_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Register-resident trunk (hold_amd/csrc/rmlp.hip): lin0..lin7 of ImplicitNet.forward (shape_net.py:84-130) with the
+ * layer outputs kept in the wave's accumulator registers -- one wave per SIMD owns 32 points for the whole network, the
+ * previous layer's accumulators become the next layer's MFMA B operand after softplus + limb split in registers, the weight
+ * limbs are the only stream (LDS-DMA ring shared by the four waves of a workgroup).  Split-precision arithmetic of
+ * hold_fused_sdf_x6 (three bf16 limbs of both operands, six products, fp32 accumulation).
+ * wpack_r6: hold_trunk_r6_pack_bytes() bytes of bf16, [115 k steps][8 n-tiles nt][3 limbs t][2 halves h][32 rows i][8 e]:
+ *   k steps 0..2   = layer 0 (K = 48, columns 39.. zero):  limb_t(W_0)[32 nt + i][16 step + 8 h + e]
+ *   k steps 3 + 16 (l - 1) + j, j = 0..15 = layer l = 1..7 (rows / scaling as for hold_fused_sdf):
+ *                    limb_t(W_l)[32 nt + i][32 (j / 2) + 16 (j % 2) + 8 (e / 4) + 4 h + e % 4]
+ *   (the order in which a lane holds the previous layer's outputs after v_mfma_f32_32x32x16_bf16).
+ * hold_fused_sdf_r6: the contract of hold_fused_sdf_x6 (the sampler's SDF query).
+ * hold_trunk_r6: training forward, h[l] [P][ldh] (l = 0..7) = softplus outputs of lin0..lin7, columns 217..255 of h[3] =
+ *   the embedding (skip concat); replaces embed + hold_chain_x6(SOFTPLUS) of the forward trunk.
+ * ---------------------------------------------------------------------------------------- */
+int64_t hold_trunk_r6_pack_bytes(void);
+int hold_fused_sdf_r6(const float* xc, int32_t ldx, int64_t P, const void* wpack_r6, const float* bias, const float* w8,
+                      float b8, const float* barf_w, float* sdf, int32_t ld_sdf, hold_stream_t stream);
+int hold_trunk_r6(const float* xc, int32_t ldx, int64_t P, const void* wpack_r6, const float* bias, const float* barf_w,
+                  float* const* h, int32_t ldh, hold_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * LDS-resident layer chains of the ImplicitNet for the TRAINING path (hold_amd/csrc/chain.hip): up to 8 consecutive
  * 256-wide layers of one sweep in one launch; the running activation stays in LDS, per-layer side inputs are read
  * from and per-layer results written to HBM directly from the accumulators.  Replaces n_layers hold_gemm_nt calls of

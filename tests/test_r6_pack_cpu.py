@@ -1,0 +1,94 @@
+"""Index algebra of the register-resident trunk (hold_amd/csrc/rmlp.hip) checked on the CPU: a lane-level numpy model of
+v_mfma_f32_32x32x16_bf16 (operand / accumulator register layout of /opt/skills/guides/cdna_hip_programming.md section 3)
+runs the kernel's dataflow -- the previous layer's accumulator registers 8 q .. 8 q + 7 of tile nt ARE the B operand of
+k step j = 2 nt + q -- on the weight stream produced by hold_amd.field.pack_r6, and must reproduce a plain
+ImplicitNet trunk (shape_net.py:84-130: softplus(beta = 100), skip concat at layer 4).  This pins pack_r6 / r6_kmap and
+the feature <-> register formulas the kernel uses; the arithmetic itself is tested on the GPU (test_rmlp_gpu.py)."""
+import numpy as np
+import torch
+
+from hold_amd.field import pack_r6
+
+NSTEP, L0S, LKS, SKIP = 115, 3, 16, 217
+
+
+def mfma_32x32x16(A_lane, B_lane, acc):
+    """A_lane / B_lane [64 lanes][8]: lane l holds A[i = l % 32][k = 8 (l // 32) + e] / B[k = 8 (l // 32) + e][j = l % 32];
+    acc [16 regs][64 lanes]: lane l holds D[i = 8 g + 4 (l // 32) + r][j = l % 32] in register 4 g + r."""
+    A = np.zeros((32, 16))
+    B = np.zeros((16, 32))
+    for l in range(64):
+        A[l % 32, 8 * (l // 32):8 * (l // 32) + 8] = A_lane[l]
+        B[8 * (l // 32):8 * (l // 32) + 8, l % 32] = B_lane[l]
+    D = A @ B
+    for l in range(64):
+        for g in range(4):
+            for r in range(4):
+                acc[4 * g + r, l] += D[8 * g + 4 * (l // 32) + r, l % 32]
+
+
+def softplus100(y):
+    return np.maximum(y, 0) + np.log1p(np.exp(-np.abs(100 * y))) / 100
+
+
+def test_r6_stream_reproduces_the_trunk():
+    g = torch.Generator().manual_seed(3)
+    w0 = torch.randn(256, 40, generator=g) * 0.2
+    w0[:, 39] = 0
+    S = torch.randn(7, 256, 256, generator=g) * 0.08
+    S[2, SKIP:] = 0  # layer 3 has 217 outputs (rows zero-padded)
+    bias = torch.randn(8, 256, generator=g) * 0.05
+    bias[3, SKIP:] = 0
+    emb = torch.randn(32, 48, generator=g)
+    emb[:, 39:] = 0
+    pack = pack_r6(w0, S).float().numpy().reshape(NSTEP, 8, 3, 2, 32, 8).astype(np.float64)
+    Wsum = pack.sum(2)  # limbs add up exactly: [step][nt][h][i][e]
+    A_frag = Wsum.reshape(NSTEP, 8, 64, 8)  # lane = 32 h + i
+    b = bias.numpy().astype(np.float64)
+    x = emb.numpy().astype(np.float64)
+    lanes = np.arange(64)
+    hh, li = lanes // 32, lanes % 32
+
+    def init(layer):
+        acc = np.zeros((8, 16, 64))
+        for nt in range(8):
+            for gq in range(4):
+                for r in range(4):
+                    acc[nt, 4 * gq + r] = b[layer, 32 * nt + 8 * gq + 4 * hh + r]
+        return acc
+
+    # layer 0: B limbs from the embedding in natural k order
+    Q = init(0)
+    for j in range(L0S):
+        Bl = np.stack([x[li[l], 16 * j + 8 * hh[l]:16 * j + 8 * hh[l] + 8] for l in range(64)])
+        for nt in range(8):
+            mfma_32x32x16(A_frag[j, nt], Bl, Q[nt])
+    for layer in range(1, 8):
+        P, Q = Q, init(layer)
+        t0 = L0S + (layer - 1) * LKS
+        for j in range(LKS):
+            nt_in, q = j // 2, j % 2
+            Bl = softplus100(P[nt_in, 8 * q:8 * q + 8, :]).T.copy()  # [lane][e]
+            if layer == 4:  # kernel: value e of lane half hh is feature f; columns 217.. come from the embedding
+                for l in range(64):
+                    for e in range(8):
+                        f = 32 * nt_in + 16 * q + 8 * (e // 4) + 4 * hh[l] + e % 4
+                        if f >= SKIP:
+                            Bl[l, e] = x[li[l], f - SKIP]
+            for nt in range(8):
+                mfma_32x32x16(A_frag[t0 + j, nt], Bl, Q[nt])
+    h7 = np.zeros((32, 256))
+    for nt in range(8):
+        for gq in range(4):
+            for r in range(4):
+                for l in range(64):
+                    h7[li[l], 32 * nt + 8 * gq + 4 * hh[l] + r] = softplus100(Q[nt, 4 * gq + r, l])
+
+    # plain trunk
+    W = [w0.numpy().astype(np.float64)] + [S[i].numpy().astype(np.float64) for i in range(7)]
+    a = x[:, :40]
+    for layer in range(8):
+        if layer == 4:
+            a = np.concatenate([a[:, :SKIP], x[:, :39]], 1)
+        a = softplus100(a @ W[layer].T[:a.shape[1]] + b[layer])
+    assert np.abs(h7 - a).max() < 1e-9, np.abs(h7 - a).max()
