@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 matrix)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 matrix, same guide
-ROUND = "r02"
+ROUND = "r03"
 
 
 def parse():
@@ -57,14 +57,19 @@ def parse():
     ap.add_argument("--fp32-mfma", action="store_true", help="true-fp32 MFMA everywhere (no split-precision kernels)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-refine", action="store_true", help="--mode c3: skip the pose-refinement leg")
+    ap.add_argument("--no-freeze", action="store_true",
+                    help="let Adam move the weights during the run (default: the flat parameter bucket is restored after "
+                         "every optimiser step, inside the timed region, so that every step sees the same SDF and runs the "
+                         "same number of sampler rounds -- the workload of step 1 is the workload of step K)")
     ap.add_argument("--shape-report", default="", help="write per-(kernel, flop bucket) launch aggregates to this json file")
     return ap.parse_args()
 
 
-def cpu_baseline(sc, sd_np, threads=32, repeats=3):
+def cpu_baseline(sc, sd_np, threads=32, repeats=10, n_frames=4):
     """The CPU oracle (torch restatement of the reference's PyTorch path, oracle/hold_oracle.py) timed on the host:
-    the reference's own training batch shape -- up to 10 frames (the synthetic scene has 8) x 128 random pixels
-    (general.yaml:82, tempo_dataset.py:27-36) -- fwd + loss + backward, median of `repeats` steps."""
+    training steps of the reference's batch layout -- frames x 128 random pixels each (general.yaml:82,
+    tempo_dataset.py:27-36; 4 of the reference's 10 frames per step so that the >= 10 steps SURVEY 8(d) asks for stay a
+    bounded sample of about a minute) -- fwd + loss + backward, median over `repeats` steps."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from hold_amd import synthetic as syn
     from hold_amd.train import pixel_losses
@@ -78,7 +83,7 @@ def cpu_baseline(sc, sd_np, threads=32, repeats=3):
     mano = {"right": syn.make_mano_model(True), "left": syn.make_mano_model(False)}
     osc = ho.OracleScene(sc, mano)
     sd = {k: torch.as_tensor(v) for k, v in sd_np.items()}
-    frames = list(range(min(10, sc["n_frames"])))
+    frames = list(range(min(n_frames, sc["n_frames"])))
     W = 512
     times = []
     for rep in range(repeats):
@@ -109,9 +114,24 @@ def cpu_baseline(sc, sd_np, threads=32, repeats=3):
         times.append(time.time() - t0)
     med = float(np.median(times))
     return {"value": N / med, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"{repeats} training steps of the reference's batch shape ({len(frames)} frames x 128 pixels = {N} rays), fwd + rgb/sem "
-                      f"loss + backward, median step {med:.2f} s; oracle/hold_oracle.py (torch CPU restatement of the "
-                      f"reference, pinned to it by tests/golden), {cores} of {os.cpu_count()} host threads"}
+            "sample": f"{repeats} training steps of {len(frames)} frames x 128 random pixels = {N} rays each (the reference's batch "
+                      f"layout, general.yaml:82; its own step is 10 frames), fwd + rgb/semantic loss + backward -- lighter than "
+                      f"the GPU step, which also evaluates the loss-target geometry, the full Loss and Adam; median step "
+                      f"{med:.2f} s; kind 'port': oracle/hold_oracle.py, the torch-CPU restatement pinned to the reference by "
+                      f"tests/golden -- the reference tree itself is not present on the GPU box; {cores} torch threads of "
+                      f"{os.cpu_count()} host hardware threads (torch's intra-op pool stops scaling near 32 on these tensors)"}
+
+
+# ALGORITHMIC FLOP per ray of SURVEY.md 8(d): linear layers only, 1 MAC = 2 FLOP
+F_IMP, F_REND_HAND, F_REND_OBJ, F_BGIMP, F_BGREND = 1_049_088, 532_992, 549_376, 1_065_472, 81_408
+
+
+def flop_per_ray(node_ids, mean_iters, S, n0, training):
+    """sum_n I_n * n0 * F_imp (sampler queries, no grad) + sum_n S * (2 F_imp + F_rend_n) + 32 (F_bgimp + F_bgrend);
+    fwd + bwd = sampler term + 3 x the rest (fwd + dX + dW; the reverse sweep is the "2 F_imp")"""
+    samp = sum(mean_iters[n] * n0 * F_IMP for n in node_ids)
+    rest = sum(S * (2 * F_IMP + (F_REND_OBJ if n == "object" else F_REND_HAND)) for n in node_ids) + 32 * (F_BGIMP + F_BGREND)
+    return samp + (3 if training else 1) * rest
 
 
 def gemm_shapes(prof):
@@ -130,7 +150,7 @@ def gemm_shapes(prof):
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the separate rocprofv3 --pmc passes of this same command
     (scripts/pmc.sh -> profiles/<round>_pmc_traffic.json, FETCH_SIZE doubled per the gfx950 calibration)."""
-    for rnd in (ROUND, "r01"):
+    for rnd in (ROUND, "r02", "r01"):
         f = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
         if os.path.exists(f):
             k = json.load(open(f)).get("kernels", {}).get(kernel)
@@ -205,6 +225,7 @@ def main():
                                      node.params.betas.weight[:1])
                     node.spawn_cano_mano(so)
     opt = FlatAdam(net, lr=5e-4, clip_norm=0.5) if training else None
+    frozen = opt.flat.clone() if (training and not args.no_freeze) else None
 
     uv = syn.make_uv(W, H)
     if args.mode == "c3":  # the reference's batch: 10 frames x 128 random pixels, a different draw every step
@@ -239,6 +260,8 @@ def main():
         else:
             lv, _ = train_step(net, inp, args.chunk, step=i + 1, epoch=0, loss_fn=loss_fn)
         opt.step()
+        if frozen is not None:  # same weights (hence the same SDF, sampler rounds and FLOP per ray) at every step
+            opt.flat.copy_(frozen)
         return lv
 
     for i in range(args.warmup):
@@ -249,6 +272,8 @@ def main():
     if not args.no_profile:
         gemm.PROFILE = []
     from hold_amd import _lib as _L
+    for node in net.nodes.values():
+        node.ray_sampler.sum_iters = node.ray_sampler.n_calls = 0
     calls0 = _L.CALLS
     t0 = time.perf_counter()
     rays = 0
@@ -270,6 +295,11 @@ def main():
     if rank == 0:
         total_rays = rays * world
         iters = {nid: node.ray_sampler.last_iters for nid, node in net.nodes.items()}
+        mean_iters = {nid: node.ray_sampler.sum_iters / max(1, node.ray_sampler.n_calls) for nid, node in net.nodes.items()}
+        smp = next(iter(net.nodes.values())).ray_sampler
+        S_node = smp.N_samples + 2 + smp.N_samples_extra
+        fpr = flop_per_ray(list(net.nodes), mean_iters, S_node, smp.N_samples_eval, training)
+        fpr4 = flop_per_ray(list(net.nodes), {n: 4.0 / len(net.nodes) for n in net.nodes}, S_node, smp.N_samples_eval, training)
         x6 = hold_amd.precision() == "f32x6"
         scene = ("configs[3]-like ARCTIC two-hand (right+left+object+background), " if args.two_hands else
                  "hold_bottle1_itw-like single-hand (right+object+background), ")
@@ -298,7 +328,14 @@ def main():
                       if x6 else "f32"),
             "data": "synthetic",
             "config": {"workload": workload, "chunk_rays": args.chunk if args.mode != "c3" else 1280,
-                       "sampler_rounds_last_call": iters, "loss_terms": args.loss if training else None,
+                       "sampler_rounds_last_call": iters, "sampler_rounds_mean_over_timed_calls": mean_iters,
+                       "sigma_I": sum(mean_iters.values()),
+                       "flop_per_ray": fpr, "flop_per_ray_note": "SURVEY 8(d) algorithmic FLOP (linear layers only) at the "
+                       "measured mean sampler rounds of the timed region",
+                       "rays_per_s_at_sigmaI_4": total_rays / dt * fpr / fpr4,
+                       "algorithmic_tflops_end_to_end": total_rays / dt * fpr / 1e12,
+                       "weights_frozen": frozen is not None,
+                       "loss_terms": args.loss if training else None,
                        "parallelism": f"dp{world} (frames sharded, one RCCL all-reduce of the flat gradient bucket)",
                        "loss": float(loss), "precision": hold_amd.precision(),
                        "steps_per_s": args.steps / dt},
@@ -315,41 +352,48 @@ def main():
             split = {"fused_sdf_kernel", "wgrad_kernel", "chain_kernel", "gemm_nt_kernel"} if x6 else set()
             labels = {"gemm_nt_kernel": ("gemm_nt_kernel<x6> (one layer per launch, 3-limb split on v_mfma_f32_32x32x16_bf16)"
                                          if x6 else "gemm_nt_kernel (one layer per launch, v_mfma_f32_32x32x2_f32)"),
-                      "chain_kernel": ("chain_x6_kernel (7-8 trunk layers per launch, LDS-resident, 3-limb split on "
-                                       "v_mfma_f32_32x32x16_bf16)" if x6 else
+                      "chain_kernel": ("chain_x6_kernel (backward / reverse sweeps: 7-8 trunk layers per launch, LDS-resident) + "
+                                       "rmlp_kernel<STORE> (forward trunk, register-resident), 3-limb split on "
+                                       "v_mfma_f32_32x32x16_bf16" if x6 else
                                        "chain_kernel (7-8 trunk layers per launch, LDS-resident, v_mfma_f32_32x32x2_f32)"),
-                      "fused_sdf_kernel": ("fused_sdf_x6p_kernel (sampler SDF queries, 3-limb split on v_mfma_f32_32x32x16_bf16)"
+                      "fused_sdf_kernel": ("rmlp_kernel<HEAD> (sampler SDF queries: register-resident trunk, 3-limb split on "
+                                           "v_mfma_f32_32x32x16_bf16)"
                                            if x6 else "fused_sdf_pipe_kernel (sampler SDF queries, v_mfma_f32_32x32x2_f32)"),
                       "wgrad_kernel": ("wgrad_lds_kernel<x6> (weight gradients, 3-limb split on v_mfma_f32_32x32x16_bf16)"
                                        if x6 else "wgrad_lds_kernel (weight gradients, v_mfma_f32_32x32x2_f32)")}
             ent = {}
             for name, (t_, fl_, n_) in agg.items():
                 tf = fl_ / t_ / 1e12
-                ent[name] = {"achieved": tf, "frac": tf / FP32_MFMA_PEAK_TFLOPS, "launches": n_,
-                             "avg_launch_ms": t_ / n_ * 1e3, "time_share": t_ / dt, "flop_per_launch_avg": fl_ / n_,
-                             "arithmetic": "f32x6" if name in split else "f32"}
-                if name in split:  # disclosure: algorithmic (fp32-equivalent) rate vs what the matrix cores actually issue
-                    ent[name]["fp32_equivalent_tflops"] = tf
-                    ent[name]["bf16_mfma_tflops_issued"] = 6.0 * tf
-                    ent[name]["frac_of_bf16_mfma_peak"] = 6.0 * tf / BF16_MFMA_PEAK_TFLOPS
-                    ent[name]["note"] = ("frac is fp32-equivalent FLOP/s over the fp32-MFMA peak (can exceed 1: the kernel does not "
-                                         "run on the fp32 pipe); frac_of_bf16_mfma_peak prices the 6 limb products it issues")
+                is6 = name in split
+                # split-precision kernels are priced on the pipe they run on: 6 bf16 limb products issued per algorithmic
+                # product, against the dense bf16 MFMA peak; the algorithmic (fp32-equivalent) rate is a named extra
+                ent[name] = {"achieved": 6.0 * tf if is6 else tf, "peak": BF16_MFMA_PEAK_TFLOPS if is6 else FP32_MFMA_PEAK_TFLOPS,
+                             "frac": (6.0 * tf / BF16_MFMA_PEAK_TFLOPS) if is6 else tf / FP32_MFMA_PEAK_TFLOPS,
+                             "launches": n_, "avg_launch_ms": t_ / n_ * 1e3, "time_share": t_ / dt,
+                             "flop_per_launch_avg": fl_ / n_, "arithmetic": "f32x6" if is6 else "f32",
+                             "fp32_equivalent_tflops": tf}
+                if is6:
+                    ent[name]["note"] = ("achieved = bf16 MFMA FLOP/s issued (6 limb products per algorithmic fp32 product), peak = "
+                                         "dense bf16 MFMA; fp32_equivalent_tflops = algorithmic FLOP / time")
             dom = max(ent, key=lambda k: ent[k]["time_share"])
             traffic, tsrc = pmc_traffic(dom)
-            res["roofline"] = {"bound": "mfma", "achieved": ent[dom]["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS,
+            res["roofline"] = {"bound": "mfma", "achieved": ent[dom]["achieved"], "peak": ent[dom]["peak"],
                                "unit": "TFLOP/s", "frac": ent[dom]["frac"], "traffic": traffic,
                                "kernel": labels.get(dom, dom), "launches": ent[dom]["launches"],
                                "avg_launch_ms": ent[dom]["avg_launch_ms"], "time_share": ent[dom]["time_share"],
                                "flop_per_launch_avg": ent[dom]["flop_per_launch_avg"],
                                "arithmetic": ent[dom]["arithmetic"],
+                               "fp32_equivalent_tflops": ent[dom]["fp32_equivalent_tflops"],
                                "traffic_note": f"HBM bytes/launch of this kernel from separate --pmc passes (profiles/{tsrc})",
                                "kernels": ent}
-            for k in ("fp32_equivalent_tflops", "bf16_mfma_tflops_issued", "frac_of_bf16_mfma_peak", "note"):
-                if k in ent[dom]:
-                    res["roofline"][k] = ent[dom][k]
+            if "note" in ent[dom]:
+                res["roofline"]["note"] = ent[dom]["note"]
             mf = sum(v[1] for v in agg.values())
+            mf6 = sum((6.0 if k in split else 1.0) * v[1] for k, v in agg.items())
             res["roofline"]["end_to_end"] = {"mfma_tflops_fp32_equivalent": mf / dt / 1e12,
-                                             "frac_of_fp32_mfma_peak": mf / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                             "mfma_tflops_issued": mf6 / dt / 1e12,
+                                             "frac_of_bf16_mfma_peak_issued": (mf6 / dt / 1e12 / BF16_MFMA_PEAK_TFLOPS) if x6 else None,
+                                             "frac_of_fp32_mfma_peak": None if x6 else mf / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                                              "time_in_mfma_kernels": sum(v[0] for v in agg.values()) / dt}
         res["config"]["c_abi_calls_per_step"] = (_L.CALLS - calls0) / args.steps
         if args.mode == "c3" and not args.no_refine:

@@ -92,6 +92,15 @@ __device__ __forceinline__ rsrc_t make_rsrc(const float* p, uint32_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, p ? bytes : 0u, 0x00020000);
 }
 
+// 16-byte row-fragment store.  The column offset goes into the instruction's immediate field (constant part of
+// voffset), NOT into soffset: with an SGPR soffset hipcc assumes the ">64-bit store data overwritten by the next VALU"
+// hazard away and re-uses the data registers right behind the store -- on gfx950 that corrupted the stored rows
+// (first hardware run of this kernel: the layer-7 block, where results are produced back to back, was wrong).
+__device__ __forceinline__ void store4(const f32x4& v, rsrc_t rs, uint32_t voff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, voff, 0, 0);
+  asm volatile("s_nop 3");
+}
+
 struct Limbs { u32x4 l[3]; };  // three bf16x8 B fragments, as dwords (dword d = elements 2 d, 2 d + 1)
 
 // exact truncation split of two fp32 values into one dword of each of the three bf16 limb fragments
@@ -340,8 +349,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         keep[2 * (c & 1)] = v0;
         keep[2 * (c & 1) + 1] = v1;
         if (c & 1)  // four consecutive features of this lane's point: one 16-byte store of h_{layer-1}
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, keep), hrs, hvoff,
-                                                 (32 * nt + 16 * q + 8 * (c >> 1)) * 4, 0);
+          store4(keep, hrs, hvoff + (32 * nt + 16 * q + 8 * (c >> 1)) * 4);
       }
     };
     for (int layer = 1; layer < 8; ++layer) {
@@ -384,7 +392,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             part += v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
           }
           if (STORE)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), h7rs, hvoff, (32 * nt + 8 * g) * 4, 0);
+            store4(v, h7rs, hvoff + (32 * nt + 8 * g) * 4);
         }
       if (HEAD) {
         const float s = part + __shfl_xor(part, 32) + a.b8;

@@ -28,6 +28,8 @@ FEAT = 256
 FUSED_SDF = os.environ.get("HOLD_FUSED_SDF", "1") != "0"  # sampler queries through the fused LDS-resident kernel
 # training-path sweeps as LDS-resident layer chains (hold_chain) instead of one hold_gemm_nt per layer
 USE_CHAIN = os.environ.get("HOLD_CHAIN", "1") != "0"
+# register-resident trunk (csrc/rmlp.hip) for the sampler queries and the training forward trunk (f32x6 arithmetic only)
+USE_R6 = os.environ.get("HOLD_R6", "1") != "0"
 RIN_FEAT, RIN_X, RIN_N, RIN_POSE, RIN_TIME = 0, 256, 259, 262, 270
 
 
@@ -238,10 +240,17 @@ class NodeField:
         return xc, w
 
     # ------------------------------------------------------------------ implicit net trunk
-    def _trunk(self, pk, xc, P, barf_w, keep_all):
+    def _trunk(self, pk, xc, P, barf_w, keep_all, need_in0=True):
         sp, pool = self.spec, self.pool
         in0 = pool.get("in0", P, sp.K0)
         h = [pool.get(f"h{l}" if (keep_all or l == 3) else f"h_pp{l & 1}", P, 256) for l in range(8)]
+        if USE_R6 and keep_all and "trunk_r6" in pk:
+            # register-resident trunk: embedding in-kernel, h_0..h_7 (and the skip columns of h_3) stored from the
+            # accumulator registers; the embedding matrix itself is only needed by the backward (layer-0 weight gradient)
+            if need_in0:
+                K.embed_fwd(xc, 3, sp.L, P, in0, barf_w=barf_w)
+            K.trunk_r6(xc, P, pk["trunk_r6"], pk["fused"][1], barf_w, h)
+            return in0, h
         K.embed_fwd(xc, 3, sp.L, P, in0, out2=h[3][:, sp.skip_out:], barf_w=barf_w)
         W, b = pk["W"], pk["b"]
         if USE_CHAIN and keep_all:
@@ -284,6 +293,9 @@ class NodeField:
         """no-grad SDF query of the sampler (sdf_func_with_deformer, volsdf_utils.py:150-169).  out_sdf [P,1]."""
         self.gen += 1  # overwrites the pooled canonical points a pending backward would read
         xc, _ = self._deform(x, P, ppf, dfm, want_w=False)
+        if FUSED_SDF and USE_R6 and "trunk_r6" in pk:
+            K.fused_sdf_r6(xc, P, pk["trunk_r6"], pk["fused"][1], pk["w8_sdf"], pk["b8_sdf_f"], barf_w, out_sdf)
+            return
         if FUSED_SDF and "fused_x6" in pk:
             K.fused_sdf_x6(xc, P, pk["fused_x6"], pk["fused"][1], pk["w8_sdf"], pk["b8_sdf_f"], barf_w, out_sdf)
             return
@@ -301,7 +313,7 @@ class NodeField:
         sp, pool = self.spec, self.pool
         self.gen += 1
         xc, w_def = self._deform(x, P, ppf, dfm, want_w=training)
-        in0, h = self._trunk(pk, xc, P, barf_w, keep_all=True)
+        in0, h = self._trunk(pk, xc, P, barf_w, keep_all=True, need_in0=training)
         rin = pool.get("rin", P, sp.Kr)
         sdf = pool.get("sdf", P, 1)
         # lin8 = 256 feature rows as a full-tile GEMM + the sdf row as a row dot (N = 257 would add a 256-wide tile for it)

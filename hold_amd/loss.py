@@ -80,6 +80,27 @@ class Loss(nn.Module):
         super().__init__()
         self.args = args
         self.milestone = 30000
+        # ray-chunked steps (hold_amd.train.train_step): off-surface ray counts per node, accumulated on the device over
+        # the chunks of the running step / the completed previous step
+        self._off_acc, self._off_prev = {}, {}
+
+    def _chunked_sparse_den(self, nid, cnt, first_chunk, scale):
+        """Denominator of a node's opacity-sparsity mean in a ray-chunked step.  The reference takes the mean over the
+        off-surface rays of the WHOLE batch (loss_terms.get_opacity_sparse_loss); a chunk only knows its own count, and
+        the later chunks' counts do not exist yet when this chunk is backpropagated.  Chunks are therefore normalised
+        by the previous step's whole-batch count (exact in steady state: the count moves by a few rays per step), in the
+        first step by the chunk's own count scaled to the batch -- so that the chunk terms ADD UP to one batch mean
+        instead of to `n_chunks` means.  Everything stays on the device (no host sync)."""
+        cnt = cnt.detach()
+        if first_chunk:
+            if nid in self._off_acc:
+                self._off_prev[nid] = self._off_acc[nid]
+            self._off_acc[nid] = cnt.clone()
+        else:
+            self._off_acc[nid] = self._off_acc.get(nid, torch.zeros_like(cnt)) + cnt
+        prev = self._off_prev.get(nid)
+        est = cnt * scale
+        return est if prev is None else torch.where(prev > 0, prev, est)
 
     def forward(self, batch, model_outputs):
         rgb = model_outputs["rgb"]
@@ -98,8 +119,15 @@ class Loss(nn.Module):
             rgb_loss = sums[0] / (sums[2] + 1e-6)  # valid_pix[nan_filter].sum() (loss.py:38-44)
         sem_loss = sums[1] / n_total
         opacity_sparse_loss = 0.0
-        for i in range(len(node_ids)):
-            opacity_sparse_loss = opacity_sparse_loss + sums[3 + 2 * i] / sums[4 + 2 * i]
+        chunked = "hold_amd.n_total" in batch
+        for i, nid in enumerate(node_ids):
+            num, cnt = sums[3 + 2 * i], sums[4 + 2 * i]
+            if chunked:
+                den = self._chunked_sparse_den(nid, cnt, bool(batch.get("hold_amd.frame_terms", True)), n_total / float(N))
+                # a chunk without off-surface rays contributes 0 (0 / 0 would poison the accumulated gradient bucket)
+                opacity_sparse_loss = opacity_sparse_loss + torch.where(den > 0, num / den.clamp_min(1.0), torch.zeros_like(num))
+            else:
+                opacity_sparse_loss = opacity_sparse_loss + num / cnt
         eikonal_loss = 0.0
         for k in model_outputs.keys():
             if "grad_theta" in k:

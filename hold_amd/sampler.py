@@ -61,6 +61,8 @@ class ErrorBoundSampler:
         self.sync_group = None
         self.pool = None
         self.last_iters = 0
+        self.sum_iters = 0  # rounds summed over all calls / number of calls (bench.py: FLOP per ray of a timed region)
+        self.n_calls = 0
 
     def _rand(self, shape, dev):
         if self.rng_device == "cpu":
@@ -164,6 +166,8 @@ class ErrorBoundSampler:
             K.sampler_sample(z, sdf, S, N, beta, False, self.add_tiny, u, ns, zs, None)
             break
         self.last_iters = iters
+        self.sum_iters += iters
+        self.n_calls += 1
         nx = self.N_samples_extra
         if nx > 0:
             if is_training:

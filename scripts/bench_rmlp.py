@@ -24,7 +24,8 @@ def timeit(fn, n=5):
     return e0.elapsed_time(e1) / n
 
 
-for P in (128 * 16384, 128 * 1280, 98 * 16384):
+PS = [int(a) for a in sys.argv[1:]] or [128 * 16384, 128 * 1280, 98 * 16384]
+for P in PS:
     xc = torch.zeros(P, 4, device=dev); xc[:, :3] = torch.rand(P, 3, device=dev) * 1.6 - 0.8
     out = torch.empty(P, 1, device=dev); out2 = torch.empty(P, 1, device=dev)
     flops = 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256)
@@ -43,6 +44,18 @@ for P in (128 * 16384, 128 * 1280, 98 * 16384):
         ms = timeit(chain)
         ms2 = timeit(lambda: K.trunk_r6(xc, P, pk["trunk_r6"], bias8, None, h2))
         fl = 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256)
-        d = max(float((a - b).abs().max()) for a, b in zip(h, h2))
+        dl = [float((a - b).abs().max()) for a, b in zip(h, h2)]
+        d = max(dl)
+        if d > 1e-3:  # diagnostics: which layer / column, and which of the two kernels is off a torch fp32 trunk on 512 rows
+            l = dl.index(d); idx = int((h[l] - h2[l]).abs().argmax()); r, c = idx // 256, idx % 256
+            print(f"  per-layer max diff {['%.1e' % v for v in dl]}; layer {l} row {r} col {c}: chain {float(h[l][r, c]):.6f} r6 {float(h2[l][r, c]):.6f}")
+            rows = slice(r - r % 128, r - r % 128 + 128)
+            cur = in0[rows, :39].double(); emb = cur
+            for ll in range(8):
+                W = pk["W"][ll].double()
+                cur = torch.nn.functional.softplus(cur @ W.t()[:cur.shape[1]] + pk["b"][ll].double()[:W.shape[0]], beta=100)
+                if ll == 3: cur = torch.cat([cur[:, :217], emb], 1)
+                print(f"    layer {ll}: |chain - ref| {float((h[ll][rows].double() - cur).abs().max()):.2e}  |r6 - ref| {float((h2[ll][rows].double() - cur).abs().max()):.2e}"
+                      f"  worst r6 col {int((h2[ll][rows].double() - cur).abs().max(0).values.argmax())}")
         print(f"fwd trunk P={P}: embed+chain_x6 {ms:.3f} ms {fl / ms / 1e9:.1f} TF-eq | trunk_r6 {ms2:.3f} ms {fl / ms2 / 1e9:.1f} TF-eq | "
               f"max diff {d:.2e}", flush=True)

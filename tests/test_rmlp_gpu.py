@@ -104,7 +104,7 @@ def test_trunk_r6_stores_every_layer(P, barf):
         err = (h[l].double() - cur).abs().max().item()
         assert err < 3e-5 * max(1.0, cur.abs().max().item()), (l, err)
         # small activations keep RELATIVE accuracy (the backward sweeps recover softplus' from the stored h)
-        small = cur < 1e-4
+        small = (cur < 1e-4) & (cur > 1e-30)  # below that exp2 flushes to zero: absolute error 1e-32
         if small.any() and l != 3:
             rel = ((h[l].double() - cur).abs() / cur)[small].max().item()
             assert rel < 1e-4, (l, rel)
