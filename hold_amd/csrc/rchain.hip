@@ -1,0 +1,507 @@
+// Register-resident BACKWARD sweeps of the ImplicitNet trunk (gfx950) -- the descending sweeps (d sdf / d a_l of the normal
+// path and the first-order backward) and the ascending second-order sweep that torch.autograd derives from
+// ImplicitNet.forward (code/src/networks/shape_net.py:84-130) under create_graph=True (code/src/engine/volsdf_utils.py:71-96),
+// in the structure of csrc/rmlp.hip: one wave per SIMD owns 32 points for the whole chain, a layer's 256 x 32 outputs stay
+// in the wave's accumulator registers, and -- after the per-layer epilogue -- ARE the next layer's MFMA B operand (the
+// "virtual k order" of rmlp.hip: k step j, element e of lane half hh <-> feature 16 j + 8 (e / 4) + 4 hh + e % 4).
+//
+//   RC_DSP   v_{l-1} = (M_j v_l) * sp'(aux1_j) [+ aux2_j]                         7 layers, input v_7 [P][256]
+//   RC_DBWD  tb = M_j vb ; out_j = tb * sp'(aux1_j) ; out2_j = 100 tb aux2_j (1 - sp'(aux1_j))   8 layers, input [P][40]
+//   (the semantics of hold_chain / hold_chain_x6 with skip_layer = 3, include/hold_hip.h)
+//
+// What streams: the weight limbs (24 KiB per 16-wide k step, LDS ring of 3 slots filled by LDS-DMA two steps ahead,
+// shared by the four waves) and, new here, the per-layer SIDE inputs -- for every k step the 8 stored h (and a2 / t)
+// values a lane needs are two (four) 16-byte row fragments: they are fetched by LDS-DMA too (lane-linear image, wave
+// private, ring of 3, two steps ahead), so no load ever has a register destination in flight and the compiler's
+// counters only see ds_reads and stores; completion of all DMA is counted by hand at the one rendezvous per k step
+// ("everything issued before this step began has landed").  The results (next layer's input) are stored with
+// 16-byte row-fragment stores straight from the epilogue.
+// Exposed per block of 128 points: loading the chain input (32 x 16 B per lane) and the epilogue of the LAST layer.
+// Roofline: bf16 MFMA pipe; HBM bytes per point and layer: DSP 2 KiB (1 side + 1 out), DSP + a2 3 KiB, DBWD 4 KiB.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hold_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int NW = 4, BPTS = 32 * NW, PIECE = 1024, SLOT = 24 * PIECE, R3 = 3;
+constexpr int SKIP_OUT = 217, IN_STR = 52;
+enum { RC_DSP = 1, RC_DBWD = 2 };
+
+struct RCArgs {
+  long P;
+  const char* wpack;      // DSP: 7 x 16 k steps; DBWD: 3 + 7 x 16 (the stream of hold_trunk_r6)
+  const float* in;        // DSP: v_7 [P][ld_in >= 256]; DBWD: [P][ld_in >= 40] (layer-0 input and the skip-layer side)
+  int ld_in, ld;
+  const float* aux1[8];
+  const float* aux2[8];
+  float* out[8];
+  float* out2[8];
+};
+
+__device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ float bitsf(uint32_t x) { return __builtin_bit_cast(float, x); }
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const float* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, p ? bytes : 0u, 0x00020000);
+}
+// column offset as an instruction immediate, soffset = 0 (see rmlp.hip: the store-data hazard hipcc assumes away for
+// SGPR soffsets)
+__device__ __forceinline__ void store4(const f32x4& v, rsrc_t rs, uint32_t voff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, voff, 0, 0);
+  asm volatile("s_nop 3");
+}
+
+struct Limbs { u32x4 l[3]; };
+struct Split3 { uint32_t p1, p2, p3; };
+__device__ __forceinline__ Split3 split2(float x0, float x1) {  // exact truncation split, two values -> one dword per limb
+  const uint32_t b0 = fbits(x0), b1 = fbits(x1);
+  const float r0 = x0 - bitsf(b0 & 0xffff0000u), r1 = x1 - bitsf(b1 & 0xffff0000u);
+  const uint32_t c0 = fbits(r0), c1 = fbits(r1);
+  const float s0 = r0 - bitsf(c0 & 0xffff0000u), s1 = r1 - bitsf(c1 & 0xffff0000u);
+  Split3 o;
+  o.p1 = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+  o.p2 = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
+  o.p3 = __builtin_amdgcn_perm(fbits(s1), fbits(s0), 0x07060302u);
+  return o;
+}
+__device__ __forceinline__ void put_limbs(Limbs& out, int c, Split3 s) {  // pinned: see rmlp.hip
+  asm volatile("" : "+v"(s.p1), "+v"(s.p2), "+v"(s.p3));
+  out.l[0][c] = s.p1;
+  out.l[1][c] = s.p2;
+  out.l[2][c] = s.p3;
+}
+
+// softplus'(a) recovered from h = softplus(a): 1 - e^{-100 h}; e is returned too (the second-order gate needs it)
+__device__ __forceinline__ float dsp_e(float h, float& e) {
+  const float x = 100.0f * h;
+  e = __builtin_amdgcn_exp2f(-144.26950408889634f * h);
+  const float ser = x * (1.0f - x * (0.5f - x * (0.16666667f - 0.041666668f * x)));
+  return (x < 0.05f) ? ser : 1.0f - e;
+}
+
+// weights: six 1 KiB pieces of k step `step` into ring slot `slot` (inline assembly: see rmlp.hip)
+__device__ __forceinline__ void dma_w(const char* wpack, uint32_t lane16, int step, int slot, int wave) {
+  const char* src = wpack + (long)step * SLOT + wave * (6 * PIECE);
+  const uint32_t dst = (uint32_t)(slot * SLOT + wave * (6 * PIECE));
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %4\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+      "s_mov_b32 m0, %5\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %3\n\t"
+      "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(lane16), "s"(src), "s"(src + 4 * PIECE), "s"(dst), "s"(dst + 4 * PIECE)
+      : "memory");
+}
+// side input: the two 16-byte row fragments (columns c0 + 4 hh .. and c0 + 8 + 4 hh ..) of one matrix for this wave's 32
+// rows -> two lane-linear 1 KiB pieces at LDS byte `dst`.  `base` = matrix + c0 (wave-uniform), rowoff = this lane's
+// (row * ld + 4 hh) * 4.  The instruction offset advances the global AND the LDS address: M0 of the second piece is
+// dst + 1024 - 32.
+__device__ __forceinline__ void dma_side(const float* base, uint32_t rowoff, uint32_t dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %4\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:32\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(rowoff), "s"(base), "s"(dst), "s"(dst + PIECE - 32)
+      : "memory");
+}
+
+#define RC_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+template <int MODE, bool A2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rchain_kernel(RCArgs a) {
+  constexpr bool DB = MODE == RC_DBWD;
+  constexpr int NAUX = (DB || A2) ? 2 : 1;   // side matrices per layer
+  constexpr int NOUT = DB ? 2 : 1;           // result matrices per layer
+  constexpr int L = DB ? 8 : 7;              // chain layers
+  constexpr int L0 = DB ? 3 : 16;            // k steps of chain layer 0
+  constexpr int NST = L0 + 16 * (L - 1);     // k steps per block of points
+  constexpr int SIDE_SLOT = NAUX * 2 * PIECE;
+  constexpr int OFF_SIDE = R3 * SLOT;
+  constexpr int OFF_IN = OFF_SIDE + NW * R3 * SIDE_SLOT;  // DBWD: the [32][IN_STR] input rows of each wave
+  constexpr int VPER = 4;
+  constexpr int NWAIT = 2 * NAUX + NOUT;  // VMEM operations of a step issued before its rendezvous (side DMA + stores A)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, li = lane & 31;
+  const uint32_t lane16 = lane * 16;
+  const char* ring_lane = smem + lane * 16;
+  const uint32_t side_dst0 = (uint32_t)(OFF_SIDE + wave * (R3 * SIDE_SLOT));
+  const float* side_rd = reinterpret_cast<const float*>(smem + OFF_SIDE + wave * (R3 * SIDE_SLOT)) + lane * 4;
+  float* inw = reinterpret_cast<float*>(smem + OFF_IN) + wave * (32 * IN_STR);
+  const uint32_t nbytes = (uint32_t)(a.P * a.ld * 4);
+
+  f32x16 P[8], Q[8];
+  u32x4 A[2][6];
+  Limbs Bc, Bn;
+
+  auto read_pair = [&](int slot, int pair, u32x4 (&dst)[6]) {
+    const char* base = ring_lane + slot * SLOT + pair * (6 * PIECE);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dst[i] = *reinterpret_cast<const u32x4*>(base + i * PIECE);
+  };
+  auto mfma12 = [&](int pair, const u32x4 (&af)[6], const Limbs& b) {
+#pragma unroll
+    for (int pr = 0; pr < 6; ++pr) {
+      const int wl = (pr == 2 || pr == 3) ? 1 : (pr == 5 ? 2 : 0);  // (w limb, act limb): 00 01 10 11 02 20
+      const int al = (pr == 1 || pr == 3) ? 1 : (pr == 4 ? 2 : 0);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        Q[2 * pair + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[3 * t + wl]),
+                                                                 __builtin_bit_cast(bf16x8, b.l[al]), Q[2 * pair + t],
+                                                                 0, 0, 0);
+    }
+  };
+  auto zero_q = [&]() {
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Q[nt][r] = 0.f;
+  };
+
+  // the first two k steps of the stream; gs counts k steps over all blocks (ring slot = gs % 3)
+  dma_w(a.wpack, lane16, 0, 0, wave);
+  dma_w(a.wpack, lane16, 1, 1, wave);
+  int gs = 0;
+  int first = 1;
+
+  for (long blk = blockIdx.x; blk * BPTS < a.P; blk += gridDim.x) {
+    const long row = blk * BPTS + wave * 32 + li;  // this lane's point
+    const long crow = row < a.P ? row : a.P - 1;    // clamped for the DMA reads (rows >= P: results dropped by the stores)
+    const uint32_t st_off = (uint32_t)((row * a.ld + 4 * hh) * 4);   // stores: unclamped, the buffer range check drops them
+    const uint32_t ld_off = (uint32_t)((crow * a.ld + 4 * hh) * 4);  // side DMA source
+
+    // ---- chain input ----
+    if (!DB) {  // v_7 rows into the accumulator layout: P[nt][4 g + k] = in[row][32 nt + 8 g + 4 hh + k]
+      const rsrc_t irs = make_rsrc(a.in, (uint32_t)(a.P * a.ld_in * 4));
+      const uint32_t ioff = (uint32_t)((row * a.ld_in + 4 * hh) * 4);
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(irs, ioff + (32 * nt + 8 * g) * 4, 0, 0);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) P[nt][4 * g + k] = bitsf(v[k]);
+        }
+    } else {  // [P][40] rows -> wave-private LDS (layer-0 B operand in natural k order + the skip-layer side)
+      const float* xr = a.in + crow * a.ld_in + 24 * hh;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (24 * hh + 4 * i < 40) v = *reinterpret_cast<const f32x4*>(xr + 4 * i);
+        *reinterpret_cast<f32x4*>(inw + li * IN_STR + 24 * hh + 4 * i) = v;
+      }
+    }
+    if (first) {
+      RC_WAIT_VM(0);
+      __builtin_amdgcn_s_barrier();
+      read_pair(0, 0, A[0]);
+      first = 0;
+    }
+
+    // side pointers of the epilogue layers lw = l - 1 ("lo", DMA of steps j' < 13) and lw = l ("hi", steps j' >= 13)
+    const float *lo1 = a.aux1[0], *lo2 = NAUX == 2 ? a.aux2[0] : nullptr, *hi1 = lo1, *hi2 = lo2;
+    int sb = 0;  // (16 (l - 1)) % 3: side slot of epilogue k step 0 of the layer being consumed
+
+    // One k step.  tl = step in the block's weight stream, jp = k step inside the layer (static), issue = side DMA of this step.
+    auto kstep = [&](int tl, int jp, auto&& nextB) {
+      const int slot = gs % R3, nslot = (gs + 1) % R3, fslot = (gs + 2) % R3;
+#pragma unroll
+      for (int pair = 0; pair < 4; ++pair) {
+        if (pair == 0) {  // side inputs consumed two steps from now: epilogue k step jc of layer lo (jp < 13) / hi
+          const int jc = (jp + 3) & 15;
+          const int sslot = (sb + jp) % R3;  // = (16 (l - 1) + jp + 3) % 3
+          const float* s1 = (jp < 13 ? lo1 : hi1) + 16 * jc;
+          dma_side(s1, ld_off, side_dst0 + sslot * SIDE_SLOT);
+          if (NAUX == 2) {
+            const float* s2 = (jp < 13 ? lo2 : hi2) + 16 * jc;
+            dma_side(s2, ld_off, side_dst0 + sslot * SIDE_SLOT + 2 * PIECE);
+          }
+        }
+        if (pair < 3) {
+          read_pair(slot, pair + 1, A[(pair + 1) & 1]);
+        } else {
+          read_pair(nslot, 0, A[0]);  // landed: this step's rendezvous
+        }
+        if (pair == 2) {  // rendezvous: every DMA issued before this step began has landed in every wave; slot gs - 1 is free
+          RC_WAIT_VM(NWAIT);
+          __builtin_amdgcn_s_barrier();
+          dma_w(a.wpack, lane16, (tl + 2) % NST, fslot, wave);
+        }
+        mfma12(pair, A[pair & 1], Bc);
+        nextB(pair);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x2, VPER, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      Bc = Bn;
+      gs += 1;
+    };
+    auto no_next = [](int) {};
+
+    // epilogue of one dword (two values) of k step j of the finished layer in P; lw = its chain layer (wave-uniform),
+    // raw = DSP layer 0 (the chain input itself is the B operand).  Side values from this wave's LDS ring slot `ss`.
+    rsrc_t ors = make_rsrc(nullptr, 0), ors2 = make_rsrc(nullptr, 0);
+    f32x4 keep, keep2;
+    auto epi = [&](int j, int c, int ss, bool raw, bool skip, Limbs& out) {
+      const int nt = j >> 1, q = j & 1;
+      const int f0 = 16 * j + 8 * (c >> 1) + 4 * hh + 2 * (c & 1);
+      const float* sp = side_rd + ss * (SIDE_SLOT / 4) + (c >> 1) * (PIECE / 4) + 2 * (c & 1);
+      const f32x2 hv = *reinterpret_cast<const f32x2*>(sp);
+      f32x2 xv = {0.f, 0.f};
+      if (NAUX == 2) xv = *reinterpret_cast<const f32x2*>(sp + 2 * (PIECE / 4));
+      float r[2], r2[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float y = P[nt][8 * q + 2 * c + i];
+        float e;
+        const float s = dsp_e(hv[i], e);
+        if (!DB) {
+          float v = y * s;
+          if (A2) v += xv[i];
+          r[i] = raw ? y : v;
+          r2[i] = 0.f;
+        } else {
+          r[i] = y * s;
+          r2[i] = 100.0f * y * xv[i] * e;
+        }
+      }
+      if (j >= 13) {  // skip layer (chain layer 3), columns 217..: DSP stores the raw products, DBWD takes the side input
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int m = f0 + i - SKIP_OUT;
+          const bool sp_ = skip && m >= 0;
+          if (!DB) {
+            r[i] = sp_ ? P[nt][8 * q + 2 * c + i] : r[i];
+          } else {
+            const float sv = inw[li * IN_STR + (m < 0 ? 0 : m)];
+            r[i] = sp_ ? sv : r[i];
+            r2[i] = sp_ ? 0.f : r2[i];
+          }
+        }
+      }
+      put_limbs(out, c, split2(r[0], r[1]));
+      keep[2 * (c & 1)] = r[0];
+      keep[2 * (c & 1) + 1] = r[1];
+      if (DB) {
+        keep2[2 * (c & 1)] = r2[0];
+        keep2[2 * (c & 1) + 1] = r2[1];
+      }
+      if (c & 1) {
+        store4(keep, ors, st_off + (16 * j + 8 * (c >> 1)) * 4);
+        if (DB) store4(keep2, ors2, st_off + (16 * j + 8 * (c >> 1)) * 4);
+      }
+    };
+
+    int l0 = 0;
+    if (DB) {  // chain layer 0: K = 48 from the staged input rows, natural k order 16 j + 8 hh + e
+      auto in_limbs = [&](int j, int c, Limbs& out) {
+        const float* er = inw + li * IN_STR + 16 * j + 8 * hh + 2 * c;
+        put_limbs(out, c, split2(er[0], er[1]));
+      };
+      zero_q();
+#pragma unroll
+      for (int c = 0; c < 4; ++c) in_limbs(0, c, Bc);
+      // side DMA of layer 0's three steps feeds epilogue k steps 0..2 of chain layer 0 (slots 0..2)
+      sb = 0;
+#pragma unroll
+      for (int j = 0; j < L0; ++j) {
+        // here jp = j - 3 + 16 would index the generic body; layer 0 issues epilogue k steps jc = j directly
+        const int slot = gs % R3, nslot = (gs + 1) % R3, fslot = (gs + 2) % R3;
+#pragma unroll
+        for (int pair = 0; pair < 4; ++pair) {
+          if (pair == 0) {
+            dma_side(lo1 + 16 * j, ld_off, side_dst0 + j * SIDE_SLOT);
+            dma_side(lo2 + 16 * j, ld_off, side_dst0 + j * SIDE_SLOT + 2 * PIECE);
+          }
+          if (pair < 3) {
+            read_pair(slot, pair + 1, A[(pair + 1) & 1]);
+          } else {
+            read_pair(nslot, 0, A[0]);
+          }
+          if (pair == 2) {
+            RC_WAIT_VM(NWAIT);
+            __builtin_amdgcn_s_barrier();
+            dma_w(a.wpack, lane16, (j + 2) % NST, fslot, wave);
+          }
+          mfma12(pair, A[pair & 1], Bc);
+          if (j + 1 < L0) in_limbs(j + 1, pair, Bn);
+          if (pair == 1 || pair == 3) {  // keep the per-step VMEM count of the generic steps (null descriptors: dropped)
+            store4(keep, ors, st_off);
+            store4(keep2, ors2, st_off);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        Bc = Bn;
+        gs += 1;
+      }
+      l0 = 1;
+    }
+
+    for (int l = l0; l < L; ++l) {
+      // MFMA layer l consumes P through the epilogue of chain layer lw = l - 1 (DSP l = 0: the raw chain input)
+      if (DB || l > 0) {
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) P[nt] = Q[nt];
+      }
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+a"(P[nt][r]));
+      zero_q();
+      const int lw = l - 1;
+      const bool raw = !DB && l == 0;
+      const bool skip = lw == 3;
+      const int lwc = lw < 0 ? 0 : lw, lhc = l < L - 1 ? l : L - 2;
+      lo1 = a.aux1[lwc];
+      hi1 = a.aux1[lhc];
+      if (NAUX == 2) {
+        lo2 = a.aux2[lwc];
+        hi2 = a.aux2[lhc];
+      }
+      ors = make_rsrc(raw ? nullptr : a.out[lwc], nbytes);
+      if (DB) ors2 = make_rsrc(a.out2[lwc], nbytes);
+      sb = ((16 * lw) % R3 + R3) % R3;  // DSP l = 0: (-16) mod 3 = 2 (only the DMA issue of steps 13..15 uses it)
+      const int t0 = DB ? L0 + 16 * (l - 1) : 16 * l;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) epi(0, c, sb, raw, skip, Bc);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (j + 1 < 16)
+          kstep(t0 + j, j, [&](int c) { epi(j + 1, c, (sb + j + 1) % R3, raw, skip, Bn); });
+        else
+          kstep(t0 + j, j, no_next);
+      }
+    }
+
+    // ---- epilogue of the last chain layer (exposed): side rows by ordinary buffer loads ----
+    {
+      const rsrc_t a1 = make_rsrc(a.aux1[L - 1], nbytes);
+      const rsrc_t a2 = make_rsrc(NAUX == 2 ? a.aux2[L - 1] : nullptr, nbytes);
+      const rsrc_t o1 = make_rsrc(a.out[L - 1], nbytes), o2 = make_rsrc(DB ? a.out2[L - 1] : nullptr, nbytes);
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const uint32_t co = (32 * nt + 8 * g) * 4;
+          const u32x4 hv = __builtin_amdgcn_raw_buffer_load_b128(a1, st_off + co, 0, 0);
+          u32x4 xv = {0u, 0u, 0u, 0u};
+          if (NAUX == 2) xv = __builtin_amdgcn_raw_buffer_load_b128(a2, st_off + co, 0, 0);
+          f32x4 r, r2;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float y = Q[nt][4 * g + k];
+            float e;
+            const float s = dsp_e(bitsf(hv[k]), e);
+            if (!DB) {
+              r[k] = y * s + (A2 ? bitsf(xv[k]) : 0.f);
+              r2[k] = 0.f;
+            } else {
+              r[k] = y * s;
+              r2[k] = 100.0f * y * bitsf(xv[k]) * e;
+            }
+          }
+          store4(r, o1, st_off + co);
+          if (DB) store4(r2, o2, st_off + co);
+        }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t hold_chain_r6_pack_bytes(int32_t mode) {
+  if (mode == HOLD_CHAIN_DSP) return (int64_t)(7 * 16) * SLOT;
+  if (mode == HOLD_CHAIN_DBWD) return (int64_t)(3 + 7 * 16) * SLOT;
+  return -1;
+}
+
+template <int MODE, bool A2>
+static int rchain_launch(const RCArgs& a, hipStream_t s) {
+  constexpr bool DB = MODE == RC_DBWD;
+  constexpr int NAUX = (DB || A2) ? 2 : 1;
+  constexpr int lds = R3 * SLOT + NW * R3 * NAUX * 2 * PIECE + (DB ? NW * 32 * IN_STR * 4 : 0);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static int n_cu = 0;
+  static bool attr_set = false;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return HOLD_E_LAUNCH;
+    n_cu = prop.multiProcessorCount;
+  }
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)rchain_kernel<MODE, A2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+        hipSuccess)
+      return HOLD_E_LAUNCH;
+    attr_set = true;
+  }
+  const long blocks = (a.P + BPTS - 1) / BPTS;
+  hipLaunchKernelGGL((rchain_kernel<MODE, A2>), dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(256), lds, s, a);
+  return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+}
+
+// The descriptor and semantics of hold_chain_x6 for the two backward-type sweeps with the register-resident structure:
+// mode DSP (7 layers, first_chunks 32, skip_layer 3, every out[] optional) or DBWD (8 layers, first_chunks 5, skip_layer 3,
+// side == in).  d->wpack = hold_chain_r6_pack_bytes(mode) bytes in the k order of hold_trunk_r6.
+extern "C" int hold_chain_r6(const hold_chain_desc* dp, hold_stream_t st) {
+  if (!dp) return HOLD_E_ARG;
+  const hold_chain_desc& d = *dp;
+  if (d.P < 0 || !d.in || !d.wpack || d.skip_layer != 3) return HOLD_E_ARG;
+  if (d.ld < 256 || (d.ld & 3) || (d.ld_in & 3)) return HOLD_E_ARG;
+  if (((uintptr_t)d.in & 15) || ((uintptr_t)d.wpack & 15)) return HOLD_E_ARG;
+  if (((uint64_t)d.P + 128) * (uint64_t)d.ld * 4 >= (1ull << 32)) return HOLD_E_ARG;  // 32-bit byte offsets
+  RCArgs a = {};
+  a.P = (long)d.P; a.wpack = (const char*)d.wpack; a.in = d.in; a.ld_in = d.ld_in; a.ld = d.ld;
+  const bool dsp = d.mode == HOLD_CHAIN_DSP, dbwd = d.mode == HOLD_CHAIN_DBWD;
+  if (dsp) {
+    if (d.n_layers != 7 || d.first_chunks != 32 || d.ld_in < 256) return HOLD_E_ARG;
+    if (((uint64_t)d.P + 128) * (uint64_t)d.ld_in * 4 >= (1ull << 32)) return HOLD_E_ARG;
+  } else if (dbwd) {
+    if (d.n_layers != 8 || d.first_chunks != 5 || d.ld_in < 40 || d.side != d.in) return HOLD_E_ARG;
+  } else {
+    return HOLD_E_ARG;
+  }
+  const bool has2 = d.aux2[0] != nullptr;
+  for (int l = 0; l < d.n_layers; ++l) {
+    if (!d.aux1[l] || ((uintptr_t)d.aux1[l] & 15) || ((uintptr_t)d.aux2[l] & 15) || ((uintptr_t)d.out[l] & 15) ||
+        ((uintptr_t)d.out2[l] & 15))
+      return HOLD_E_ARG;
+    if ((d.aux2[l] != nullptr) != has2) return HOLD_E_ARG;
+    if (dbwd && (!d.aux2[l] || !d.out[l] || !d.out2[l])) return HOLD_E_ARG;
+    a.aux1[l] = d.aux1[l]; a.aux2[l] = d.aux2[l]; a.out[l] = d.out[l]; a.out2[l] = d.out2[l];
+  }
+  if (d.P == 0) return HOLD_OK;
+  hipStream_t s = (hipStream_t)st;
+  if (dbwd) return rchain_launch<RC_DBWD, true>(a, s);
+  return has2 ? rchain_launch<RC_DSP, true>(a, s) : rchain_launch<RC_DSP, false>(a, s);
+}

@@ -30,6 +30,7 @@ FUSED_SDF = os.environ.get("HOLD_FUSED_SDF", "1") != "0"  # sampler queries thro
 USE_CHAIN = os.environ.get("HOLD_CHAIN", "1") != "0"
 # register-resident trunk (csrc/rmlp.hip) for the sampler queries and the training forward trunk (f32x6 arithmetic only)
 USE_R6 = os.environ.get("HOLD_R6", "1") != "0"
+USE_R6_BWD = os.environ.get("HOLD_R6_BWD", "1") != "0"  # ... and for the descending / second-order sweeps (csrc/rchain.hip)
 RIN_FEAT, RIN_X, RIN_N, RIN_POSE, RIN_TIME = 0, 256, 259, 262, 270
 
 
@@ -151,6 +152,14 @@ def pack_r6(w0, S):
     return torch.cat([p0, pk]).contiguous()
 
 
+def pack_r6_stack(S):
+    """hold_chain_r6 (DSP) stream of L [256, 256] matrices: every layer in the virtual k order (r6_kmap)"""
+    L = S.shape[0]
+    lk = torch.stack(split_limbs(S))  # [3, L, 256, 256]
+    g = lk[:, :, :, r6_kmap(S.device)]  # [3 t, L, 256 out, 16 j, 2 h, 8 e]
+    return g.reshape(3, L, 8, 32, 16, 2, 8).permute(1, 4, 2, 0, 5, 3, 6).reshape(-1).contiguous()
+
+
 def frag_pack_stack(S):
     """fp32 MFMA-fragment order of hold_fused_sdf / hold_chain for L [256, 256] matrices:
     per matrix [K/8 chunks][8 n-tiles][2 h][32 i][4]"""
@@ -205,6 +214,7 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
     if config.x6():  # limb packs of the same matrices for hold_chain_x6 (the forward-type sweeps share the sampler trunk's)
         pk["chain_fwd_x6"] = pk["fused_x6"]
         pk["chain_bwd_x6"] = pack_x6_stack(STf)
+        pk["chain_bwd_r6"] = pack_r6_stack(STf)
     if rw is None:  # implicit net only (ImplicitNet.forward / gradient)
         return pk
     r0 = torch.zeros(256, spec.Kr, device=dev)
@@ -244,7 +254,7 @@ class NodeField:
         sp, pool = self.spec, self.pool
         in0 = pool.get("in0", P, sp.K0)
         h = [pool.get(f"h{l}" if (keep_all or l == 3) else f"h_pp{l & 1}", P, 256) for l in range(8)]
-        if USE_R6 and keep_all and "trunk_r6" in pk:
+        if USE_R6 and USE_CHAIN and keep_all and "trunk_r6" in pk:
             # register-resident trunk: embedding in-kernel, h_0..h_7 (and the skip columns of h_3) stored from the
             # accumulator registers; the embedding matrix itself is only needed by the backward (layer-0 weight gradient)
             if need_in0:
@@ -276,7 +286,7 @@ class NodeField:
         if USE_CHAIN:
             outs = [t[l - 1] if (keep_all or l - 1 in (0, 3)) else None for l in range(7, 0, -1)]
             K.chain(K.CHAIN_DSP, P, t[7], pk["chain_bwd"], 7, 32, skip_layer=3, aux1=[h[l - 1] for l in range(7, 0, -1)],
-                    out=outs, wpack_x6=pk.get("chain_bwd_x6"))
+                    out=outs, wpack_x6=pk.get("chain_bwd_x6"), wpack_r6=pk.get("chain_bwd_r6") if USE_R6_BWD else None)
             K.copy_cols(t[3][:, sp.skip_out:], ge, sp.E, P)  # raw columns 217.. = d sdf / d (skip embedding)
         else:
             for l in range(7, 0, -1):
@@ -361,7 +371,7 @@ class NodeField:
         if USE_CHAIN:
             vb = [pool.get(f"vbc{l}", P, 256) for l in range(8)]
             K.chain(K.CHAIN_DBWD, P, gebar, pk["fused"][0], 8, 5, skip_layer=3, side=gebar, aux1=h, aux2=t, out=vb,
-                    out2=a2, wpack_x6=pk.get("chain_fwd_x6"))
+                    out2=a2, wpack_x6=pk.get("chain_fwd_x6"), wpack_r6=pk.get("trunk_r6") if USE_R6_BWD else None)
             G.wgrad(t[0], gebar, dW[0], None, K=sp.K0, accumulate=True)
             for l in range(1, 8):
                 if l == 3:
@@ -397,7 +407,8 @@ class NodeField:
             r = [pool.get(f"rbc{l}", P, 256) for l in range(7)] + [r7]
             K.chain(K.CHAIN_DSP, P, r7, pk["chain_bwd"], 7, 32, skip_layer=3, aux1=[h[l - 1] for l in range(7, 0, -1)],
                     aux2=None if a2 is None else [a2[l - 1] for l in range(7, 0, -1)],
-                    out=[r[l - 1] for l in range(7, 0, -1)], wpack_x6=pk.get("chain_bwd_x6"))
+                    out=[r[l - 1] for l in range(7, 0, -1)], wpack_x6=pk.get("chain_bwd_x6"),
+                    wpack_r6=pk.get("chain_bwd_r6") if USE_R6_BWD else None)
             if ebar is not None:
                 K.copy_cols(r[3][:, sp.skip_out:], ebar, sp.E, P)
             for l in range(7, 0, -1):

@@ -153,7 +153,7 @@ _CHAIN_MAX_ROWS = ((1 << 32) // 1024 - 1) // 128 * 128  # 32-bit byte offsets in
 
 
 def chain(mode, P, x_in, wpack, n_layers, first_chunks, skip_layer=-1, side=None, bias=None, aux1=None, aux2=None,
-          out=None, out2=None, wpack_x6=None):
+          out=None, out2=None, wpack_x6=None, wpack_r6=None):
     """hold_chain: n_layers consecutive 256-wide layers of one sweep with the activation resident in LDS.
     bias: per-layer [256] tensors; aux1 / aux2 / out / out2: per-layer [P,256] tensors (one common row stride) or None
     entries.  Batches beyond the kernel's 32-bit offset range are split by rows."""
@@ -161,6 +161,10 @@ def chain(mode, P, x_in, wpack, n_layers, first_chunks, skip_layer=-1, side=None
     assert wpack.numel() == _lib.lib().hold_chain_pack_floats(first_chunks, n_layers)
     if wpack_x6 is not None:  # split-precision sweep (hold_chain_x6): same descriptor, the weights as bf16 limbs
         assert wpack_x6.numel() * wpack_x6.element_size() == _lib.lib().hold_chain_x6_pack_bytes(first_chunks, n_layers)
+    r6 = wpack_r6 is not None and mode in (CHAIN_DSP, CHAIN_DBWD)  # register-resident sweep (hold_chain_r6): same descriptor
+    if r6:
+        assert wpack_r6.numel() * wpack_r6.element_size() == _lib.lib().hold_chain_r6_pack_bytes(mode)
+        assert skip_layer == 3 and (mode == CHAIN_DSP or side is x_in)
     for r0 in range(0, P, _CHAIN_MAX_ROWS):
         r1 = min(P, r0 + _CHAIN_MAX_ROWS)
         d = _lib.ChainDesc()
@@ -168,7 +172,7 @@ def chain(mode, P, x_in, wpack, n_layers, first_chunks, skip_layer=-1, side=None
         d.in_, d.ld_in = x_in[r0:r1].data_ptr(), _ld(x_in)
         if side is not None:
             d.side, d.ld_side = side[r0:r1].data_ptr(), _ld(side)
-        d.wpack = (wpack if wpack_x6 is None else wpack_x6).data_ptr()
+        d.wpack = wpack_r6.data_ptr() if r6 else (wpack if wpack_x6 is None else wpack_x6).data_ptr()
         ld = None
         for name, lst in (("bias", bias), ("aux1", aux1), ("aux2", aux2), ("out", out), ("out2", out2)):
             if lst is None:
@@ -186,7 +190,7 @@ def chain(mode, P, x_in, wpack, n_layers, first_chunks, skip_layer=-1, side=None
                 ld = _ld(t)
         d.ld = ld if ld is not None else 256
         e0 = _g._prof_begin()
-        call("hold_chain" if wpack_x6 is None else "hold_chain_x6", C.byref(d))
+        call("hold_chain_r6" if r6 else ("hold_chain" if wpack_x6 is None else "hold_chain_x6"), C.byref(d))
         _g._prof_end(e0, 2.0 * (r1 - r0) * 256 * (8 * first_chunks + 256 * (n_layers - 1)), "chain_kernel")
 
 

@@ -28,6 +28,15 @@ def _pack_x6(mats, first_k):
 
 
 ARITH = ["f32", "f32x6"]  # hold_chain (fp32 MFMA) and hold_chain_x6 (3-limb bf16 split, fp32 accumulate): same tolerance
+ARITH_BWD = ARITH + ["r6"]  # + hold_chain_r6: the register-resident structure (csrc/rchain.hip), f32x6 arithmetic
+
+
+def _r6_stream(mode, mats):
+    """weight stream of hold_chain_r6 (hold_amd/field.py:pack_r6 / pack_r6_stack)"""
+    from hold_amd import field as F
+    if mode == "dsp":
+        return F.pack_r6_stack(torch.stack(mats))
+    return F.pack_r6(mats[0], torch.stack(mats[1:]))
 
 
 class _Guarded:
@@ -75,8 +84,8 @@ def test_chain_softplus_forward(P, arith):
         cur = out[l].double()  # follow the kernel's own rounding from layer to layer
 
 
-@pytest.mark.parametrize("arith", ARITH)
-@pytest.mark.parametrize("P,with_a2", [(130, False), (1000, True), (128 * 257 + 3, True)])
+@pytest.mark.parametrize("arith", ARITH_BWD)
+@pytest.mark.parametrize("P,with_a2", [(130, False), (1000, True), (128 * 257 + 3, True), (128 * 257 + 3, False)])
 def test_chain_descending_dsp(P, with_a2, arith):
     from hold_amd import kernels as K
     dev = _dev()
@@ -89,7 +98,8 @@ def test_chain_descending_dsp(P, with_a2, arith):
     guard = _Guarded(7, P, dev)
     out = guard.views
     K.chain(K.CHAIN_DSP, P, v7, _pack(Ms), 7, 32, skip_layer=3, aux1=hs, aux2=a2, out=out,
-            wpack_x6=_pack_x6(Ms, 256) if arith == "f32x6" else None)
+            wpack_x6=_pack_x6(Ms, 256) if arith == "f32x6" else None,
+            wpack_r6=_r6_stream("dsp", Ms) if arith == "r6" else None)
     guard.check()
     cur = v7.double()
     for j in range(7):
@@ -105,7 +115,7 @@ def test_chain_descending_dsp(P, with_a2, arith):
         cur = out[j].double()
 
 
-@pytest.mark.parametrize("arith", ARITH)
+@pytest.mark.parametrize("arith", ARITH_BWD)
 @pytest.mark.parametrize("P", [200, 128 * 256 + 64])
 def test_chain_second_order_dbwd(P, arith):
     from hold_amd import kernels as K
@@ -122,7 +132,8 @@ def test_chain_second_order_dbwd(P, arith):
     g1, g2 = _Guarded(8, P, dev), _Guarded(8, P, dev)
     o1, o2 = g1.views, g2.views
     K.chain(K.CHAIN_DBWD, P, x0, _pack(Ws), 8, 5, skip_layer=3, side=x0, aux1=hs, aux2=ts, out=o1, out2=o2,
-            wpack_x6=_pack_x6(Ws, 48) if arith == "f32x6" else None)
+            wpack_x6=_pack_x6(Ws, 48) if arith == "f32x6" else None,
+            wpack_r6=_r6_stream("dbwd", Ws) if arith == "r6" else None)
     g1.check()
     g2.check()
     cur = x0.double()
@@ -139,6 +150,25 @@ def test_chain_second_order_dbwd(P, arith):
         assert (o1[l].double() - r).abs().max().item() < 3e-5 * s1, l
         assert (o2[l].double() - r2).abs().max().item() < 3e-5 * s2, l
         cur = o1[l].double()
+
+
+def test_chain_r6_optional_outputs():
+    """hold_chain_r6 DSP with some out[] entries NULL (the eval-mode reverse sweep keeps t_0 and t_3 only): the stored
+    layers equal the all-outputs run bit for bit"""
+    from hold_amd import kernels as K
+    dev = _dev()
+    P = 777
+    g = torch.Generator().manual_seed(21)
+    v7 = torch.randn(P, 256, generator=g).to(dev)
+    Ms = [(torch.randn(256, 256, generator=g) / 16).to(dev) for _ in range(7)]
+    hs = [_sp(torch.randn(P, 256, generator=g) * 0.03).to(dev) for _ in range(7)]
+    full = [torch.empty(P, 256, device=dev) for _ in range(7)]
+    r6 = _r6_stream("dsp", Ms)
+    K.chain(K.CHAIN_DSP, P, v7, _pack(Ms), 7, 32, skip_layer=3, aux1=hs, out=full, wpack_r6=r6)
+    part = [torch.full((P, 256), 5.0, device=dev) if j in (3, 6) else None for j in range(7)]
+    K.chain(K.CHAIN_DSP, P, v7, _pack(Ms), 7, 32, skip_layer=3, aux1=hs, out=part, wpack_r6=r6)
+    for j in (3, 6):
+        assert torch.equal(part[j], full[j])
 
 
 def test_chain_row_split_matches_single_call(monkeypatch):

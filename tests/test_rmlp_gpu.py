@@ -103,9 +103,11 @@ def test_trunk_r6_stores_every_layer(P, barf):
             cur = torch.cat([cur[:, :SK], emb], 1)
         err = (h[l].double() - cur).abs().max().item()
         assert err < 3e-5 * max(1.0, cur.abs().max().item()), (l, err)
-        # small activations keep RELATIVE accuracy (the backward sweeps recover softplus' from the stored h)
+        # small activations keep RELATIVE accuracy (the backward sweeps recover softplus' from the stored h): for y < 0
+        # softplus ~ exp(100 y) / 100, so the fp32 rounding of the pre-activation (1e-6 absolute) alone is 1e-4 relative;
+        # a log1p that rounded e away (log(1 + e) at e <= 1e-3) would show up as 1e-2 and more
         small = (cur < 1e-4) & (cur > 1e-30)  # below that exp2 flushes to zero: absolute error 1e-32
         if small.any() and l != 3:
             rel = ((h[l].double() - cur).abs() / cur)[small].max().item()
-            assert rel < 1e-4, (l, rel)
+            assert rel < 1e-3, (l, rel)
         cur = h[l].double()  # follow the kernel's own rounding from layer to layer
