@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // epilogue of one dword (two values) of k step j of the finished layer in P; lw = its chain layer (wave-uniform),
     // raw = DSP layer 0 (the chain input itself is the B operand).  Side values from this wave's LDS ring slot `ss`.
     rsrc_t ors = make_rsrc(nullptr, 0), ors2 = make_rsrc(nullptr, 0);
-    f32x4 keep, keep2;
+    f32x4 keep = {0.f, 0.f, 0.f, 0.f}, keep2 = {0.f, 0.f, 0.f, 0.f};
     auto epi = [&](int j, int c, int ss, bool raw, bool skip, Limbs& out) {
       const int nt = j >> 1, q = j & 1;
       const int f0 = 16 * j + 8 * (c >> 1) + 4 * hh + 2 * (c & 1);

@@ -13,7 +13,8 @@ two contiguous device buffers ordered [pose tables | everything else], so that
 Semantics vs ``torch.optim.Adam``: identical arithmetic per element (bias corrections in double on the host); a
 parameter whose ``.grad`` torch would leave ``None`` (no gradient at all this step) is treated as having a zero
 gradient, i.e. its moments decay and the bias-correction step is the global one -- HOLD's parameters all receive
-gradients from step 0, where the two coincide (verified against torch.optim.Adam in tests/test_optim_gpu.py).
+gradients from step 0, where the two coincide (verified against torch.optim.Adam in
+tests/test_train_targets_gpu.py::test_flat_adam_matches_torch_adam_with_clip).
 """
 from __future__ import annotations
 
@@ -95,8 +96,42 @@ class FlatAdam:
             return 1.0 / dist.get_world_size(self.group) if average else 1.0
         return 1.0
 
+    def rehome(self):
+        """re-attach parameters whose storage left the bucket (``net.to()`` / ``.float()`` / ``p.data = ...`` after
+        construction, e.g. GenericParams.init_parameters): their current values are copied in -- without this step()
+        would keep updating the bucket while the model reads the detached storage."""
+        moved = 0
+        with torch.no_grad():
+            for p, off in zip(self.params, self.offsets):
+                if p.data_ptr() != self.flat.data_ptr() + 4 * off:
+                    k = p.numel()
+                    self.flat[off:off + k].copy_(p.data.reshape(-1).to(self.flat.device, torch.float32))
+                    p.data = self.flat[off:off + k].view(p.shape)
+                    moved += 1
+        return moved
+
+    def state_dict(self):
+        """optimiser state for checkpoint / resume (the reference's Lightning checkpoints carry Adam's moments and step
+        count): per-parameter views are not needed, the layout is (offsets, numel) over the flat bucket."""
+        return {"step_count": self.step_count, "m": self.m.clone(), "v": self.v.clone(), "offsets": list(self.offsets),
+                "numels": [p.numel() for p in self.params], "n": self.n, "n_low": self.n_low, "lr": self.lr,
+                "pose_lr_scale": self.pose_lr_scale, "betas": tuple(self.betas), "eps": self.eps, "clip_norm": self.clip_norm}
+
+    def load_state_dict(self, sd):
+        if list(sd["offsets"]) != list(self.offsets) or list(sd["numels"]) != [p.numel() for p in self.params]:
+            raise ValueError("FlatAdam.load_state_dict: the parameter layout of the checkpoint differs from this model's")
+        self.step_count = int(sd["step_count"])
+        self.m.copy_(sd["m"].to(self.m.device))
+        self.v.copy_(sd["v"].to(self.v.device))
+        for k in ("lr", "pose_lr_scale", "eps", "clip_norm"):
+            if k in sd:
+                setattr(self, k, float(sd[k]))
+        if "betas" in sd:
+            self.betas = tuple(sd["betas"])
+
     def step(self, grad_mul=1.0):
         """reduce (if distributed) -> clip by global norm on the reduced gradients -> Adam."""
+        self.rehome()
         self.gather_stray_grads()
         grad_mul = grad_mul * self.allreduce(average=True)
         self.step_count += 1
