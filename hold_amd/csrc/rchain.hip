@@ -12,9 +12,11 @@
 // What streams: the weight limbs (24 KiB per 16-wide k step, LDS ring of 3 slots filled by LDS-DMA two steps ahead,
 // shared by the four waves) and, new here, the per-layer SIDE inputs -- for every k step the 8 stored h (and a2 / t)
 // values a lane needs are two (four) 16-byte row fragments: they are fetched by LDS-DMA too (lane-linear image, wave
-// private, ring of 3, two steps ahead), so no load ever has a register destination in flight and the compiler's
-// counters only see ds_reads and stores; completion of all DMA is counted by hand at the one rendezvous per k step
-// ("everything issued before this step began has landed").  The results (next layer's input) are stored with
+// private, ring of 4, requested three steps before use), so no load ever has a register destination in flight and the
+// compiler's counters only see ds_reads and stores; completion of all DMA is counted by hand at the one rendezvous per
+// k step.  The vector-memory counter retires in order, so the side request is issued right BEHIND the weight DMA of a
+// rendezvous: the next rendezvous waits for those weights (L2-resident, one step is ample) without forcing the side
+// fragments that follow them in the queue -- these get two full steps of HBM latency.  The results (next layer's input) are stored with
 // 16-byte row-fragment stores straight from the epilogue.
 // Exposed per block of 128 points: loading the chain input (32 x 16 B per lane) and the epilogue of the LAST layer.
 // Roofline: bf16 MFMA pipe; HBM bytes per point and layer: DSP 2 KiB (1 side + 1 out), DSP + a2 3 KiB, DBWD 4 KiB.
@@ -32,7 +34,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int NW = 4, BPTS = 32 * NW, PIECE = 1024, SLOT = 24 * PIECE, R3 = 3;
-constexpr int SKIP_OUT = 217, IN_STR = 52;
+constexpr int SKIP_OUT = 217, IN_STR = 44, SIDE_RING = 4;
 enum { RC_DSP = 1, RC_DBWD = 2 };
 
 struct RCArgs {
@@ -142,18 +144,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int NST = L0 + 16 * (L - 1);     // k steps per block of points
   constexpr int SIDE_SLOT = NAUX * 2 * PIECE;
   constexpr int OFF_SIDE = R3 * SLOT;
-  constexpr int OFF_IN = OFF_SIDE + NW * R3 * SIDE_SLOT;  // DBWD: the [32][IN_STR] input rows of each wave
+  constexpr int OFF_IN = OFF_SIDE + NW * SIDE_RING * SIDE_SLOT;  // DBWD: the [32][IN_STR] (+ 4) input rows of each wave
   constexpr int VPER = 4;
-  constexpr int NWAIT = 2 * NAUX + NOUT;  // VMEM operations of a step issued before its rendezvous (side DMA + stores A)
+  // VMEM operations issued between the weight DMA of the previous rendezvous and this one's wait: the side DMA that follows
+  // that weight DMA, the previous step's stores B, this step's stores A.  Waiting down to this count lands the weights
+  // (needed now) and every side fragment issued ONE rendezvous earlier, while the newest side fragments stay in flight:
+  // they get two full steps, the L2-resident weights one.
+  constexpr int NWAIT = 2 * NAUX + 2 * NOUT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, li = lane & 31;
   const uint32_t lane16 = lane * 16;
   const char* ring_lane = smem + lane * 16;
-  const uint32_t side_dst0 = (uint32_t)(OFF_SIDE + wave * (R3 * SIDE_SLOT));
-  const float* side_rd = reinterpret_cast<const float*>(smem + OFF_SIDE + wave * (R3 * SIDE_SLOT)) + lane * 4;
-  float* inw = reinterpret_cast<float*>(smem + OFF_IN) + wave * (32 * IN_STR);
+  const uint32_t side_dst0 = (uint32_t)(OFF_SIDE + wave * (SIDE_RING * SIDE_SLOT));
+  const float* side_rd = reinterpret_cast<const float*>(smem + OFF_SIDE + wave * (SIDE_RING * SIDE_SLOT)) + lane * 4;
+  float* inw = reinterpret_cast<float*>(smem + OFF_IN) + wave * (32 * IN_STR + 4);
   const uint32_t nbytes = (uint32_t)(a.P * a.ld * 4);
 
   f32x16 P[8], Q[8];
@@ -224,34 +230,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       first = 0;
     }
 
-    // side pointers of the epilogue layers lw = l - 1 ("lo", DMA of steps j' < 13) and lw = l ("hi", steps j' >= 13)
+    // side pointers of the epilogue layers lw = l - 1 ("lo", DMA of steps j' < 12) and lw = l ("hi", steps j' >= 12)
     const float *lo1 = a.aux1[0], *lo2 = NAUX == 2 ? a.aux2[0] : nullptr, *hi1 = lo1, *hi2 = lo2;
-    int sb = 0;  // (16 (l - 1)) % 3: side slot of epilogue k step 0 of the layer being consumed
 
-    // One k step.  tl = step in the block's weight stream, jp = k step inside the layer (static), issue = side DMA of this step.
+    // One k step.  tl = step in the block's weight stream, jp = k step inside the layer (static).  At the rendezvous of
+    // step (l, jp) the side fragments of epilogue k step 16 (l - 1) + jp + 4 are requested (consumed three steps later,
+    // side slot = k step % 4: 16 is a multiple of the ring).
     auto kstep = [&](int tl, int jp, auto&& nextB) {
       const int slot = gs % R3, nslot = (gs + 1) % R3, fslot = (gs + 2) % R3;
 #pragma unroll
       for (int pair = 0; pair < 4; ++pair) {
-        if (pair == 0) {  // side inputs consumed two steps from now: epilogue k step jc of layer lo (jp < 13) / hi
-          const int jc = (jp + 3) & 15;
-          const int sslot = (sb + jp) % R3;  // = (16 (l - 1) + jp + 3) % 3
-          const float* s1 = (jp < 13 ? lo1 : hi1) + 16 * jc;
-          dma_side(s1, ld_off, side_dst0 + sslot * SIDE_SLOT);
-          if (NAUX == 2) {
-            const float* s2 = (jp < 13 ? lo2 : hi2) + 16 * jc;
-            dma_side(s2, ld_off, side_dst0 + sslot * SIDE_SLOT + 2 * PIECE);
-          }
-        }
         if (pair < 3) {
           read_pair(slot, pair + 1, A[(pair + 1) & 1]);
         } else {
           read_pair(nslot, 0, A[0]);  // landed: this step's rendezvous
         }
-        if (pair == 2) {  // rendezvous: every DMA issued before this step began has landed in every wave; slot gs - 1 is free
+        if (pair == 2) {  // rendezvous: the weights of step gs + 1 have landed in every wave; slot gs - 1 is free
           RC_WAIT_VM(NWAIT);
           __builtin_amdgcn_s_barrier();
           dma_w(a.wpack, lane16, (tl + 2) % NST, fslot, wave);
+          const int jc = (jp + 4) & 15, sslot = jp & 3;
+          dma_side((jp < 12 ? lo1 : hi1) + 16 * jc, ld_off, side_dst0 + sslot * SIDE_SLOT);
+          if (NAUX == 2) dma_side((jp < 12 ? lo2 : hi2) + 16 * jc, ld_off, side_dst0 + sslot * SIDE_SLOT + 2 * PIECE);
         }
         mfma12(pair, A[pair & 1], Bc);
         nextB(pair);
@@ -331,18 +331,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       zero_q();
 #pragma unroll
       for (int c = 0; c < 4; ++c) in_limbs(0, c, Bc);
-      // side DMA of layer 0's three steps feeds epilogue k steps 0..2 of chain layer 0 (slots 0..2)
-      sb = 0;
+      // epilogue k step 0 of chain layer 0 is requested here, k steps 1..3 at the rendezvous of this layer's three steps
+      dma_side(lo1, ld_off, side_dst0);
+      dma_side(lo2, ld_off, side_dst0 + 2 * PIECE);
 #pragma unroll
       for (int j = 0; j < L0; ++j) {
-        // here jp = j - 3 + 16 would index the generic body; layer 0 issues epilogue k steps jc = j directly
         const int slot = gs % R3, nslot = (gs + 1) % R3, fslot = (gs + 2) % R3;
 #pragma unroll
         for (int pair = 0; pair < 4; ++pair) {
-          if (pair == 0) {
-            dma_side(lo1 + 16 * j, ld_off, side_dst0 + j * SIDE_SLOT);
-            dma_side(lo2 + 16 * j, ld_off, side_dst0 + j * SIDE_SLOT + 2 * PIECE);
-          }
           if (pair < 3) {
             read_pair(slot, pair + 1, A[(pair + 1) & 1]);
           } else {
@@ -352,6 +348,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             RC_WAIT_VM(NWAIT);
             __builtin_amdgcn_s_barrier();
             dma_w(a.wpack, lane16, (j + 2) % NST, fslot, wave);
+            dma_side(lo1 + 16 * (j + 1), ld_off, side_dst0 + (j + 1) * SIDE_SLOT);
+            dma_side(lo2 + 16 * (j + 1), ld_off, side_dst0 + (j + 1) * SIDE_SLOT + 2 * PIECE);
           }
           mfma12(pair, A[pair & 1], Bc);
           if (j + 1 < L0) in_limbs(j + 1, pair, Bn);
@@ -390,14 +388,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
       ors = make_rsrc(raw ? nullptr : a.out[lwc], nbytes);
       if (DB) ors2 = make_rsrc(a.out2[lwc], nbytes);
-      sb = ((16 * lw) % R3 + R3) % R3;  // DSP l = 0: (-16) mod 3 = 2 (only the DMA issue of steps 13..15 uses it)
       const int t0 = DB ? L0 + 16 * (l - 1) : 16 * l;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) epi(0, c, sb, raw, skip, Bc);
+      for (int c = 0; c < 4; ++c) epi(0, c, 0, raw, skip, Bc);
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         if (j + 1 < 16)
-          kstep(t0 + j, j, [&](int c) { epi(j + 1, c, (sb + j + 1) % R3, raw, skip, Bn); });
+          kstep(t0 + j, j, [&](int c) { epi(j + 1, c, (j + 1) & 3, raw, skip, Bn); });
         else
           kstep(t0 + j, j, no_next);
       }
@@ -449,7 +446,7 @@ template <int MODE, bool A2>
 static int rchain_launch(const RCArgs& a, hipStream_t s) {
   constexpr bool DB = MODE == RC_DBWD;
   constexpr int NAUX = (DB || A2) ? 2 : 1;
-  constexpr int lds = R3 * SLOT + NW * R3 * NAUX * 2 * PIECE + (DB ? NW * 32 * IN_STR * 4 : 0);
+  constexpr int lds = R3 * SLOT + NW * SIDE_RING * NAUX * 2 * PIECE + (DB ? NW * (32 * IN_STR + 4) * 4 : 0);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static int n_cu = 0;
   static bool attr_set = false;

@@ -45,8 +45,11 @@ class MeshIndex:
         h = 0.5 * self.thr  # h * sqrt(3) = 0.87 thr < thr
         margin = self.thr + 2.0 * h
         G = int(torch.ceil(torch.tensor((ext + 2 * margin) / h))) + 1
-        if G > max_nodes:
-            raise ValueError(f"MeshIndex: threshold {self.thr} needs a {G}^3 node grid for a mesh of extent {ext:.3f}")
+        # a mesh too large for the node grid (an object whose canonical extent is >> the threshold) falls back to the
+        # exact brute-force test the index accelerates (what the reference always runs through kaolin)
+        self.brute = G > max_nodes
+        if self.brute:
+            return
         self.G, self.h = G, h
         ctr = 0.5 * (lo + hi)
         self.origin = (ctr - 0.5 * (G - 1) * h).tolist()
@@ -82,6 +85,8 @@ class MeshIndex:
     def off_surface(self, x_cano, num_rays):
         """x_cano [..., 3] canonical sample points, ray-major (num_rays x S) -> bool [num_rays]."""
         x = x_cano.detach().reshape(-1, x_cano.shape[-1])
+        if self.brute:
+            return check_off_in_surface_points_cano_mesh(self.verts, self.faces, x[None, :, :3].float(), num_rays, self.thr)[0]
         if x.dtype != torch.float32 or x.stride(1) != 1:
             x = x.float().contiguous()
         S = x.shape[0] // num_rays

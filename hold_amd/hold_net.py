@@ -58,7 +58,15 @@ class BarfEmbedder(Embedder):
         self.alphas = torch.cat((torch.zeros(start), torch.linspace(0, num_freq, end - start)), 0)
         self.register_buffer("alpha_iter", torch.tensor(0))
         self.register_buffer("alpha_max_iter", torch.tensor(len(self.alphas)))
+        self._iter_host = 0  # host mirror of alpha_iter: step() must not read a device buffer back (a sync per node and step)
+        self._register_load_state_dict_pre_hook(self._sync_host_counter)
         self.populate(self.alphas[int(self.alpha_iter)])
+
+    def _sync_host_counter(self, state_dict, prefix, *args):
+        v = state_dict.get(prefix + "alpha_iter")
+        if v is not None:
+            self._iter_host = int(v)
+            self.populate(self.alphas[min(self._iter_host, len(self.alphas) - 1)])
 
     def populate(self, alpha):
         k = torch.arange(self.num_freq, dtype=torch.float32)
@@ -71,9 +79,9 @@ class BarfEmbedder(Embedder):
         self.barf_weights = torch.cat((torch.ones(self.input_dims), w), 0)
 
     def step(self):
-        self.alpha_iter = torch.tensor(min(int(self.alpha_iter) + 1, int(self.alpha_max_iter) - 1),
-                                       device=self.alpha_iter.device)
-        self.populate(self.alphas[int(self.alpha_iter)])
+        self._iter_host = min(self._iter_host + 1, len(self.alphas) - 1)
+        self.alpha_iter.fill_(self._iter_host)  # the checkpointed buffer follows, without a device-to-host read
+        self.populate(self.alphas[self._iter_host])
 
     def eval(self):  # embedders.py:124-125
         self.no_barf = True
@@ -720,6 +728,8 @@ class ObjectNode(Node):
     def update_cano(self, mesh_canonical):
         """object_node.py:123-132 (``mesh_o``, kaolin's face-vertex tensor, is kept as the face-gathered vertices)."""
         dev = self.frame_latent_encoder.weight.device
+        if mesh_canonical is None or len(np.asarray(mesh_canonical.vertices)) == 0 or len(np.asarray(mesh_canonical.faces)) == 0:
+            return  # no zero crossing in the box (the reference's generate_mesh returns None): keep the previous targets
         self.mesh_vo_cano = torch.as_tensor(np.asarray(mesh_canonical.vertices)[None], device=dev).float()
         self.mesh_fo_cano = torch.as_tensor(np.asarray(mesh_canonical.faces).astype(np.int64), device=dev)
         self.mesh_o = self.mesh_vo_cano[:, self.mesh_fo_cano]
@@ -915,6 +925,14 @@ class HOLDNet(nn.Module):
                 if ("hand_poses" in ent) or ("object_poses" in ent):
                     node.params.load_entity(ent)
         self.auto_step_embedding = True  # train_step() steps the BARF counter once per optimiser step instead
+        # weight packs are cached per node and keyed on torch's version counters; writes those counters do not see
+        # (load_state_dict copies through .data on some paths, .to() / .float() re-create the storages) bump the epoch
+        self.register_load_state_dict_post_hook(lambda module, incompatible: config.bump_weights_epoch())
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        config.bump_weights_epoch()
+        return out
 
     def init_network(self, shape_init=""):
         """hold_net.py:136-152: optionally start the hand / object SDF nets from a pre-trained checkpoint."""

@@ -14,7 +14,7 @@ Semantics vs ``torch.optim.Adam``: identical arithmetic per element (bias correc
 parameter whose ``.grad`` torch would leave ``None`` (no gradient at all this step) is treated as having a zero
 gradient, i.e. its moments decay and the bias-correction step is the global one -- HOLD's parameters all receive
 gradients from step 0, where the two coincide (verified against torch.optim.Adam in
-tests/test_train_targets_gpu.py::test_flat_adam_matches_torch_adam_with_clip).
+tests/test_train_targets_gpu.py::test_flat_adam_matches_torch_adam_with_clipping).
 """
 from __future__ import annotations
 

@@ -254,10 +254,20 @@ def test_field_chain_route_matches_layered_route(kind, node):
     # order).  Downstream of it sits the rendering net's ReLU: a pre-activation within rounding of zero switches its
     # unit on in one route and off in the other, which moves that unit's share of a weight gradient discontinuously
     # -- a few such flips among 666 points x 1 024 units bound the agreement of the rendering-net gradients at ~1 %.
-    tol = {"iw": 2e-4, "ib": 2e-4, "rw": 1e-2, "rb": 1e-2}
-    for k in ("iw", "ib", "rw", "rb"):
+    # Trunk gradients (no discontinuity between them and the inputs): 2e-4 of the tensor's largest entry, every entry.
+    # Rendering-net gradients: a flipped (point, unit) pair moves ONE point's contribution to ONE row (256 entries =
+    # 0.4 %) of a weight gradient, so the bulk of the entries agree to rounding and a few rows carry a flip -- the test
+    # holds 98 % of the entries of every tensor to 2e-4, the flipped rows to 5 % of the largest entry, and every tensor
+    # to 0.2 % in norm.
+    for k in ("iw", "ib"):
         for i, (a, b) in enumerate(zip(ga[k], gb[k])):
-            assert (a - b).abs().max().item() <= tol[k] * max(1e-3, a.abs().max().item()), (k, i)
+            assert (a - b).abs().max().item() <= 2e-4 * max(1e-3, a.abs().max().item()), (k, i)
+    for k in ("rw", "rb"):
+        for i, (a, b) in enumerate(zip(ga[k], gb[k])):
+            scale = max(1e-3, a.abs().max().item())
+            d = (a - b).abs().reshape(-1)
+            assert (d > 2e-4 * scale).float().mean().item() <= 2e-2, (k, i, (d > 2e-4 * scale).float().mean().item())
+            assert d.max().item() <= 5e-2 * scale, (k, i)
             assert (a - b).norm().item() <= 2e-3 * max(1e-3, a.norm().item()), (k, i)  # and in norm they agree to 0.2 %
     for k in ("tfs", "pose_embed", "time_code"):
         if ga[k] is None:

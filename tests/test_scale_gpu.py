@@ -2,7 +2,8 @@
 kernel launch), where the oracle cannot run the whole call:
 
 * the oracle is run on 1 024 rays drawn at random from the 16 384-ray call, with the HIP sampler's z_vals for exactly
-  those rays fed in, and every rendered quantity of those rays must agree to 1e-4 (north_star tolerance);
+  those rays fed in, and every rendered quantity of EVERY ray that is not a K = 15 nearest-vertex tie ray (identified
+  from the oracle's own distances) must agree to 1e-4 (north_star tolerance); the tie rays are bounded separately;
 * linearity: parameter gradients of the one 16 384-ray call == the sum over sixteen 1 024-ray calls (same z, same
   draws) to 1e-5 relative -- large launches and small launches of every kernel agree;
 * full 512x512 frame through size-independent invariants (range, sortedness, partition of unity, determinism).
@@ -127,20 +128,48 @@ def _run_chunk_case(two_hands, n_rays):
     ex = {}
     oo = ho.holdnet_forward(osc, sd, oinp, True, rng=rng, z_override={n: zfull[n][sel.cuda()].cpu() for n in nodes},
                             current_epoch=0, barf_alpha_iter=4000, extras=ex, stable_merge=True)
-    # Two discontinuities of the path make a FEW rays differ by more than rounding, in the reference's own arithmetic as
-    # much as here: the K = 15 nearest-vertex selection (a sample equidistant from its 15th and 16th MANO vertex to fp32
-    # rounding gets a different skinning blend -- far from the hand that is every sample, but the density there is zero)
-    # and ties in the merge of the nodes' samples.  So the 1e-4 bar is applied to the rays' 98 % quantile (at least 1 004
-    # of the 1 024 rays agree on EVERY output to 1e-4) and the worst ray is bounded separately.
+    # ONE discontinuity of the path makes a few rays differ by more than rounding, in the reference's own arithmetic as
+    # much as here: the K = 15 nearest-vertex selection of the KNN deformer (code/src/model/mano/deformer.py:84-105) -- a
+    # sample whose 15th and 16th nearest MANO vertex are equidistant to fp32 rounding gets one or the other into its
+    # skinning blend depending on the last bit of the distance arithmetic.  (Ties of the merge are not a difference
+    # here: the oracle runs with stable_merge=True, the HIP merge is stable.)  The test therefore IDENTIFIES the tie
+    # rays from the oracle's own distances -- a ray is a tie ray iff one of its samples that carries compositing weight
+    # (> 1e-6) has a relative gap < TIE_GAP between its 15th and 16th squared vertex distance -- and holds EVERY other
+    # ray to 1e-4 on every output; the tie rays themselves are bounded too (a one-vertex change of a 15-vertex blend).
+    TIE_GAP = 1e-6
+    ray_o, ray_d = oo["cam_loc"].detach().view(-1, 3), oo["ray_dirs"].detach().view(-1, 3)
+    tie = torch.zeros(1024, dtype=torch.bool)
+    gap_min = torch.full((1024,), 1.0)
+    for n in nodes:
+        if n == "object":
+            continue
+        z = zfull[n][sel.cuda()].cpu()
+        x = ray_o[:, None, :] + z[:, :, None] * ray_d[:, None, :]  # [1024, S, 3] deformed-space samples
+        verts = ex[n]["verts"].detach().reshape(-1, 3)  # posed MANO vertices of the frame
+        xs = x.reshape(-1, 3)
+        top = torch.cat([torch.topk(((xc[:, None, :] - verts[None]) ** 2).sum(-1), 16, dim=1, largest=False, sorted=True).values
+                         for xc in xs.split(8192)])
+        gap = ((top[:, 15] - top[:, 14]) / top[:, 14].clamp_min(1e-12)).view(1024, S)
+        w = oo[n + ".fg_weights"].detach().view(1024, -1)
+        wmax = torch.zeros(1024, S)
+        wmax[:, :w.shape[1]] = w  # per-node weights of the S samples (the oracle drops none of a single node's)
+        carried = wmax > 1e-6
+        g_ray = torch.where(carried, gap, torch.ones_like(gap)).min(dim=1).values
+        gap_min = torch.minimum(gap_min, g_ray)
+        tie |= g_ray < TIE_GAP
     outputs = []
+    n_tie = int(tie.sum())
+    outputs.append(("number of tie rays (must stay a small minority)", float(n_tie), 64.0))
     for k in outc:
         ref = oo[k].detach()
         err = (outc[k][sel] - ref).abs().reshape(1024, -1).max(dim=1).values
         # the three-node rendered normal is the one ill-conditioned quantity (normalised gradient where |grad sdf| is small,
         # three overlapping nodes): 5e-4 there, as in the round-1 three-node test
-        tol = (5e-4 if (two_hands and k.endswith("normal")) else 1e-4) * max(1.0, float(ref.abs().max()))
-        outputs.append((k, float(torch.quantile(err, 0.98)), tol))
-        outputs.append((k + "[worst ray]", float(err.max()), 0.25 * max(1.0, float(ref.abs().max()))))
+        scale = max(1.0, float(ref.abs().max()))
+        tol = (5e-4 if (two_hands and k.endswith("normal")) else 1e-4) * scale
+        outputs.append((k + "[every non-tie ray]", float(err[~tie].max()), tol))
+        if n_tie:
+            outputs.append((k + "[tie rays]", float(err[tie].max()), 0.05 * scale))
     for n in nodes:
         ref = ex[n]["sdf"].detach().view(1024, S)
         dens = float(ex[n]["sdf"].detach().abs().max())
