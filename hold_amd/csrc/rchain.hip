@@ -33,7 +33,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int NW = 4, BPTS = 32 * NW, PIECE = 1024, SLOT = 24 * PIECE, R3 = 3;
+constexpr int NW = 4, BPTS = 32 * NW, PIECE = 1024, SLOT = 24 * PIECE;
 constexpr int SKIP_OUT = 217, IN_STR = 44, SIDE_RING = 4;
 enum { RC_DSP = 1, RC_DBWD = 2 };
 
@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int L = DB ? 8 : 7;              // chain layers
   constexpr int L0 = DB ? 3 : 16;            // k steps of chain layer 0
   constexpr int NST = L0 + 16 * (L - 1);     // k steps per block of points
+  constexpr int R3 = DB ? 3 : 4;             // weight ring slots (LDS budget); DMA distance R3 - 1 steps
   constexpr int SIDE_SLOT = NAUX * 2 * PIECE;
   constexpr int OFF_SIDE = R3 * SLOT;
   constexpr int OFF_IN = OFF_SIDE + NW * SIDE_RING * SIDE_SLOT;  // DBWD: the [32][IN_STR] (+ 4) input rows of each wave
@@ -150,7 +151,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // that weight DMA, the previous step's stores B, this step's stores A.  Waiting down to this count lands the weights
   // (needed now) and every side fragment issued ONE rendezvous earlier, while the newest side fragments stay in flight:
   // they get two full steps, the L2-resident weights one.
-  constexpr int NWAIT = 2 * NAUX + 2 * NOUT;
+  // With a 4-slot weight ring the weights needed next were requested TWO rendezvous ago, like the side fragments consumed in
+  // the next step (which sit right behind them in the queue): everything younger -- the previous rendezvous' 6 weight
+  // pieces and side request, two steps' stores -- may stay in flight; weights and side both get two full steps.
+  constexpr int NWAIT = R3 == 4 ? 6 + 2 * NAUX + 4 * NOUT : 2 * NAUX + 2 * NOUT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -190,9 +194,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int r = 0; r < 16; ++r) Q[nt][r] = 0.f;
   };
 
-  // the first two k steps of the stream; gs counts k steps over all blocks (ring slot = gs % 3)
-  dma_w(a.wpack, lane16, 0, 0, wave);
-  dma_w(a.wpack, lane16, 1, 1, wave);
+  // the first R3 - 1 k steps of the stream; gs counts k steps over all blocks (ring slot = gs % R3)
+#pragma unroll
+  for (int s0 = 0; s0 < R3 - 1; ++s0) dma_w(a.wpack, lane16, s0, s0, wave);
   int gs = 0;
   int first = 1;
 
@@ -216,11 +220,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     } else {  // [P][40] rows -> wave-private LDS (layer-0 B operand in natural k order + the skip-layer side)
       const float* xr = a.in + crow * a.ld_in + 24 * hh;
+      // columns 40..43 are zero padding inside the row; the natural-order k step 2 also reads 44..47 = the next row's
+      // first values (finite, multiplied by the zero columns of the packed layer 0) -- nobody WRITES beyond column 43
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (24 * hh + 4 * i < 40) v = *reinterpret_cast<const f32x4*>(xr + 4 * i);
-        *reinterpret_cast<f32x4*>(inw + li * IN_STR + 24 * hh + 4 * i) = v;
+        if (24 * hh + 4 * i < IN_STR) *reinterpret_cast<f32x4*>(inw + li * IN_STR + 24 * hh + 4 * i) = v;
       }
     }
     if (first) {
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // step (l, jp) the side fragments of epilogue k step 16 (l - 1) + jp + 4 are requested (consumed three steps later,
     // side slot = k step % 4: 16 is a multiple of the ring).
     auto kstep = [&](int tl, int jp, auto&& nextB) {
-      const int slot = gs % R3, nslot = (gs + 1) % R3, fslot = (gs + 2) % R3;
+      const int slot = gs % R3, nslot = (gs + 1) % R3, fslot = (gs + R3 - 1) % R3;
 #pragma unroll
       for (int pair = 0; pair < 4; ++pair) {
         if (pair < 3) {
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (pair == 2) {  // rendezvous: the weights of step gs + 1 have landed in every wave; slot gs - 1 is free
           RC_WAIT_VM(NWAIT);
           __builtin_amdgcn_s_barrier();
-          dma_w(a.wpack, lane16, (tl + 2) % NST, fslot, wave);
+          dma_w(a.wpack, lane16, (tl + R3 - 1) % NST, fslot, wave);
           const int jc = (jp + 4) & 15, sslot = jp & 3;
           dma_side((jp < 12 ? lo1 : hi1) + 16 * jc, ld_off, side_dst0 + sslot * SIDE_SLOT);
           if (NAUX == 2) dma_side((jp < 12 ? lo2 : hi2) + 16 * jc, ld_off, side_dst0 + sslot * SIDE_SLOT + 2 * PIECE);
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       dma_side(lo2, ld_off, side_dst0 + 2 * PIECE);
 #pragma unroll
       for (int j = 0; j < L0; ++j) {
-        const int slot = gs % R3, nslot = (gs + 1) % R3, fslot = (gs + 2) % R3;
+        const int slot = gs % R3, nslot = (gs + 1) % R3, fslot = (gs + R3 - 1) % R3;
 #pragma unroll
         for (int pair = 0; pair < 4; ++pair) {
           if (pair < 3) {
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           if (pair == 2) {
             RC_WAIT_VM(NWAIT);
             __builtin_amdgcn_s_barrier();
-            dma_w(a.wpack, lane16, (j + 2) % NST, fslot, wave);
+            dma_w(a.wpack, lane16, (j + R3 - 1) % NST, fslot, wave);
             dma_side(lo1 + 16 * (j + 1), ld_off, side_dst0 + (j + 1) * SIDE_SLOT);
             dma_side(lo2 + 16 * (j + 1), ld_off, side_dst0 + (j + 1) * SIDE_SLOT + 2 * PIECE);
           }
@@ -446,7 +452,7 @@ template <int MODE, bool A2>
 static int rchain_launch(const RCArgs& a, hipStream_t s) {
   constexpr bool DB = MODE == RC_DBWD;
   constexpr int NAUX = (DB || A2) ? 2 : 1;
-  constexpr int lds = R3 * SLOT + NW * SIDE_RING * NAUX * 2 * PIECE + (DB ? NW * (32 * IN_STR + 4) * 4 : 0);
+  constexpr int lds = (DB ? 3 : 4) * SLOT + NW * SIDE_RING * NAUX * 2 * PIECE + (DB ? NW * (32 * IN_STR + 4) * 4 : 0);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static int n_cu = 0;
   static bool attr_set = false;

@@ -568,8 +568,10 @@ class OracleScene:
     """Holds constant tensors derived from the scene + MANO model (what the reference
     computes in the MANOServer / MANODeformer / ObjectServer constructors)."""
 
-    def __init__(self, scene, mano_models: dict, dtype=torch.float32):
+    def __init__(self, scene, mano_models: dict, dtype=torch.float32, N_samples=64):
         self.dtype = dtype
+        # ray_sampler.N_samples of the config (general.yaml:71): 64 shipped; BASELINE.json configs[0] uses 32, configs[4] 128
+        self.N_samples = N_samples
         self.R = float(scene["scene_bounding_sphere"])
         self.nodes = list(scene["entities"].keys())
         self.mano, self.verts_c, self.tfs_c_inv, self.skin_w = {}, {}, {}, {}
@@ -632,6 +634,7 @@ def node_forward(osc: OracleScene, sd, node, inp, ray_dirs, cam_loc, is_training
     if z_vals_override is None:
         with torch.no_grad():
             z_vals, iters = error_bound_sample(z0, sdf_only, cam_loc, ray_dirs, beta0, osc.R, is_training, rng,
+                                               N_samples=getattr(osc, "N_samples", 64),
                                                trace=(extras.setdefault("trace", []) if extras is not None else None))
     else:
         z_vals = z_vals_override

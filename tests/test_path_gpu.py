@@ -280,6 +280,42 @@ def test_two_hand_scene_three_nodes():
     assert torch.equal(out["instance_map"].cpu(), oo["instance_map"])
 
 
+@pytest.mark.parametrize("n_samples,W,frames", [(32, 64, [0]), (128, 16, [0, 1])])
+def test_c1_c5_sampler_configs_match_oracle(ctx, n_samples, W, frames):
+    """BASELINE.json configs[0] (C1: 64 x 64 rays, N_samples = 32 -> 66 z per node) and configs[4] (C5: N_samples = 128 ->
+    162 z per node) against the oracle: the sampler end to end (same number of rounds, < 2 % of the samples moved by the
+    discontinuous inverse-CDF stage), and -- with the ORACLE's z fed in -- every rendered output to 1e-4."""
+    import hold_amd
+    from hold_amd.hold_net import DEFAULT_SAMPLER
+    from hold_amd import synthetic as syn
+    sc, sd = ctx["sc"], ctx["sd"]
+    mano = {"right": syn.make_mano_model(True), "left": syn.make_mano_model(False)}
+    osc = ho.OracleScene(sc, mano, N_samples=n_samples)
+    b, oinp = oracle_input(sc, sd, frames, W, W)
+    ex = {}
+    oo = ho.holdnet_forward(osc, sd, oinp, False, extras=ex, stable_merge=True)
+    net = hold_amd.build_from_scene(sc, ctx["sd_np"], device="cuda:0", sampler_opt=dict(DEFAULT_SAMPLER, N_samples=n_samples))
+    for node in net.nodes.values():
+        node.params.defrost()
+        node.implicit_network.embedder_obj.step()
+        node.implicit_network.embedder_obj.eval()
+    net.eval()
+    S = n_samples + 2 + 32
+    out = net(hip_input(b, net))
+    for n in sc["entities"]:
+        z = out[n + ".z_vals"].cpu()
+        assert z.shape[1] == S and oo[n + ".z_vals"].shape[1] == S
+        assert torch.all(z[:, 1:] >= z[:, :-1])
+        assert net.nodes[n].ray_sampler.last_iters == ex[n]["iters"]
+        dz = (z - oo[n + ".z_vals"]).abs()
+        assert float((dz > 1e-3).float().mean()) < 0.02, (n, float(dz.max()))
+    assert out["fg_weights"].shape[1] == 2 * S - 3
+    out = net(hip_input(b, net), z_override={n: oo[n + ".z_vals"].cuda() for n in sc["entities"]})
+    for k in OUT_KEYS:
+        assert float((out[k].cpu() - oo[k].detach()).abs().max()) < 1e-4 * max(1.0, float(oo[k].abs().max())), k
+    assert torch.equal(out["instance_map"].cpu(), oo["instance_map"])
+
+
 def test_c5_sampler_config_128_samples():
     """config C5 sampling (N_samples = 128 -> 162 samples per node): shapes + invariants."""
     import hold_amd
