@@ -163,7 +163,6 @@ def _declare(L):
     L.hold_fused_sdf_pack_floats.restype = C.c_int64
     L.hold_fused_sdf_x6_pack_bytes.restype = C.c_int64
     L.hold_trunk_r6_pack_bytes.restype = C.c_int64
-    L.hold_chain_r6_pack_bytes.argtypes = [C.c_int32]
     L.hold_chain_r6_pack_bytes.restype = C.c_int64
     L.hold_chain_pack_floats.argtypes = [C.c_int32, C.c_int32]
     L.hold_chain_pack_floats.restype = C.c_int64

@@ -1,13 +1,16 @@
-// Register-resident BACKWARD sweeps of the ImplicitNet trunk (gfx950) -- the descending sweeps (d sdf / d a_l of the normal
-// path and the first-order backward) and the ascending second-order sweep that torch.autograd derives from
-// ImplicitNet.forward (code/src/networks/shape_net.py:84-130) under create_graph=True (code/src/engine/volsdf_utils.py:71-96),
-// in the structure of csrc/rmlp.hip: one wave per SIMD owns 32 points for the whole chain, a layer's 256 x 32 outputs stay
+// Register-resident DESCENDING sweeps of the ImplicitNet trunk (gfx950) -- d sdf / d a_l of the normal path and the
+// first-order backward that torch.autograd derives from ImplicitNet.forward (code/src/networks/shape_net.py:84-130;
+// code/src/engine/volsdf_utils.py:71-96) -- in the structure of csrc/rmlp.hip: one wave per SIMD owns 32 points for the whole chain, a layer's 256 x 32 outputs stay
 // in the wave's accumulator registers, and -- after the per-layer epilogue -- ARE the next layer's MFMA B operand (the
 // "virtual k order" of rmlp.hip: k step j, element e of lane half hh <-> feature 16 j + 8 (e / 4) + 4 hh + e % 4).
 //
-//   RC_DSP   v_{l-1} = (M_j v_l) * sp'(aux1_j) [+ aux2_j]                         7 layers, input v_7 [P][256]
-//   RC_DBWD  tb = M_j vb ; out_j = tb * sp'(aux1_j) ; out2_j = 100 tb aux2_j (1 - sp'(aux1_j))   8 layers, input [P][40]
-//   (the semantics of hold_chain / hold_chain_x6 with skip_layer = 3, include/hold_hip.h)
+//   v_{l-1} = (M_j v_l) * sp'(aux1_j) [+ aux2_j]          7 layers, input v_7 [P][256]
+//   (the semantics of hold_chain / hold_chain_x6, mode DSP, skip_layer = 3, include/hold_hip.h)
+// The ascending second-order sweep (mode DBWD: two side inputs and two results per layer) was built in this structure too
+// and measured SLOWER than hold_chain_x6 (85 vs 108 TF-eq, matrix pipe 22 % busy, 57 % of the wave time stalled at issue):
+// a lane owns a POINT here, so side inputs and results move as 32-byte row fragments -- four L2 requests per 128-byte
+// line where the LDS-resident kernel's feature-per-lane layout issues one -- and at 4 KiB per point and layer the L2
+// request rate, not the matrix pipe, is the bound.  It was removed again (git history); DBWD stays on hold_chain_x6.
 //
 // What streams: the weight limbs (24 KiB per 16-wide k step, LDS ring of 3 slots filled by LDS-DMA two steps ahead,
 // shared by the four waves) and, new here, the per-layer SIDE inputs -- for every k step the 8 stored h (and a2 / t)
@@ -19,7 +22,7 @@
 // fragments that follow them in the queue -- these get two full steps of HBM latency.  The results (next layer's input) are stored with
 // 16-byte row-fragment stores straight from the epilogue.
 // Exposed per block of 128 points: loading the chain input (32 x 16 B per lane) and the epilogue of the LAST layer.
-// Roofline: bf16 MFMA pipe; HBM bytes per point and layer: DSP 2 KiB (1 side + 1 out), DSP + a2 3 KiB, DBWD 4 KiB.
+// Roofline: bf16 MFMA pipe; HBM bytes per point and layer: DSP 2 KiB (1 side + 1 out), DSP + a2 3 KiB.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -34,18 +37,16 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int NW = 4, BPTS = 32 * NW, PIECE = 1024, SLOT = 24 * PIECE;
-constexpr int SKIP_OUT = 217, IN_STR = 44, SIDE_RING = 4;
-enum { RC_DSP = 1, RC_DBWD = 2 };
+constexpr int SKIP_OUT = 217, SIDE_RING = 4;
 
 struct RCArgs {
   long P;
-  const char* wpack;      // DSP: 7 x 16 k steps; DBWD: 3 + 7 x 16 (the stream of hold_trunk_r6)
-  const float* in;        // DSP: v_7 [P][ld_in >= 256]; DBWD: [P][ld_in >= 40] (layer-0 input and the skip-layer side)
+  const char* wpack;      // 7 x 16 k steps
+  const float* in;        // v_7 [P][ld_in >= 256]
   int ld_in, ld;
   const float* aux1[8];
   const float* aux2[8];
   float* out[8];
-  float* out2[8];
 };
 
 __device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
@@ -82,10 +83,10 @@ __device__ __forceinline__ void put_limbs(Limbs& out, int c, Split3 s) {  // pin
   out.l[2][c] = s.p3;
 }
 
-// softplus'(a) recovered from h = softplus(a): 1 - e^{-100 h}; e is returned too (the second-order gate needs it)
-__device__ __forceinline__ float dsp_e(float h, float& e) {
+// softplus'(a) recovered from h = softplus(a): 1 - e^{-100 h} (series where the subtraction would cancel)
+__device__ __forceinline__ float dsp(float h) {
   const float x = 100.0f * h;
-  e = __builtin_amdgcn_exp2f(-144.26950408889634f * h);
+  const float e = __builtin_amdgcn_exp2f(-144.26950408889634f * h);
   const float ser = x * (1.0f - x * (0.5f - x * (0.16666667f - 0.041666668f * x)));
   return (x < 0.05f) ? ser : 1.0f - e;
 }
@@ -134,27 +135,24 @@ __device__ __forceinline__ void dma_side(const float* base, uint32_t rowoff, uin
 
 #define RC_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
-template <int MODE, bool A2>
+template <bool A2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rchain_kernel(RCArgs a) {
-  constexpr bool DB = MODE == RC_DBWD;
-  constexpr int NAUX = (DB || A2) ? 2 : 1;   // side matrices per layer
-  constexpr int NOUT = DB ? 2 : 1;           // result matrices per layer
-  constexpr int L = DB ? 8 : 7;              // chain layers
-  constexpr int L0 = DB ? 3 : 16;            // k steps of chain layer 0
-  constexpr int NST = L0 + 16 * (L - 1);     // k steps per block of points
-  constexpr int R3 = DB ? 3 : 4;             // weight ring slots (LDS budget); DMA distance R3 - 1 steps
+  constexpr int NAUX = A2 ? 2 : 1;           // side matrices per layer
+  constexpr int NOUT = 1;                    // result matrices per layer
+  constexpr int L = 7;                       // chain layers
+  constexpr int NST = 16 * L;                // k steps per block of points
+  constexpr int R3 = 4;                      // weight ring slots; DMA distance R3 - 1 steps
   constexpr int SIDE_SLOT = NAUX * 2 * PIECE;
   constexpr int OFF_SIDE = R3 * SLOT;
-  constexpr int OFF_IN = OFF_SIDE + NW * SIDE_RING * SIDE_SLOT;  // DBWD: the [32][IN_STR] (+ 4) input rows of each wave
   constexpr int VPER = 4;
   // VMEM operations issued between the weight DMA of the previous rendezvous and this one's wait: the side DMA that follows
   // that weight DMA, the previous step's stores B, this step's stores A.  Waiting down to this count lands the weights
   // (needed now) and every side fragment issued ONE rendezvous earlier, while the newest side fragments stay in flight:
   // they get two full steps, the L2-resident weights one.
-  // With a 4-slot weight ring the weights needed next were requested TWO rendezvous ago, like the side fragments consumed in
-  // the next step (which sit right behind them in the queue): everything younger -- the previous rendezvous' 6 weight
-  // pieces and side request, two steps' stores -- may stay in flight; weights and side both get two full steps.
-  constexpr int NWAIT = R3 == 4 ? 6 + 2 * NAUX + 4 * NOUT : 2 * NAUX + 2 * NOUT;
+  // The weights needed next were requested TWO rendezvous ago, like the side fragments consumed in the next step (which
+  // sit right behind them in the queue): everything younger -- the previous rendezvous' 6 weight pieces and side request,
+  // two steps' stores -- may stay in flight; weights and side both get two full steps.
+  constexpr int NWAIT = 6 + 2 * NAUX + 4 * NOUT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -163,7 +161,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const char* ring_lane = smem + lane * 16;
   const uint32_t side_dst0 = (uint32_t)(OFF_SIDE + wave * (SIDE_RING * SIDE_SLOT));
   const float* side_rd = reinterpret_cast<const float*>(smem + OFF_SIDE + wave * (SIDE_RING * SIDE_SLOT)) + lane * 4;
-  float* inw = reinterpret_cast<float*>(smem + OFF_IN) + wave * (32 * IN_STR + 4);
   const uint32_t nbytes = (uint32_t)(a.P * a.ld * 4);
 
   f32x16 P[8], Q[8];
@@ -206,8 +203,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const uint32_t st_off = (uint32_t)((row * a.ld + 4 * hh) * 4);   // stores: unclamped, the buffer range check drops them
     const uint32_t ld_off = (uint32_t)((crow * a.ld + 4 * hh) * 4);  // side DMA source
 
-    // ---- chain input ----
-    if (!DB) {  // v_7 rows into the accumulator layout: P[nt][4 g + k] = in[row][32 nt + 8 g + 4 hh + k]
+    // ---- chain input: v_7 rows into the accumulator layout, P[nt][4 g + k] = in[row][32 nt + 8 g + 4 hh + k] ----
+    {
       const rsrc_t irs = make_rsrc(a.in, (uint32_t)(a.P * a.ld_in * 4));
       const uint32_t ioff = (uint32_t)((row * a.ld_in + 4 * hh) * 4);
 #pragma unroll
@@ -218,16 +215,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
           for (int k = 0; k < 4; ++k) P[nt][4 * g + k] = bitsf(v[k]);
         }
-    } else {  // [P][40] rows -> wave-private LDS (layer-0 B operand in natural k order + the skip-layer side)
-      const float* xr = a.in + crow * a.ld_in + 24 * hh;
-      // columns 40..43 are zero padding inside the row; the natural-order k step 2 also reads 44..47 = the next row's
-      // first values (finite, multiplied by the zero columns of the packed layer 0) -- nobody WRITES beyond column 43
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (24 * hh + 4 * i < 40) v = *reinterpret_cast<const f32x4*>(xr + 4 * i);
-        if (24 * hh + 4 * i < IN_STR) *reinterpret_cast<f32x4*>(inw + li * IN_STR + 24 * hh + 4 * i) = v;
-      }
     }
     if (first) {
       RC_WAIT_VM(0);
@@ -276,8 +263,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // epilogue of one dword (two values) of k step j of the finished layer in P; lw = its chain layer (wave-uniform),
     // raw = DSP layer 0 (the chain input itself is the B operand).  Side values from this wave's LDS ring slot `ss`.
-    rsrc_t ors = make_rsrc(nullptr, 0), ors2 = make_rsrc(nullptr, 0);
-    f32x4 keep = {0.f, 0.f, 0.f, 0.f}, keep2 = {0.f, 0.f, 0.f, 0.f};
+    rsrc_t ors = make_rsrc(nullptr, 0);
+    f32x4 keep = {0.f, 0.f, 0.f, 0.f};
     auto epi = [&](int j, int c, int ss, bool raw, bool skip, Limbs& out) {
       const int nt = j >> 1, q = j & 1;
       const int f0 = 16 * j + 8 * (c >> 1) + 4 * hh + 2 * (c & 1);
@@ -285,95 +272,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const f32x2 hv = *reinterpret_cast<const f32x2*>(sp);
       f32x2 xv = {0.f, 0.f};
       if (NAUX == 2) xv = *reinterpret_cast<const f32x2*>(sp + 2 * (PIECE / 4));
-      float r[2], r2[2];
+      float r[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const float y = P[nt][8 * q + 2 * c + i];
-        float e;
-        const float s = dsp_e(hv[i], e);
-        if (!DB) {
-          float v = y * s;
-          if (A2) v += xv[i];
-          r[i] = raw ? y : v;
-          r2[i] = 0.f;
-        } else {
-          r[i] = y * s;
-          r2[i] = 100.0f * y * xv[i] * e;
-        }
+        float v = y * dsp(hv[i]);
+        if (A2) v += xv[i];
+        r[i] = raw ? y : v;
       }
-      if (j >= 13) {  // skip layer (chain layer 3), columns 217..: DSP stores the raw products, DBWD takes the side input
+      if (j >= 13) {  // skip layer (chain layer 3), columns 217..: the raw products (d / d skip input) are stored
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int m = f0 + i - SKIP_OUT;
-          const bool sp_ = skip && m >= 0;
-          if (!DB) {
-            r[i] = sp_ ? P[nt][8 * q + 2 * c + i] : r[i];
-          } else {
-            const float sv = inw[li * IN_STR + (m < 0 ? 0 : m)];
-            r[i] = sp_ ? sv : r[i];
-            r2[i] = sp_ ? 0.f : r2[i];
-          }
-        }
+        for (int i = 0; i < 2; ++i) r[i] = (skip && f0 + i >= SKIP_OUT) ? P[nt][8 * q + 2 * c + i] : r[i];
       }
       put_limbs(out, c, split2(r[0], r[1]));
       keep[2 * (c & 1)] = r[0];
       keep[2 * (c & 1) + 1] = r[1];
-      if (DB) {
-        keep2[2 * (c & 1)] = r2[0];
-        keep2[2 * (c & 1) + 1] = r2[1];
-      }
-      if (c & 1) {
-        store4(keep, ors, st_off + (16 * j + 8 * (c >> 1)) * 4);
-        if (DB) store4(keep2, ors2, st_off + (16 * j + 8 * (c >> 1)) * 4);
-      }
+      if (c & 1) store4(keep, ors, st_off + (16 * j + 8 * (c >> 1)) * 4);
     };
 
-    int l0 = 0;
-    if (DB) {  // chain layer 0: K = 48 from the staged input rows, natural k order 16 j + 8 hh + e
-      auto in_limbs = [&](int j, int c, Limbs& out) {
-        const float* er = inw + li * IN_STR + 16 * j + 8 * hh + 2 * c;
-        put_limbs(out, c, split2(er[0], er[1]));
-      };
-      zero_q();
-#pragma unroll
-      for (int c = 0; c < 4; ++c) in_limbs(0, c, Bc);
-      // epilogue k step 0 of chain layer 0 is requested here, k steps 1..3 at the rendezvous of this layer's three steps
-      dma_side(lo1, ld_off, side_dst0);
-      dma_side(lo2, ld_off, side_dst0 + 2 * PIECE);
-#pragma unroll
-      for (int j = 0; j < L0; ++j) {
-        const int slot = gs % R3, nslot = (gs + 1) % R3, fslot = (gs + R3 - 1) % R3;
-#pragma unroll
-        for (int pair = 0; pair < 4; ++pair) {
-          if (pair < 3) {
-            read_pair(slot, pair + 1, A[(pair + 1) & 1]);
-          } else {
-            read_pair(nslot, 0, A[0]);
-          }
-          if (pair == 2) {
-            RC_WAIT_VM(NWAIT);
-            __builtin_amdgcn_s_barrier();
-            dma_w(a.wpack, lane16, (j + R3 - 1) % NST, fslot, wave);
-            dma_side(lo1 + 16 * (j + 1), ld_off, side_dst0 + (j + 1) * SIDE_SLOT);
-            dma_side(lo2 + 16 * (j + 1), ld_off, side_dst0 + (j + 1) * SIDE_SLOT + 2 * PIECE);
-          }
-          mfma12(pair, A[pair & 1], Bc);
-          if (j + 1 < L0) in_limbs(j + 1, pair, Bn);
-          if (pair == 1 || pair == 3) {  // keep the per-step VMEM count of the generic steps (null descriptors: dropped)
-            store4(keep, ors, st_off);
-            store4(keep2, ors2, st_off);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        Bc = Bn;
-        gs += 1;
-      }
-      l0 = 1;
-    }
-
-    for (int l = l0; l < L; ++l) {
+    for (int l = 0; l < L; ++l) {
       // MFMA layer l consumes P through the epilogue of chain layer lw = l - 1 (DSP l = 0: the raw chain input)
-      if (DB || l > 0) {
+      if (l > 0) {
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) P[nt] = Q[nt];
       }
@@ -383,7 +302,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int r = 0; r < 16; ++r) asm volatile("" : "+a"(P[nt][r]));
       zero_q();
       const int lw = l - 1;
-      const bool raw = !DB && l == 0;
+      const bool raw = l == 0;
       const bool skip = lw == 3;
       const int lwc = lw < 0 ? 0 : lw, lhc = l < L - 1 ? l : L - 2;
       lo1 = a.aux1[lwc];
@@ -393,8 +312,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         hi2 = a.aux2[lhc];
       }
       ors = make_rsrc(raw ? nullptr : a.out[lwc], nbytes);
-      if (DB) ors2 = make_rsrc(a.out2[lwc], nbytes);
-      const int t0 = DB ? L0 + 16 * (l - 1) : 16 * l;
+      const int t0 = 16 * l;
 #pragma unroll
       for (int c = 0; c < 4; ++c) epi(0, c, 0, raw, skip, Bc);
 #pragma unroll
@@ -410,7 +328,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     {
       const rsrc_t a1 = make_rsrc(a.aux1[L - 1], nbytes);
       const rsrc_t a2 = make_rsrc(NAUX == 2 ? a.aux2[L - 1] : nullptr, nbytes);
-      const rsrc_t o1 = make_rsrc(a.out[L - 1], nbytes), o2 = make_rsrc(DB ? a.out2[L - 1] : nullptr, nbytes);
+      const rsrc_t o1 = make_rsrc(a.out[L - 1], nbytes);
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
@@ -419,22 +337,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           const u32x4 hv = __builtin_amdgcn_raw_buffer_load_b128(a1, st_off + co, 0, 0);
           u32x4 xv = {0u, 0u, 0u, 0u};
           if (NAUX == 2) xv = __builtin_amdgcn_raw_buffer_load_b128(a2, st_off + co, 0, 0);
-          f32x4 r, r2;
+          f32x4 r;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float y = Q[nt][4 * g + k];
-            float e;
-            const float s = dsp_e(bitsf(hv[k]), e);
-            if (!DB) {
-              r[k] = y * s + (A2 ? bitsf(xv[k]) : 0.f);
-              r2[k] = 0.f;
-            } else {
-              r[k] = y * s;
-              r2[k] = 100.0f * y * bitsf(xv[k]) * e;
-            }
-          }
+          for (int k = 0; k < 4; ++k) r[k] = Q[nt][4 * g + k] * dsp(bitsf(hv[k])) + (A2 ? bitsf(xv[k]) : 0.f);
           store4(r, o1, st_off + co);
-          if (DB) store4(r2, o2, st_off + co);
         }
     }
   }
@@ -442,17 +348,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 }  // namespace
 
-extern "C" int64_t hold_chain_r6_pack_bytes(int32_t mode) {
-  if (mode == HOLD_CHAIN_DSP) return (int64_t)(7 * 16) * SLOT;
-  if (mode == HOLD_CHAIN_DBWD) return (int64_t)(3 + 7 * 16) * SLOT;
-  return -1;
-}
+extern "C" int64_t hold_chain_r6_pack_bytes(void) { return (int64_t)(7 * 16) * SLOT; }
 
-template <int MODE, bool A2>
+template <bool A2>
 static int rchain_launch(const RCArgs& a, hipStream_t s) {
-  constexpr bool DB = MODE == RC_DBWD;
-  constexpr int NAUX = (DB || A2) ? 2 : 1;
-  constexpr int lds = (DB ? 3 : 4) * SLOT + NW * SIDE_RING * NAUX * 2 * PIECE + (DB ? NW * (32 * IN_STR + 4) * 4 : 0);
+  constexpr int NAUX = A2 ? 2 : 1;
+  constexpr int lds = 4 * SLOT + NW * SIDE_RING * NAUX * 2 * PIECE;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static int n_cu = 0;
   static bool attr_set = false;
@@ -463,48 +364,37 @@ static int rchain_launch(const RCArgs& a, hipStream_t s) {
     n_cu = prop.multiProcessorCount;
   }
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)rchain_kernel<MODE, A2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-        hipSuccess)
+    if (hipFuncSetAttribute((const void*)rchain_kernel<A2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return HOLD_E_LAUNCH;
     attr_set = true;
   }
   const long blocks = (a.P + BPTS - 1) / BPTS;
-  hipLaunchKernelGGL((rchain_kernel<MODE, A2>), dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((rchain_kernel<A2>), dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(256), lds, s, a);
   return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
 }
 
-// The descriptor and semantics of hold_chain_x6 for the two backward-type sweeps with the register-resident structure:
-// mode DSP (7 layers, first_chunks 32, skip_layer 3, every out[] optional) or DBWD (8 layers, first_chunks 5, skip_layer 3,
-// side == in).  d->wpack = hold_chain_r6_pack_bytes(mode) bytes in the k order of hold_trunk_r6.
+// The descriptor and semantics of hold_chain_x6 for the descending sweeps (mode DSP, 7 layers, first_chunks 32,
+// skip_layer 3, every out[] optional, aux2 optional) with the register-resident structure.  d->wpack =
+// hold_chain_r6_pack_bytes() bytes in the k order of hold_trunk_r6.
 extern "C" int hold_chain_r6(const hold_chain_desc* dp, hold_stream_t st) {
   if (!dp) return HOLD_E_ARG;
   const hold_chain_desc& d = *dp;
-  if (d.P < 0 || !d.in || !d.wpack || d.skip_layer != 3) return HOLD_E_ARG;
+  if (d.P < 0 || !d.in || !d.wpack || d.skip_layer != 3 || d.mode != HOLD_CHAIN_DSP) return HOLD_E_ARG;
+  if (d.n_layers != 7 || d.first_chunks != 32 || d.ld_in < 256) return HOLD_E_ARG;
   if (d.ld < 256 || (d.ld & 3) || (d.ld_in & 3)) return HOLD_E_ARG;
   if (((uintptr_t)d.in & 15) || ((uintptr_t)d.wpack & 15)) return HOLD_E_ARG;
   if (((uint64_t)d.P + 128) * (uint64_t)d.ld * 4 >= (1ull << 32)) return HOLD_E_ARG;  // 32-bit byte offsets
+  if (((uint64_t)d.P + 128) * (uint64_t)d.ld_in * 4 >= (1ull << 32)) return HOLD_E_ARG;
   RCArgs a = {};
   a.P = (long)d.P; a.wpack = (const char*)d.wpack; a.in = d.in; a.ld_in = d.ld_in; a.ld = d.ld;
-  const bool dsp = d.mode == HOLD_CHAIN_DSP, dbwd = d.mode == HOLD_CHAIN_DBWD;
-  if (dsp) {
-    if (d.n_layers != 7 || d.first_chunks != 32 || d.ld_in < 256) return HOLD_E_ARG;
-    if (((uint64_t)d.P + 128) * (uint64_t)d.ld_in * 4 >= (1ull << 32)) return HOLD_E_ARG;
-  } else if (dbwd) {
-    if (d.n_layers != 8 || d.first_chunks != 5 || d.ld_in < 40 || d.side != d.in) return HOLD_E_ARG;
-  } else {
-    return HOLD_E_ARG;
-  }
   const bool has2 = d.aux2[0] != nullptr;
-  for (int l = 0; l < d.n_layers; ++l) {
-    if (!d.aux1[l] || ((uintptr_t)d.aux1[l] & 15) || ((uintptr_t)d.aux2[l] & 15) || ((uintptr_t)d.out[l] & 15) ||
-        ((uintptr_t)d.out2[l] & 15))
+  for (int l = 0; l < 7; ++l) {
+    if (!d.aux1[l] || ((uintptr_t)d.aux1[l] & 15) || ((uintptr_t)d.aux2[l] & 15) || ((uintptr_t)d.out[l] & 15))
       return HOLD_E_ARG;
     if ((d.aux2[l] != nullptr) != has2) return HOLD_E_ARG;
-    if (dbwd && (!d.aux2[l] || !d.out[l] || !d.out2[l])) return HOLD_E_ARG;
-    a.aux1[l] = d.aux1[l]; a.aux2[l] = d.aux2[l]; a.out[l] = d.out[l]; a.out2[l] = d.out2[l];
+    a.aux1[l] = d.aux1[l]; a.aux2[l] = d.aux2[l]; a.out[l] = d.out[l];
   }
   if (d.P == 0) return HOLD_OK;
   hipStream_t s = (hipStream_t)st;
-  if (dbwd) return rchain_launch<RC_DBWD, true>(a, s);
-  return has2 ? rchain_launch<RC_DSP, true>(a, s) : rchain_launch<RC_DSP, false>(a, s);
+  return has2 ? rchain_launch<true>(a, s) : rchain_launch<false>(a, s);
 }

@@ -30,7 +30,7 @@ FUSED_SDF = os.environ.get("HOLD_FUSED_SDF", "1") != "0"  # sampler queries thro
 USE_CHAIN = os.environ.get("HOLD_CHAIN", "1") != "0"
 # register-resident trunk (csrc/rmlp.hip) for the sampler queries and the training forward trunk (f32x6 arithmetic only)
 USE_R6 = os.environ.get("HOLD_R6", "1") != "0"
-USE_R6_BWD = os.environ.get("HOLD_R6_BWD", "1") != "0"  # ... and for the descending / second-order sweeps (csrc/rchain.hip)
+USE_R6_BWD = os.environ.get("HOLD_R6_BWD", "1") != "0"  # ... and for the descending sweeps (csrc/rchain.hip)
 RIN_FEAT, RIN_X, RIN_N, RIN_POSE, RIN_TIME = 0, 256, 259, 262, 270
 
 
@@ -371,7 +371,7 @@ class NodeField:
         if USE_CHAIN:
             vb = [pool.get(f"vbc{l}", P, 256) for l in range(8)]
             K.chain(K.CHAIN_DBWD, P, gebar, pk["fused"][0], 8, 5, skip_layer=3, side=gebar, aux1=h, aux2=t, out=vb,
-                    out2=a2, wpack_x6=pk.get("chain_fwd_x6"), wpack_r6=pk.get("trunk_r6") if USE_R6_BWD else None)
+                    out2=a2, wpack_x6=pk.get("chain_fwd_x6"))
             G.wgrad(t[0], gebar, dW[0], None, K=sp.K0, accumulate=True)
             for l in range(1, 8):
                 if l == 3:

@@ -161,10 +161,10 @@ def chain(mode, P, x_in, wpack, n_layers, first_chunks, skip_layer=-1, side=None
     assert wpack.numel() == _lib.lib().hold_chain_pack_floats(first_chunks, n_layers)
     if wpack_x6 is not None:  # split-precision sweep (hold_chain_x6): same descriptor, the weights as bf16 limbs
         assert wpack_x6.numel() * wpack_x6.element_size() == _lib.lib().hold_chain_x6_pack_bytes(first_chunks, n_layers)
-    r6 = wpack_r6 is not None and mode in (CHAIN_DSP, CHAIN_DBWD)  # register-resident sweep (hold_chain_r6): same descriptor
+    r6 = wpack_r6 is not None and mode == CHAIN_DSP  # register-resident descending sweep (hold_chain_r6): same descriptor
     if r6:
-        assert wpack_r6.numel() * wpack_r6.element_size() == _lib.lib().hold_chain_r6_pack_bytes(mode)
-        assert skip_layer == 3 and (mode == CHAIN_DSP or side is x_in)
+        assert wpack_r6.numel() * wpack_r6.element_size() == _lib.lib().hold_chain_r6_pack_bytes()
+        assert skip_layer == 3
     for r0 in range(0, P, _CHAIN_MAX_ROWS):
         r1 = min(P, r0 + _CHAIN_MAX_ROWS)
         d = _lib.ChainDesc()

@@ -28,15 +28,14 @@ def _pack_x6(mats, first_k):
 
 
 ARITH = ["f32", "f32x6"]  # hold_chain (fp32 MFMA) and hold_chain_x6 (3-limb bf16 split, fp32 accumulate): same tolerance
-ARITH_BWD = ARITH + ["r6"]  # + hold_chain_r6: the register-resident structure (csrc/rchain.hip), f32x6 arithmetic
+ARITH_BWD = ARITH + ["r6"]  # descending sweeps: + hold_chain_r6, the register-resident structure (csrc/rchain.hip)
 
 
 def _r6_stream(mode, mats):
-    """weight stream of hold_chain_r6 (hold_amd/field.py:pack_r6 / pack_r6_stack)"""
+    """weight stream of hold_chain_r6 (hold_amd/field.py:pack_r6_stack)"""
     from hold_amd import field as F
-    if mode == "dsp":
-        return F.pack_r6_stack(torch.stack(mats))
-    return F.pack_r6(mats[0], torch.stack(mats[1:]))
+    assert mode == "dsp"
+    return F.pack_r6_stack(torch.stack(mats))
 
 
 class _Guarded:
@@ -115,7 +114,7 @@ def test_chain_descending_dsp(P, with_a2, arith):
         cur = out[j].double()
 
 
-@pytest.mark.parametrize("arith", ARITH_BWD)
+@pytest.mark.parametrize("arith", ARITH)
 @pytest.mark.parametrize("P", [200, 128 * 256 + 64])
 def test_chain_second_order_dbwd(P, arith):
     from hold_amd import kernels as K
@@ -132,8 +131,7 @@ def test_chain_second_order_dbwd(P, arith):
     g1, g2 = _Guarded(8, P, dev), _Guarded(8, P, dev)
     o1, o2 = g1.views, g2.views
     K.chain(K.CHAIN_DBWD, P, x0, _pack(Ws), 8, 5, skip_layer=3, side=x0, aux1=hs, aux2=ts, out=o1, out2=o2,
-            wpack_x6=_pack_x6(Ws, 48) if arith == "f32x6" else None,
-            wpack_r6=_r6_stream("dbwd", Ws) if arith == "r6" else None)
+            wpack_x6=_pack_x6(Ws, 48) if arith == "f32x6" else None)
     g1.check()
     g2.check()
     cur = x0.double()
@@ -244,7 +242,7 @@ def test_field_chain_route_matches_layered_route(kind, node):
         o = nf.forward(pk, x, P, ppf, dfm, barf, pose, tcode, training=True)
         fw = {k: o[k].clone() for k in ("sdf", "rgb", "normal", "grad")}
         gr = nf.backward(d_sdf, d_rgb, d_n, B)
-        res[route] = (fw, gr)
+        res[route] = (fw, gr, [(r > 0).clone() for r in nf.saved["r"]])
     F.USE_CHAIN = True
     for k in res[False][0]:
         a, b = res[False][0][k], res[True][0][k]
@@ -254,21 +252,24 @@ def test_field_chain_route_matches_layered_route(kind, node):
     # order).  Downstream of it sits the rendering net's ReLU: a pre-activation within rounding of zero switches its
     # unit on in one route and off in the other, which moves that unit's share of a weight gradient discontinuously
     # -- a few such flips among 666 points x 1 024 units bound the agreement of the rendering-net gradients at ~1 %.
-    # Trunk gradients (no discontinuity between them and the inputs): 2e-4 of the tensor's largest entry, every entry.
-    # Rendering-net gradients: a flipped (point, unit) pair moves ONE point's contribution to ONE row (256 entries =
-    # 0.4 %) of a weight gradient, so the bulk of the entries agree to rounding and a few rows carry a flip -- the test
-    # holds 98 % of the entries of every tensor to 2e-4, the flipped rows to 5 % of the largest entry, and every tensor
-    # to 0.2 % in norm.
+    # The comparison is strict when the two routes took the same side of every ReLU; the (point, unit) pairs on which they
+    # did not are counted from the stored activations, must be a handful, and only then are the bounds relaxed: a flipped
+    # pair moves one point's contribution to one row of its layer's weight gradient and a rank-one term of everything
+    # upstream of it.
+    flips = sum(int((m0 != m1).sum()) for m0, m1 in zip(res[False][2], res[True][2]))
+    assert flips <= 12, flips
+    t_max = 5e-4 if flips == 0 else 5e-2
+    t_nrm = 2e-4 if flips == 0 else 1e-2
     for k in ("iw", "ib"):
         for i, (a, b) in enumerate(zip(ga[k], gb[k])):
-            assert (a - b).abs().max().item() <= 2e-4 * max(1e-3, a.abs().max().item()), (k, i)
+            assert (a - b).abs().max().item() <= (2e-4 if flips == 0 else 5e-3) * max(1e-3, a.abs().max().item()), (k, i, flips)
     for k in ("rw", "rb"):
         for i, (a, b) in enumerate(zip(ga[k], gb[k])):
             scale = max(1e-3, a.abs().max().item())
             d = (a - b).abs().reshape(-1)
-            assert (d > 2e-4 * scale).float().mean().item() <= 2e-2, (k, i, (d > 2e-4 * scale).float().mean().item())
-            assert d.max().item() <= 5e-2 * scale, (k, i)
-            assert (a - b).norm().item() <= 2e-3 * max(1e-3, a.norm().item()), (k, i)  # and in norm they agree to 0.2 %
+            assert (d > 5e-4 * scale).float().mean().item() <= (0.0 if flips == 0 else 0.004 * flips + 0.02), (k, i, flips)
+            assert d.max().item() <= t_max * scale, (k, i, flips)
+            assert (a - b).norm().item() <= t_nrm * max(1e-3, a.norm().item()), (k, i, flips)
     for k in ("tfs", "pose_embed", "time_code"):
         if ga[k] is None:
             continue

@@ -82,3 +82,78 @@ def test_loop_subdivision_torch_equals_numpy_restatement():
     assert to.mesh_as_triangle_set(vd.numpy(), fd.numpy(), 9) == to.mesh_as_triangle_set(ov, of, 9)
     from oracle import meshing_oracle as mo
     assert mo.mesh_stats(vd.numpy(), fd.numpy())["closed_oriented"]
+
+
+def _grid(n, lim=1.0):
+    ax = np.linspace(-lim, lim, n)
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    return X, Y, Z, ax[1] - ax[0]
+
+
+def _watertight(tris):
+    from collections import Counter
+    key = lambda p: tuple(np.round(p, 9))
+    cnt = Counter()
+    for t in tris:
+        for k in range(3):
+            cnt[frozenset((key(t[k]), key(t[(k + 1) % 3])))] += 1
+    return all(v == 2 for v in cnt.values())
+
+
+def test_marching_cubes_restatement_is_pinned_to_closed_forms():
+    """the table-free marching cubes of oracle/meshing_oracle.py (the triangulation family of the reference's
+    skimage call, code/src/utils/meshing.py:48-50): watertight, outward wound, area / volume of a sphere and of a torus
+    to the discretisation error of the grid, vertices on the level set of the trilinear interpolant's edges."""
+    from oracle import meshing_oracle as mo
+    X, Y, Z, h = _grid(33)
+    r = 0.63
+    mc = mo.marching_cubes(np.sqrt(X ** 2 + Y ** 2 + Z ** 2) - r, [-1, -1, -1], h)
+    assert _watertight(mc)
+    A, V = mo.mesh_area_volume(mc)
+    # an inscribed polyhedron: area and volume fall short of the sphere's by O((h / r)^2) = 0.3 % / 0.6 % on this grid
+    assert abs(A / (4 * math.pi * r ** 2) - 1) < 5e-3 and abs(V / (4 / 3 * math.pi * r ** 3) - 1) < 1e-2 and V > 0
+    assert np.abs(np.linalg.norm(mc.reshape(-1, 3), axis=1) - r).max() < 0.02 * h + 2e-3  # chord error of a linear edge cut
+    R, a = 0.6, 0.22
+    mc = mo.marching_cubes(np.sqrt((np.sqrt(X ** 2 + Y ** 2) - R) ** 2 + Z ** 2) - a, [-1, -1, -1], h)
+    assert _watertight(mc)
+    A, V = mo.mesh_area_volume(mc)
+    assert abs(A / (4 * math.pi ** 2 * R * a) - 1) < 1e-2 and abs(V / (2 * math.pi ** 2 * R * a ** 2) - 1) < 2e-2
+    # ambiguous faces: a field built to have them (two blobs touching diagonally) still gives a closed surface
+    f = np.minimum(np.sqrt((X - 0.31) ** 2 + (Y - 0.31) ** 2 + Z ** 2), np.sqrt((X + 0.31) ** 2 + (Y + 0.31) ** 2 + Z ** 2)) - 0.43
+    assert _watertight(mo.marching_cubes(f, [-1, -1, -1], _grid(17)[3] * 0 + h))
+
+
+def test_marching_tetrahedra_stays_within_half_a_voxel_of_marching_cubes():
+    """the product triangulates with marching tetrahedra where the reference uses (Lewiner) marching
+    cubes.  Both cut the same grid edges at the same points; MT adds vertices on face / body diagonals.  Stated tolerance
+    for downstream consumers (optimize_ckpt.py reads the exported .obj): every MT vertex lies within 0.5 voxel of the MC
+    surface and vice versa, area and volume agree to 1 % -- on hand-like and object-like canonical SDFs at the voxel
+    sizes the reference meshes with (features >= 3 voxels, smooth fields: at a sharp crease the bound is reached)."""
+    from oracle import meshing_oracle as mo
+    X, Y, Z, h = _grid(37)
+    # "hand": a flat palm ellipsoid with five finger capsules (smooth union); "object": a rounded box with a dent
+    def capsule(ax_, ay, bx, by, r):
+        pa = np.stack([X - ax_, Y - ay, Z], -1)
+        ba = np.array([bx - ax_, by - ay, 0.0])
+        t = np.clip((pa @ ba) / (ba @ ba), 0, 1)
+        return np.linalg.norm(pa - t[..., None] * ba, axis=-1) - r
+    palm = (np.sqrt((X / 0.42) ** 2 + ((Y + 0.25) / 0.38) ** 2 + (Z / 0.16) ** 2) - 1) * 0.16
+    hand = palm
+    for k in range(5):
+        ang = -0.5 + 0.25 * k
+        hand = np.minimum(hand, capsule(0.3 * math.sin(ang) * 1.2, 0.05, 0.75 * math.sin(ang), 0.1 + 0.6 * math.cos(ang), 0.07))
+    # (off the grid lines: a face lying exactly ON grid nodes puts crossings on the nodes themselves -- degenerate triangles)
+    q = np.stack([np.abs(X - 0.013) - 0.447, np.abs(Y + 0.007) - 0.303, np.abs(Z - 0.021) - 0.378], -1)
+    box = np.linalg.norm(np.maximum(q, 0), axis=-1) + np.minimum(q.max(-1), 0) - 0.08
+    dent = -(np.sqrt((X - 0.507) ** 2 + (Y - 0.003) ** 2 + (Z - 0.396) ** 2) - 0.247)
+    obj = 0.05 * np.logaddexp(box / 0.05, dent / 0.05)  # smooth intersection: a learnt SDF has no sharp creases
+    for name, f in (("hand", hand), ("object", obj)):
+        mc = mo.marching_cubes(f, [-1, -1, -1], h)
+        mt = np.array(mo.marching_tetrahedra(f, [-1, -1, -1], h))
+        assert _watertight(mc), name
+        Ac, Vc = mo.mesh_area_volume(mc)
+        At, Vt = mo.mesh_area_volume(mt)
+        assert abs(At / Ac - 1) < 1e-2 and abs(Vt / Vc - 1) < 1e-2, (name, At / Ac, Vt / Vc)
+        d1 = mo.point_to_tris(np.unique(mt.reshape(-1, 3).round(9), axis=0)[::2], mc)
+        d2 = mo.point_to_tris(np.unique(mc.reshape(-1, 3).round(9), axis=0)[::2], mt)
+        assert d1.max() < 0.5 * h and d2.max() < 0.5 * h, (name, d1.max() / h, d2.max() / h)

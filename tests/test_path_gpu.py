@@ -180,14 +180,32 @@ def test_train_step_gradients_match_oracle_autograd(ctx):
     lh.backward()
     assert abs(float(lo) - float(lh)) < 1e-5
     assert float((out["rgb"].detach().cpu() - oo["rgb"].detach()).abs().max()) < 1e-4
+    # The yardstick for the gradients is the oracle's autograd in FLOAT64 on the same z and draws: against it the error is
+    # the HIP path's alone (the fp32 oracle carries 3e-5 of its own on the background net).  Every parameter tensor --
+    # dense layers, density betas, frame latents, pose / shape / translation tables -- is held to 2e-4 of its norm
+    # (measured worst: 6e-5, scripts/grad_parity_report.py); the fp32 oracle is kept as a cross-check at 3e-4.
+    from hold_amd import synthetic as syn
+    o64 = ho.OracleScene(sc, {"right": syn.make_mano_model(True), "left": syn.make_mano_model(False)}, dtype=torch.float64)
+    sd64 = {k: (v.detach().double().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    _, oi64 = oracle_input(sc, sd64, [0, 2], 6, 6)
+    oi64 = {k: (v.double() if torch.is_tensor(v) and v.dtype.is_floating_point else v) for k, v in oi64.items()}
+    r64 = {k: ({kk: (vv.double() if torch.is_tensor(vv) else vv) for kk, vv in v.items()} if isinstance(v, dict) else v.double())
+           for k, v in rng.items()}
+    oo64 = ho.holdnet_forward(o64, sd64, oi64, True, rng=r64, z_override={n: z.double() for n, z in zo.items()},
+                              current_epoch=25, barf_alpha_iter=4000, stable_merge=True)
+    _loss(oo64, gt.double()).backward()
     checked = 0
     for name, p in net.named_parameters():
         if name not in sdg or sdg[name].grad is None:
             continue
-        og = sdg[name].grad
         assert p.grad is not None, name
-        rel = float((p.grad.cpu() - og).norm() / (og.norm() + 1e-20))
-        assert rel < 1e-3, (name, rel)
+        g = p.grad.cpu().double()
+        og64 = sd64[name].grad
+        rel64 = float((g - og64).norm() / (og64.norm() + 1e-30))
+        assert rel64 < 2e-4, (name, rel64)
+        og = sdg[name].grad.double()
+        rel = float((g - og).norm() / (og.norm() + 1e-30))
+        assert rel < 3e-4, (name, rel)
         checked += 1
     assert checked >= 100
     # BARF counter stepped once by the training forward (hold_net.py:121-122)
