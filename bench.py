@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 matrix)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 matrix, same guide
+HBM_PEAK_GBPS = 8000.0  # HBM3E spec (6.3 TB/s achievable by a float4 copy), same guide
 ROUND = "r03"
 
 
@@ -61,6 +62,10 @@ def parse():
                     help="let Adam move the weights during the run (default: the flat parameter bucket is restored after "
                          "every optimiser step, inside the timed region, so that every step sees the same SDF and runs the "
                          "same number of sampler rounds -- the workload of step 1 is the workload of step K)")
+    ap.add_argument("--split", default="frames", choices=["frames", "rays"],
+                    help="multi-GPU partition: 'frames' = one frame per rank (weak scaling, the default); 'rays' = ONE frame, "
+                         "contiguous ray tiles per rank, the sampler's convergence test synchronised by a 2-float MAX all-reduce "
+                         "per round (strong scaling, SURVEY 8(e))")
     ap.add_argument("--shape-report", default="", help="write per-(kernel, flop bucket) launch aggregates to this json file")
     return ap.parse_args()
 
@@ -238,10 +243,17 @@ def main():
             batches.append({k: torch.from_numpy(v).to(dev) for k, v in bb.items()})
         rays_per_step = 10 * 128
     else:
-        frame = rank % n_frames
-        b = syn.make_batch(sc, [frame], uv, W, H)
+        split_rays = args.split == "rays" and world > 1
+        if split_rays:  # one frame for the whole job; rank r owns rays [r, r + 1) * W * H / world of it
+            tile = (W * H + world - 1) // world
+            b = syn.make_batch(sc, [0], uv[rank * tile:(rank + 1) * tile], W, H)
+            for node in net.nodes.values():
+                node.ray_sampler.sync_group = True
+        else:
+            b = syn.make_batch(sc, [rank % n_frames], uv, W, H)
         inp = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
-        rays_per_step = W * H
+        rays_per_step = inp["uv"].shape[1]
+        frame_rays = W * H if split_rays else None  # loss normalisation: the whole frame, so that the tiles' gradients add up
     def step(i):
         if args.mode in ("render", "c5"):
             render_frame(net, inp, args.chunk)
@@ -258,8 +270,9 @@ def main():
                 loss.backward()
                 lv = loss.detach()
         else:
-            lv, _ = train_step(net, inp, args.chunk, step=i + 1, epoch=0, loss_fn=loss_fn)
-        opt.step()
+            lv, _ = train_step(net, inp, args.chunk, step=i + 1, epoch=0, loss_fn=loss_fn, n_total=frame_rays)
+        # ray tiles: the all-reduce must SUM the tiles' gradients (FlatAdam averages over ranks: undo it)
+        opt.step(grad_mul=float(world) if (args.mode not in ("c3",) and frame_rays is not None) else 1.0)
         if frozen is not None:  # same weights (hence the same SDF, sampler rounds and FLOP per ray) at every step
             opt.flat.copy_(frozen)
         return lv
@@ -293,7 +306,7 @@ def main():
     gemm.PROFILE = None
 
     if rank == 0:
-        total_rays = rays * world
+        total_rays = rays * world if not (args.split == "rays" and world > 1 and args.mode != "c3") else args.steps * W * H
         iters = {nid: node.ray_sampler.last_iters for nid, node in net.nodes.items()}
         mean_iters = {nid: node.ray_sampler.sum_iters / max(1, node.ray_sampler.n_calls) for nid, node in net.nodes.items()}
         smp = next(iter(net.nodes.values())).ray_sampler
@@ -321,7 +334,8 @@ def main():
                       "rendered rays/sec (forward only, eval mode) -- secondary metric")
         res = {
             "metric": metric, "value": total_rays / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if (args.split == "rays" and world > 1 and args.mode != "c3") else "weak",
             "vs_baseline": None,
             "dtype": ("f32x6 (fp32 results; every MFMA product = exact 3-limb bf16 split of both fp32 operands, 6 of 9 limb "
                       "products on v_mfma_f32_32x32x16_bf16, fp32 accumulate; --fp32-mfma for true-fp32 operands)"
@@ -336,14 +350,17 @@ def main():
                        "algorithmic_tflops_end_to_end": total_rays / dt * fpr / 1e12,
                        "weights_frozen": frozen is not None,
                        "loss_terms": args.loss if training else None,
-                       "parallelism": f"dp{world} (frames sharded, one RCCL all-reduce of the flat gradient bucket)",
+                       "parallelism": (f"dp{world} (ONE frame, ray tiles per rank, sampler rounds synchronised by a 2-float MAX "
+                                       "all-reduce, one RCCL all-reduce (sum) of the flat gradient bucket)"
+                                       if (args.split == "rays" and world > 1 and args.mode != "c3") else
+                                       f"dp{world} (frames sharded, one RCCL all-reduce of the flat gradient bucket)"),
                        "loss": float(loss), "precision": hold_amd.precision(),
                        "steps_per_s": args.steps / dt},
         }
         if prof:
-            agg = {}
+            agg, hbm = {}, {}
             for e0, e1, fl, name in prof:
-                a = agg.setdefault(name, [0.0, 0.0, 0])
+                a = (hbm if name.startswith("hbm:") else agg).setdefault(name, [0.0, 0.0, 0])
                 a[0] += e0.elapsed_time(e1) * 1e-3
                 a[1] += fl
                 a[2] += 1
@@ -375,7 +392,15 @@ def main():
                 if is6:
                     ent[name]["note"] = ("achieved = bf16 MFMA FLOP/s issued (6 limb products per algorithmic fp32 product), peak = "
                                          "dense bf16 MFMA; fp32_equivalent_tflops = algorithmic FLOP / time")
-            dom = max(ent, key=lambda k: ent[k]["time_share"])
+            # the sampler / compositor stages: scan and search work on <= 640-float per-ray windows held in LDS -- their HBM
+            # traffic is the windows in and out; achieved GB/s (algorithmic bytes / live-timed launch) against the HBM roof
+            # shows they are nowhere near it (they are latency / LDS-bound at < 2 % of the step), not that they are fast
+            for name, (t_, by_, n_) in hbm.items():
+                ent[name[4:] + "_kernel"] = {"bound": "hbm", "achieved": by_ / t_ / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                             "frac": by_ / t_ / 1e9 / HBM_PEAK_GBPS, "launches": n_,
+                                             "avg_launch_ms": t_ / n_ * 1e3, "time_share": t_ / dt,
+                                             "algorithmic_bytes_per_launch_avg": by_ / n_}
+            dom = max((k for k in ent if ent[k].get("bound") != "hbm"), key=lambda k: ent[k]["time_share"])
             traffic, tsrc = pmc_traffic(dom)
             res["roofline"] = {"bound": "mfma", "achieved": ent[dom]["achieved"], "peak": ent[dom]["peak"],
                                "unit": "TFLOP/s", "frac": ent[dom]["frac"], "traffic": traffic,
@@ -388,6 +413,9 @@ def main():
                                "kernels": ent}
             if "note" in ent[dom]:
                 res["roofline"]["note"] = ent[dom]["note"]
+            for k in ent:
+                ent[k].setdefault("bound", "mfma")
+                ent[k].setdefault("unit", "TFLOP/s")
             mf = sum(v[1] for v in agg.values())
             mf6 = sum((6.0 if k in split else 1.0) * v[1] for k, v in agg.items())
             res["roofline"]["end_to_end"] = {"mfma_tflops_fp32_equivalent": mf / dt / 1e12,

@@ -63,6 +63,20 @@ class Pool:
         return sum(b.numel() * b.element_size() for b in self.bufs.values())
 
 
+_SHARED_POOLS = {}
+
+
+def shared_pool(device):
+    """ONE backward-scratch pool per device, shared by every NodeField: the backward of a node runs to completion inside
+    one autograd call and only then the next node's starts, so the sweeps' intermediates (a2_l, vbar_l, r_l, the rendering
+    net's cotangents: ~24 KB per point) need not exist once per node -- with three foreground nodes that is what lets a
+    16 384-ray chunk of the two-hand scene fit (the forward activations a backward reads stay in the node's own pool)."""
+    k = str(device)
+    if k not in _SHARED_POOLS:
+        _SHARED_POOLS[k] = Pool(device)
+    return _SHARED_POOLS[k]
+
+
 class FieldSpec:
     """static shape description of a node's networks."""
 
@@ -234,6 +248,7 @@ class NodeField:
     def __init__(self, spec: FieldSpec, device):
         self.spec = spec
         self.pool = Pool(device)
+        self.bpool = shared_pool(device)  # backward scratch (not needed across calls)
         self.device = device
         self.gen = 0  # bumped by every call that overwrites the saved activations (checked by the autograd glue)
 
@@ -366,7 +381,7 @@ class NodeField:
     def _second_order_sweep(self, pk, h, t, gebar, dW, P):
         """ascending sweep of the double backward: tbar_l = W_l vbar_l, ubar_l = tbar_l * s_l,
         a2_l = 100 * tbar_l * t_l * (1 - s_l); dW_l += t_l^T vbar_l.  Returns (a2[8], ubar_7)."""
-        sp, pool, W = self.spec, self.pool, pk["W"]
+        sp, pool, W = self.spec, self.bpool, pk["W"]
         a2 = [pool.get(f"a2_{l}", P, 256) for l in range(8)]
         if USE_CHAIN:
             vb = [pool.get(f"vbc{l}", P, 256) for l in range(8)]
@@ -402,7 +417,7 @@ class NodeField:
         """descending sweep r_{l-1} = (W_l^T r_l) * s_{l-1} + a2_{l-1} from r_7 down to r_0 with
         dW_l += r_l^T in_l, db_l += sum r_l; the skip columns of W_4^T r_4 go to ebar[:, :39] (if given).
         Returns r_0."""
-        sp, pool, WT = self.spec, self.pool, pk["WT"]
+        sp, pool, WT = self.spec, self.bpool, pk["WT"]
         if USE_CHAIN:
             r = [pool.get(f"rbc{l}", P, 256) for l in range(7)] + [r7]
             K.chain(K.CHAIN_DSP, P, r7, pk["chain_bwd"], 7, 32, skip_layer=3, aux1=[h[l - 1] for l in range(7, 0, -1)],
@@ -454,7 +469,7 @@ class NodeField:
 
     def sdf_feat_backward(self, ob):
         """first-order backward of sdf_feat_forward: ob [P,260] = d/d(features | sdf | 0) -> (g_iw[9], g_ib[9], d_x [P,4])."""
-        sp, pool, sv = self.spec, self.pool, self.saved
+        sp, pool, sv = self.spec, self.bpool, self.saved
         P, pk, h, xc = sv["P"], sv["pk"], sv["h"], sv["xc"]
         dev = self.device
         W, WT = pk["W"], pk["WT"]
@@ -494,7 +509,7 @@ class NodeField:
     def grad_points_backward(self, gbar):
         """gradient of a loss on g = d sdf/d x w.r.t. the effective implicit weights (second-order terms only:
         the points themselves and sdf / features carry no upstream gradient)."""
-        sp, pool, sv = self.spec, self.pool, self.saved
+        sp, pool, sv = self.spec, self.bpool, self.saved
         P, pk, h, t, xc = sv["P"], sv["pk"], sv["h"], sv["t"], sv["xc"]
         dev = self.device
         W, WT = pk["W"], pk["WT"]
@@ -523,7 +538,7 @@ class NodeField:
         """d_sdf [P] / [P,1], d_rgb [P,3], d_normal [P,3] (may be None) -> dict of gradients:
         iw[9], ib[9] (w.r.t. the EFFECTIVE implicit weights as passed to pack_weights), rw[5], rb[5],
         tfs [B,nb,16], pose_embed [B,8], time_code [B,32] (object)."""
-        sp, pool = self.spec, self.pool
+        sp, pool = self.spec, self.bpool
         sv = self.saved
         P, ppf, pk = sv["P"], sv["ppf"], sv["pk"]
         h, t, rin, r, rgb, xc = sv["h"], sv["t"], sv["rin"], sv["r"], sv["rgb"], sv["xc"]

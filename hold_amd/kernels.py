@@ -208,15 +208,27 @@ def sampler_init(cam_loc, ray_dirs, R, near, n0, eps, t_rand, z, beta, far, err_
          ptr(t_rand), ptr(z), _ld(z), ptr(beta), ptr(far), ptr(err_flag))
 
 
+def _hbm_prof(name, nbytes, fn):
+    """time a streaming kernel for bench.py's roofline.kernels (ALGORITHMIC bytes / time against the HBM roof)"""
+    from . import gemm as _g
+    e0 = _g._prof_begin()
+    fn()
+    _g._prof_end(e0, float(nbytes), "hbm:" + name)
+
+
 def sampler_beta(z, sdf, S, n_rays, sdf_new, slot, n_new, beta, beta0, eps, beta_iters, maxbeta_bits):
-    call("hold_sampler_beta", ptr(z), ptr(sdf), _ld(z), S, n_rays, ptr(sdf_new), ptr(slot), n_new, ptr(beta),
-         float(beta0), float(eps), beta_iters, ptr(maxbeta_bits))
+    # algorithmic HBM bytes (SURVEY 8(d)): the sorted window in (z, sdf), the merged sdf window out, the new sdf in
+    _hbm_prof("sampler_beta", 4.0 * n_rays * (2 * S + (S + n_new if n_new else 0) + 2),
+              lambda: call("hold_sampler_beta", ptr(z), ptr(sdf), _ld(z), S, n_rays, ptr(sdf_new), ptr(slot), n_new, ptr(beta),
+                           float(beta0), float(eps), beta_iters, ptr(maxbeta_bits)))
 
 
 def sampler_sample(z, sdf, S, n_rays, beta, more, add_tiny, u, n_new, samples_out, slot_out):
     u_stride = 0 if u.dim() == 1 else u.stride(0)
-    call("hold_sampler_sample", ptr(z), ptr(sdf), _ld(z), S, n_rays, ptr(beta), int(more), float(add_tiny), ptr(u),
-         u_stride, n_new, ptr(samples_out), ptr(slot_out))
+    # window in (z, sdf), new samples out, and -- when the window grows -- the merged z window + slots out
+    _hbm_prof("sampler_sample", 4.0 * n_rays * (2 * S + n_new + ((S + 2 * n_new) if more else 0)),
+              lambda: call("hold_sampler_sample", ptr(z), ptr(sdf), _ld(z), S, n_rays, ptr(beta), int(more), float(add_tiny),
+                           ptr(u), u_stride, n_new, ptr(samples_out), ptr(slot_out)))
 
 
 def sampler_final(z_samples, ns, z, idx_extra, nx, far, near, n_rays, out):
@@ -245,7 +257,12 @@ def composite_fwd(d, out_node, out_comp, out_sem, out_w=None, out_zmerge=None, o
     d.out_comp, d.out_sem = out_comp.data_ptr(), out_sem.data_ptr()
     d.out_w = out_w.data_ptr() if out_w is not None else None
     d.out_zmerge = out_zmerge.data_ptr() if out_zmerge is not None else None
-    call("hold_composite_fwd", C.byref(d))
+    n, S, N = d.n_nodes, d.S, d.n_rays
+    # per node and sample: z, sdf, colour 3, normal 3 in; per ray: 12 floats per node + composite + 4 semantics out,
+    # the merged weights (n S - 2 n + 1) and the per-node weights when requested
+    nb = 4.0 * N * (n * S * 8 + 12 * (n + 1) + 4 + ((n * S - 2 * n + 1) if out_w is not None else 0)
+                    + (n * S if out_w_node is not None else 0))
+    _hbm_prof("composite_fwd", nb, lambda: call("hold_composite_fwd", C.byref(d)))
 
 
 def composite_bwd(d, d_node, d_comp, d_sem, d_sdf, d_color, d_normal, d_beta):
@@ -253,7 +270,9 @@ def composite_bwd(d, d_node, d_comp, d_sem, d_sdf, d_color, d_normal, d_beta):
         d.d_node[i], d.d_sdf[i] = d_node[i].data_ptr(), d_sdf[i].data_ptr()
         d.d_color[i], d.d_normal[i] = d_color[i].data_ptr(), d_normal[i].data_ptr()
     d.d_comp, d.d_sem, d.d_beta = d_comp.data_ptr(), d_sem.data_ptr(), d_beta.data_ptr()
-    call("hold_composite_bwd", C.byref(d))
+    n, S, N = d.n_nodes, d.S, d.n_rays
+    nb = 4.0 * N * (n * S * 8 + 12 * (n + 1) + 4 + n * S * 7)  # forward inputs + cotangents in, d sdf / colour / normal out
+    _hbm_prof("composite_bwd", nb, lambda: call("hold_composite_bwd", C.byref(d)))
 
 
 def bg_composite_fwd(z_desc, sdf, rgb, S, n_rays, out_rgb, w_out=None):

@@ -64,6 +64,19 @@ class ErrorBoundSampler:
         self.sum_iters = 0  # rounds summed over all calls / number of calls (bench.py: FLOP per ray of a timed region)
         self.n_calls = 0
 
+    def sync_round(self, max_beta, err, dev="cpu"):
+        """the per-round exchange of the data-parallel option: MAX over the ranks of (max beta of the shard, error flag) --
+        one 2-float all-reduce; identity without a group.  With it every shard runs the number of rounds (and raises the
+        errors) the un-sharded call would (code/src/engine/ray_sampler.py:244: `beta.max()` is a max over all rays)."""
+        if self.sync_group is not None:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                t = torch.tensor([max_beta, 1.0 if err else 0.0], device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=None if self.sync_group is True else self.sync_group)
+                t = t.cpu()
+                return float(t[0]), bool(t[1] > 0)
+        return max_beta, err
+
     def _rand(self, shape, dev):
         if self.rng_device == "cpu":
             return torch.rand(shape).to(dev)
@@ -142,15 +155,9 @@ class ErrorBoundSampler:
                                flags[:, 1:2])
             iters += 1
             fl = flags.cpu()
-            if int(fl[0, 0]) != 0:
+            max_beta, err = self.sync_round(float(fl[0, 1:2].view(torch.float32)), int(fl[0, 0]) != 0, dev)
+            if err:  # every rank of a sync group raises together (the flag is reduced with the convergence test)
                 raise RuntimeError("BOUNDING SPHERE PROBLEM!")  # ray_sampler.py:16-18
-            max_beta = float(fl[0, 1:2].view(torch.float32))
-            if self.sync_group is not None:
-                import torch.distributed as dist
-                if dist.is_available() and dist.is_initialized():
-                    mb = torch.tensor([max_beta], device=dev)
-                    dist.all_reduce(mb, op=dist.ReduceOp.MAX, group=None if self.sync_group is True else self.sync_group)
-                    max_beta = float(mb)
             not_converge = max_beta > beta0
             if not_converge and iters < self.max_total_iters:
                 K.sampler_sample(z, sdf, S, N, beta, True, self.add_tiny, u_more, n0, samp, slot)

@@ -60,14 +60,16 @@ def training_step(net, loss_fn, batch, epoch=0, step=0):
     return ld["loss"], ld, out
 
 
-def train_step(net, inp, chunk_rays, step=0, epoch=0, loss_fn=None):
+def train_step(net, inp, chunk_rays, step=0, epoch=0, loss_fn=None, n_total=None):
     """fwd + loss + bwd over all rays of `inp` (uv [B,P,2]) in chunks of chunk_rays per frame; gradients accumulate in
     .grad.  Per-frame (not per-ray) loss terms -- eikonal, MANO-canonical -- are evaluated with the first chunk only;
     the BARF counter steps once per call (the reference steps it once per training_step).
-    Returns (loss value, rays processed)."""
+    ``n_total``: the ray count the ray-wise loss terms are normalised by (default: the rays of ``inp``; a rank that owns a
+    ray tile of a frame passes the frame's total so that the ranks' gradients ADD UP to the whole-frame gradient).
+    Returns (loss -- a device scalar, read it once per step at most --, rays processed)."""
     B, P = inp["uv"].shape[:2]
-    n_total = B * P
-    total = 0.0
+    n_total = B * P if n_total is None else int(n_total)
+    total = None
     auto = net.auto_step_embedding
     net.auto_step_embedding = False
     try:
@@ -82,12 +84,12 @@ def train_step(net, inp, chunk_rays, step=0, epoch=0, loss_fn=None):
             else:
                 loss = loss_fn(c, out)["loss"]
             loss.backward()
-            total += float(loss.detach())
+            total = loss.detach() if total is None else total + loss.detach()  # no host read per chunk
     finally:
         net.auto_step_embedding = auto
     if net.training and auto:
         net.step_embedding()
-    return total, n_total
+    return total, B * P
 
 
 @torch.no_grad()

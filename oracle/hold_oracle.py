@@ -212,7 +212,7 @@ def sampler_round(z_vals, sdf, beta, beta0, eps=0.1, beta_iters=10):
 
 def error_bound_sample(z_vals, sdf_fn, cam_loc, ray_dirs, beta0, R, is_training=False, rng=None,
                        N_samples=64, N_eval=128, N_extra=32, eps=0.1, beta_iters=10, max_iters=5,
-                       add_tiny=1e-6, near=0.0, trace=None):
+                       add_tiny=1e-6, near=0.0, trace=None, sync=None):
     """ErrorBoundSampler.get_z_vals, code/src/engine/ray_sampler.py:128-352.
     z_vals: the initial uniform samples; sdf_fn(points[P,3]) -> sdf[P].  ``rng`` supplies the
     training-mode draws (dict with 'u_final' [N,N_samples], 'perm' indices)."""
@@ -234,7 +234,10 @@ def error_bound_sample(z_vals, sdf_fn, cam_loc, ray_dirs, beta0, R, is_training=
             sdf = s_sdf
         beta, dists, d_star, weights, trans = sampler_round(z_vals, sdf, beta, beta0, eps, beta_iters)
         total_iters += 1
-        not_converge = bool(beta.max() > beta0)
+        bmax = float(beta.max())
+        if sync is not None:  # data-parallel shards: MAX over the ranks (hold_amd.sampler.ErrorBoundSampler.sync_round)
+            bmax = sync(bmax)
+        not_converge = bool(bmax > float(beta0))
         more = not_converge and total_iters < max_iters
         if more:
             n_new = N_eval

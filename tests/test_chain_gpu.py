@@ -274,5 +274,5 @@ def test_field_chain_route_matches_layered_route(kind, node):
         if ga[k] is None:
             continue
         # pose_embed / time_code enter the rendering net's first layer: their gradients sit behind the same ReLU flips
-        t = 2e-4 if k == "tfs" else 2e-3
-        assert (ga[k] - gb[k]).abs().max().item() <= t * max(1e-3, ga[k].abs().max().item()), k
+        t = (2e-4 if k == "tfs" else 2e-3) * (1 if flips == 0 else 10)
+        assert (ga[k] - gb[k]).abs().max().item() <= t * max(1e-3, ga[k].abs().max().item()), (k, flips)

@@ -107,3 +107,55 @@ def test_flat_bucket_allreduce_over_holdnet_parameters(tmp_path):
     for gsum, v in zip(d["grads"][5:], d["vals"][5:]):  # (the first entries hold the specially marked pose rows)
         assert torch.allclose(gsum, v * 3.0, atol=1e-5)
     assert d["base"] >= 0  # the pose table's gradient lives inside the bucket
+
+
+# ------------------------------------------------------------------------------------------ ray-tile sharding (strong scaling)
+def _rays(n):
+    """a fan of rays from (0, 0, -2): the first half hits a 0.5-sphere at the origin, the second half misses it"""
+    g = torch.Generator().manual_seed(4)
+    t = torch.cat([torch.rand(n // 2, generator=g) * 0.15, 0.45 + torch.rand(n - n // 2, generator=g) * 0.3])
+    ph = torch.rand(n, generator=g) * 6.28318
+    d = torch.stack([torch.sin(t) * torch.cos(ph), torch.sin(t) * torch.sin(ph), torch.cos(t)], -1)
+    return d, torch.tensor([0.0, 0.0, -2.0]).expand(n, 3).contiguous()
+
+
+def _sample(dirs, cam, sync=None):
+    from oracle import hold_oracle as ho
+    R = 3.0
+    far = ho.sphere_far(cam, dirs, R)
+    z0 = ho.uniform_z(torch.zeros(dirs.shape[0], 1), far, 128, None)
+    sdf = lambda p: p.norm(dim=-1) - 0.5
+    return ho.error_bound_sample(z0, sdf, cam, dirs, torch.tensor(0.0101), R, False, None, sync=sync)
+
+
+def _tile_worker(rank, world, port, out):
+    from hold_amd.sampler import ErrorBoundSampler
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dirs, cam = _rays(64)
+    lo, hi = rank * 32, (rank + 1) * 32
+    smp = ErrorBoundSampler(3.0)
+    smp.sync_group = True
+    # the host-side exchange of the HIP sampler itself: (max beta, error flag) -> MAX over the ranks
+    mb, err = smp.sync_round(0.25 * (rank + 1), rank == 1)
+    assert mb == 0.5 and err is True
+    assert smp.sync_round(0.125, False) == (0.125, False)
+    z_sync, it_sync = _sample(dirs[lo:hi], cam[lo:hi], sync=lambda b: smp.sync_round(b, False)[0])
+    z_solo, it_solo = _sample(dirs[lo:hi], cam[lo:hi])
+    torch.save(dict(z_sync=z_sync, it_sync=it_sync, z_solo=z_solo, it_solo=it_solo), out + str(rank))
+    dist.destroy_process_group()
+
+
+def test_ray_tiles_with_synchronised_rounds_equal_the_unsharded_call(tmp_path):
+    """SURVEY 8(e) caveat: the sampler's convergence test is a max over ALL rays of a call.  Two ranks that own ray tiles of
+    one frame and exchange that max (ErrorBoundSampler.sync_round: one 2-float MAX all-reduce per round) produce exactly the
+    z_vals and round count of the un-sharded call; without the exchange the tile whose rays converge early stops early."""
+    out = str(tmp_path / "t")
+    mp.spawn(_tile_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    dirs, cam = _rays(64)
+    z_full, it_full = _sample(dirs, cam)
+    parts = [torch.load(out + str(r)) for r in range(2)]
+    assert all(p["it_sync"] == it_full for p in parts)
+    assert torch.equal(torch.cat([p["z_sync"] for p in parts]), z_full)
+    assert min(p["it_solo"] for p in parts) < it_full  # the test distinguishes the two behaviours
