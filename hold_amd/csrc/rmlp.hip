@@ -218,10 +218,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const int wl = (pr == 2 || pr == 3) ? 1 : (pr == 5 ? 2 : 0);  // (w limb, act limb): 00 01 10 11 02 20
       const int al = (pr == 1 || pr == 3) ? 1 : (pr == 4 ? 2 : 0);
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t) {
         Q[2 * pair + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[3 * t + wl]),
                                                                  __builtin_bit_cast(bf16x8, b.l[al]), Q[2 * pair + t],
                                                                  0, 0, 0);
+        // MFMAs may not cross (everything else may): the two accumulators stay ALTERNATING in the instruction stream --
+        // left alone the scheduler issues the six products of one tile back to back, a dependent chain whose
+        // accumulator latency exceeds the issue interval
+        __builtin_amdgcn_sched_barrier(0x7F6);
+      }
     }
   };
   auto init_bias = [&](int layer) {
