@@ -133,6 +133,17 @@ __device__ __forceinline__ void dma_side(const float* base, uint32_t rowoff, uin
       : "memory");
 }
 
+// single 1 KiB pieces (see rmlp.hip:dma_piece: M0 is written by every statement that reads it, nothing else uses it)
+__device__ __forceinline__ void dma_piece(const char* src, uint32_t voff, uint32_t dst) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1"
+      :
+      : "v"(voff), "s"(src), "s"(dst)
+      : "memory");
+}
+
 #define RC_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
 template <bool A2>
@@ -172,7 +183,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int i = 0; i < 6; ++i) dst[i] = *reinterpret_cast<const u32x4*>(base + i * PIECE);
   };
-  auto mfma12 = [&](int pair, const u32x4 (&af)[6], const Limbs& b) {
+  // piece(i), i = 0..5: DMA statements placed between the MFMAs of a group (an LDS-DMA instruction holds the wave's issue
+  // for longer than one MFMA runs: in one block in front of the group they drain the matrix pipe)
+  auto mfma12 = [&](int pair, const u32x4 (&af)[6], const Limbs& b, auto&& piece) {
 #pragma unroll
     for (int pr = 0; pr < 6; ++pr) {
       const int wl = (pr == 2 || pr == 3) ? 1 : (pr == 5 ? 2 : 0);  // (w limb, act limb): 00 01 10 11 02 20
@@ -182,13 +195,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         Q[2 * pair + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[3 * t + wl]),
                                                                  __builtin_bit_cast(bf16x8, b.l[al]), Q[2 * pair + t],
                                                                  0, 0, 0);
-        // MFMAs may not cross (everything else may): the two accumulators stay ALTERNATING in the instruction stream --
-        // left alone the scheduler issues the six products of one tile back to back, a dependent chain whose
-        // accumulator latency exceeds the issue interval
-        __builtin_amdgcn_sched_barrier(0x7F6);
       }
+      piece(pr);
     }
   };
+  auto no_piece = [](int) {};
   auto zero_q = [&]() {
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt)
@@ -246,12 +257,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (pair == 2) {  // rendezvous: the weights of step gs + 1 have landed in every wave; slot gs - 1 is free
           RC_WAIT_VM(NWAIT);
           __builtin_amdgcn_s_barrier();
-          dma_w(a.wpack, lane16, (tl + R3 - 1) % NST, fslot, wave);
-          const int jc = (jp + 4) & 15, sslot = jp & 3;
-          dma_side((jp < 12 ? lo1 : hi1) + 16 * jc, ld_off, side_dst0 + sslot * SIDE_SLOT);
-          if (NAUX == 2) dma_side((jp < 12 ? lo2 : hi2) + 16 * jc, ld_off, side_dst0 + sslot * SIDE_SLOT + 2 * PIECE);
         }
-        mfma12(pair, A[pair & 1], Bc);
+        if (pair == 2) {  // the six weight pieces of step tl + R3 - 1, one behind every second MFMA ...
+          const char* src = a.wpack + (long)((tl + R3 - 1) % NST) * SLOT + wave * (6 * PIECE);
+          const uint32_t dst = (uint32_t)(fslot * SLOT + wave * (6 * PIECE));
+          mfma12(pair, A[pair & 1], Bc, [&](int i) { dma_piece(src + i * PIECE, lane16, dst + i * PIECE); });
+        } else if (pair == 3) {  // ... then (BEHIND them in the queue) the side fragments consumed three steps from now
+          const int jc = (jp + 4) & 15;
+          const uint32_t sd = side_dst0 + (jp & 3) * SIDE_SLOT;
+          const char* s1 = reinterpret_cast<const char*>((jp < 12 ? lo1 : hi1) + 16 * jc);
+          const char* s2 = reinterpret_cast<const char*>((jp < 12 ? lo2 : hi2) + 16 * jc);
+          mfma12(pair, A[pair & 1], Bc, [&](int i) {
+            if (i < 2) dma_piece(s1 + 32 * i, ld_off, sd + i * PIECE);
+            else if (NAUX == 2 && i < 4) dma_piece(s2 + 32 * (i - 2), ld_off, sd + 2 * PIECE + (i - 2) * PIECE);
+          });
+        } else {
+          mfma12(pair, A[pair & 1], Bc, no_piece);
+        }
         nextB(pair);
         __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
 #pragma unroll

@@ -182,6 +182,18 @@ __device__ __forceinline__ void dma_step(const char* wpack, uint32_t lane16, int
       : "memory");
 }
 
+// one 1 KiB piece (wave-uniform source, lane offset lane16) to LDS byte `dst`.  M0 is not saved: nothing else in these
+// kernels uses it (no LDS-DMA builtin, no movrel), every statement that reads it writes it first.
+__device__ __forceinline__ void dma_piece(const char* src, uint32_t lane16, uint32_t dst) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1"
+      :
+      : "v"(lane16), "s"(src), "s"(dst)
+      : "memory");
+}
+
 #define R6_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
 template <bool HEAD, bool STORE, int DMAV = 0>
@@ -212,7 +224,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int i = 0; i < 6; ++i) dst[i] = *reinterpret_cast<const u32x4*>(base + i * PIECE);
   };
-  auto mfma12 = [&](int pair, const u32x4 (&af)[6], const Limbs& b) {
+  // `piece(i)` (i = 0..2) issues one DMA piece behind MFMAs 2, 6 and 10 of the group: an LDS-DMA instruction holds the
+  // wave's issue for longer than one MFMA runs, so the six pieces of a k step are spread over the 24 MFMAs that follow the
+  // rendezvous instead of standing in one block in front of them (where the matrix pipe drains)
+  auto mfma12 = [&](int pair, const u32x4 (&af)[6], const Limbs& b, auto&& piece) {
 #pragma unroll
     for (int pr = 0; pr < 6; ++pr) {
       const int wl = (pr == 2 || pr == 3) ? 1 : (pr == 5 ? 2 : 0);  // (w limb, act limb): 00 01 10 11 02 20
@@ -222,13 +237,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         Q[2 * pair + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[3 * t + wl]),
                                                                  __builtin_bit_cast(bf16x8, b.l[al]), Q[2 * pair + t],
                                                                  0, 0, 0);
-        // MFMAs may not cross (everything else may): the two accumulators stay ALTERNATING in the instruction stream --
-        // left alone the scheduler issues the six products of one tile back to back, a dependent chain whose
-        // accumulator latency exceeds the issue interval
-        __builtin_amdgcn_sched_barrier(0x7F6);
+        // MFMAs and vector-memory operations may not cross this point (VALU, SALU, LDS may): the DMA pieces below keep their
+        // place between the MFMAs
+        __builtin_amdgcn_sched_barrier(0x786);
       }
+      if ((pr & 1) == 0) piece(pr >> 1);
     }
   };
+  auto no_piece = [](int) {};
   auto init_bias = [&](int layer) {
     const float* bl = reinterpret_cast<const float*>(smem + OFF_BIAS) + layer * 256 + 4 * hh;
 #pragma unroll
@@ -294,9 +310,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (pair == 2) {  // mid-step rendezvous: step t + 1 complete in LDS, slot of step t - 1 free
           R6_WAIT_VM(12);
           __builtin_amdgcn_s_barrier();
-          dma_step<DMAV>(a.wpack, lane16, (t + 4) % NSTEP, (t + 4) % RING, wave);
         }
-        mfma12(pair, A[pair & 1], Bc);
+        if (pair >= 2) {  // behind the rendezvous: step t + 4 into the slot step t - 1 used, three pieces per group
+          const char* src = a.wpack + (long)((t + 4) % NSTEP) * SLOT + wave * (6 * PIECE) + (pair - 2) * (3 * PIECE);
+          const uint32_t dst = (uint32_t)(((t + 4) % RING) * SLOT + wave * (6 * PIECE) + (pair - 2) * (3 * PIECE));
+          mfma12(pair, A[pair & 1], Bc, [&](int i) { dma_piece(src + i * PIECE, lane16, dst + i * PIECE); });
+        } else {
+          mfma12(pair, A[pair & 1], Bc, no_piece);
+        }
         nextB(pair);
         // placement inside the group: the fragment reads for the next group first (their latency runs under this group's
         // MFMAs), then one MFMA / a few VALU of the next step's epilogue alternating; the six DMA issues of the

@@ -1,13 +1,19 @@
-"""profiles/r02_pmc_traffic.json from the two --pmc passes of scripts/prof_r02.sh (gpurun_out/prof_r02/{FETCH,WRITE}_SIZE.json).
+"""profiles/<round>_pmc_traffic.json from the two --pmc passes of scripts/prof_r03.sh (gpurun_out/prof_r03/{FETCH,WRITE}_SIZE.json).
 Unit / correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB; on gfx950 FETCH_SIZE
 reports half of wide coalesced reads, so read bytes = 2 * FETCH_SIZE * 1024."""
 import json, os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "prof_r02")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "prof_r03")
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
 F = json.load(open(os.path.join(src, "FETCH_SIZE.json")))
 W = json.load(open(os.path.join(src, "WRITE_SIZE.json")))
-groups = {"fused_sdf_kernel": ["fused_sdf_x6p_kernel", "fused_sdf_pipe_kernel", "fused_sdf_kernel"],
-          "chain_kernel": ["chain_x6_kernel", "chain_kernel"],
+# bench.py's kernel families -> rocprof kernel names (rmlp_kernel is both the sampler query <HEAD> and the forward trunk
+# <STORE>: the counter CSV keys carry no template arguments, so its traffic is reported under its own entry too)
+groups = {"fused_sdf_kernel": ["rmlp_kernel", "fused_sdf_x6p_kernel", "fused_sdf_pipe_kernel", "fused_sdf_kernel"],
+          "chain_kernel": ["chain_x6_kernel", "rchain_kernel", "chain_kernel"],
+          "rmlp_kernel": ["rmlp_kernel"], "rchain_kernel": ["rchain_kernel"], "chain_x6_kernel": ["chain_x6_kernel"],
+          "sampler_beta_kernel": ["sampler_beta_kernel"], "sampler_sample_kernel": ["sampler_sample_kernel"],
+          "composite_fwd_kernel": ["composite_fwd_kernel"], "composite_bwd_kernel": ["composite_bwd_kernel"],
           "gemm_nt_kernel": ["gemm_nt_kernel"],
           "wgrad_kernel": ["wgrad_lds_kernel", "wgrad_kernel"]}
 notes = {
@@ -20,7 +26,7 @@ notes = {
     "wgrad_kernel": "dW[N,K] = R^T X over P = 1.61 M points: (N + K) * 4 B per point = 2 KiB (3.3 GB) for the 256x256 layers; "
                     "split-K partials (<= 256 x 256 KiB) are written here and reduced by wgrad_reduce4_kernel"}
 out = {"command": "rocprofv3 --kernel-trace --pmc <C> -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile "
-                  "(one pass per counter; scripts/prof_r02.sh), chunk 16384 rays, default precision (f32x6)",
+                  "(one pass per counter; scripts/prof_r03.sh), chunk 16384 rays, default precision (f32x6)",
        "correction": "gfx950 FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md HBM section): read bytes = "
                      "2*FETCH_SIZE*1024; WRITE_SIZE taken as KiB", "kernels": {}}
 for g, names in groups.items():
@@ -33,7 +39,7 @@ for g, names in groups.items():
     out["kernels"][g] = {"pmc_kernel_names": [n for n in names if n in F], "launches_in_pass": nf,
                          "FETCH_SIZE_KB_avg_per_launch": sf / nf, "WRITE_SIZE_KB_avg_per_launch": sw / nw,
                          "hbm_read_bytes_per_launch": 2 * 1024 * sf / nf, "hbm_write_bytes_per_launch": 1024 * sw / nw,
-                         "hbm_bytes_per_launch": 2 * 1024 * sf / nf + 1024 * sw / nw, "algorithmic_note": notes[g]}
-dst = os.path.join(root, "profiles", "r02_pmc_traffic.json")
+                         "hbm_bytes_per_launch": 2 * 1024 * sf / nf + 1024 * sw / nw, "algorithmic_note": notes.get(g, "")}
+dst = os.path.join(root, "profiles", f"{rnd}_pmc_traffic.json")
 json.dump(out, open(dst, "w"), indent=1)
 print("wrote", dst, {k: round(v["hbm_bytes_per_launch"] / 1e9, 3) for k, v in out["kernels"].items()}, "GB/launch")
