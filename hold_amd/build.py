@@ -8,7 +8,10 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(_HERE, "csrc")
 OUT = os.path.join(_HERE, "libholdhip_dev.so" if os.environ.get("HOLD_DEV") == "1" else "libholdhip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+# -pragma-unroll-threshold: the register-resident kernels (rmlp.hip / rchain.hip) write one k step as 48 MFMA gaps with
+# constant-index slices of work behind each; LLVM refuses to fully unroll `#pragma unroll` nests beyond 16 384 instructions
+# (pre-simplification) and the accumulator arrays would then be indexed dynamically -- i.e. live in scratch memory
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-pragma-unroll-threshold=1048576"]
 # developer build (HOLD_DEV=1 in the environment of the BUILD): adds the diagnostics kernels (csrc/dev/diag.hip) and
 # compiles the timing-ablation / variant-selection environment switches into the launchers (-DHOLD_DEV).  The product
 # library has neither: its entry points are stateless and read no environment variables.

@@ -155,7 +155,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int R3 = 4;                      // weight ring slots; DMA distance R3 - 1 steps
   constexpr int SIDE_SLOT = NAUX * 2 * PIECE;
   constexpr int OFF_SIDE = R3 * SLOT;
-  constexpr int VPER = 4;
   // VMEM operations issued between the weight DMA of the previous rendezvous and this one's wait: the side DMA that follows
   // that weight DMA, the previous step's stores B, this step's stores A.  Waiting down to this count lands the weights
   // (needed now) and every side fragment issued ONE rendezvous earlier, while the newest side fragments stay in flight:
@@ -163,7 +162,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // The weights needed next were requested TWO rendezvous ago, like the side fragments consumed in the next step (which
   // sit right behind them in the queue): everything younger -- the previous rendezvous' 6 weight pieces and side request,
   // two steps' stores -- may stay in flight; weights and side both get two full steps.
-  constexpr int NWAIT = 6 + 2 * NAUX + 4 * NOUT;
+  constexpr int NWAIT = 6 + 2 * NAUX + 3 * NOUT;  // (queue per step: weights x 6, store, side x 2 NAUX, store)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -183,23 +182,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int i = 0; i < 6; ++i) dst[i] = *reinterpret_cast<const u32x4*>(base + i * PIECE);
   };
-  // piece(i), i = 0..5: DMA statements placed between the MFMAs of a group (an LDS-DMA instruction holds the wave's issue
-  // for longer than one MFMA runs: in one block in front of the group they drain the matrix pipe)
-  auto mfma12 = [&](int pair, const u32x4 (&af)[6], const Limbs& b, auto&& piece) {
-#pragma unroll
-    for (int pr = 0; pr < 6; ++pr) {
-      const int wl = (pr == 2 || pr == 3) ? 1 : (pr == 5 ? 2 : 0);  // (w limb, act limb): 00 01 10 11 02 20
-      const int al = (pr == 1 || pr == 3) ? 1 : (pr == 4 ? 2 : 0);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        Q[2 * pair + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[3 * t + wl]),
-                                                                 __builtin_bit_cast(bf16x8, b.l[al]), Q[2 * pair + t],
-                                                                 0, 0, 0);
-      }
-      piece(pr);
-    }
-  };
-  auto no_piece = [](int) {};
   auto zero_q = [&]() {
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt)
@@ -242,79 +224,121 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // side pointers of the epilogue layers lw = l - 1 ("lo", DMA of steps j' < 12) and lw = l ("hi", steps j' >= 12)
     const float *lo1 = a.aux1[0], *lo2 = NAUX == 2 ? a.aux2[0] : nullptr, *hi1 = lo1, *hi2 = lo2;
 
-    // One k step.  tl = step in the block's weight stream, jp = k step inside the layer (static).  At the rendezvous of
-    // step (l, jp) the side fragments of epilogue k step 16 (l - 1) + jp + 4 are requested (consumed three steps later,
-    // side slot = k step % 4: 16 is a multiple of the ring).
-    auto kstep = [&](int tl, int jp, auto&& nextB) {
+    // One k step with an EXPLICIT schedule (see rmlp.hip:kstep): 4 groups x 12 MFMAs, behind every MFMA a fixed slice of
+    // the rest -- one fragment read for the next group (gaps 0..5); in the group behind the rendezvous the six weight
+    // pieces of step tl + R3 - 1 (every second gap), in the last group, BEHIND them in the queue, the side fragments of
+    // epilogue k step 16 (l - 1) + jp + 4 (consumed three steps later; side slot = k step % 4); and cnt[group] / 12
+    // micro-operations of the next step's epilogue -- closed by a full scheduling barrier.
+    auto kstep = [&](int tl, int jp, const int (&cnt)[4], auto&& mop) {
       const int slot = gs % R3, nslot = (gs + 1) % R3, fslot = (gs + R3 - 1) % R3;
+      const char* wsrc = a.wpack + (long)((tl + R3 - 1) % NST) * SLOT + wave * (6 * PIECE);
+      const uint32_t wdst = (uint32_t)(fslot * SLOT + wave * (6 * PIECE));
+      const int jc = (jp + 4) & 15;
+      const uint32_t sd = side_dst0 + (jp & 3) * SIDE_SLOT;
+      const char* s1 = reinterpret_cast<const char*>((jp < 12 ? lo1 : hi1) + 16 * jc);
+      const char* s2 = reinterpret_cast<const char*>((jp < 12 ? lo2 : hi2) + 16 * jc);
 #pragma unroll
       for (int pair = 0; pair < 4; ++pair) {
-        if (pair < 3) {
-          read_pair(slot, pair + 1, A[(pair + 1) & 1]);
-        } else {
-          read_pair(nslot, 0, A[0]);  // landed: this step's rendezvous
-        }
         if (pair == 2) {  // rendezvous: the weights of step gs + 1 have landed in every wave; slot gs - 1 is free
           RC_WAIT_VM(NWAIT);
           __builtin_amdgcn_s_barrier();
         }
-        if (pair == 2) {  // the six weight pieces of step tl + R3 - 1, one behind every second MFMA ...
-          const char* src = a.wpack + (long)((tl + R3 - 1) % NST) * SLOT + wave * (6 * PIECE);
-          const uint32_t dst = (uint32_t)(fslot * SLOT + wave * (6 * PIECE));
-          mfma12(pair, A[pair & 1], Bc, [&](int i) { dma_piece(src + i * PIECE, lane16, dst + i * PIECE); });
-        } else if (pair == 3) {  // ... then (BEHIND them in the queue) the side fragments consumed three steps from now
-          const int jc = (jp + 4) & 15;
-          const uint32_t sd = side_dst0 + (jp & 3) * SIDE_SLOT;
-          const char* s1 = reinterpret_cast<const char*>((jp < 12 ? lo1 : hi1) + 16 * jc);
-          const char* s2 = reinterpret_cast<const char*>((jp < 12 ? lo2 : hi2) + 16 * jc);
-          mfma12(pair, A[pair & 1], Bc, [&](int i) {
-            if (i < 2) dma_piece(s1 + 32 * i, ld_off, sd + i * PIECE);
-            else if (NAUX == 2 && i < 4) dma_piece(s2 + 32 * (i - 2), ld_off, sd + 2 * PIECE + (i - 2) * PIECE);
-          });
-        } else {
-          mfma12(pair, A[pair & 1], Bc, no_piece);
-        }
-        nextB(pair);
-        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        const char* rd = ring_lane + (pair < 3 ? slot * SLOT + (pair + 1) * (6 * PIECE) : nslot * SLOT);
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x2, VPER, 0);
+        for (int m = 0; m < 12; ++m) {
+          const int pr = m >> 1, tt = m & 1;
+          const int wl = (pr == 2 || pr == 3) ? 1 : (pr == 5 ? 2 : 0);  // (w limb, act limb): 00 01 10 11 02 20
+          const int al = (pr == 1 || pr == 3) ? 1 : (pr == 4 ? 2 : 0);
+          Q[2 * pair + tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[pair & 1][3 * tt + wl]),
+                                                                    __builtin_bit_cast(bf16x8, Bc.l[al]), Q[2 * pair + tt],
+                                                                    0, 0, 0);
+          if (m < 6) A[(pair + 1) & 1][m] = *reinterpret_cast<const u32x4*>(rd + m * PIECE);
+          if (pair == 2 && (m & 1) == 0) dma_piece(wsrc + (m >> 1) * PIECE, lane16, wdst + (m >> 1) * PIECE);
+          if (pair == 3 && (m == 1 || m == 4)) dma_piece(s1 + 32 * (m == 4), ld_off, sd + (m == 4) * PIECE);
+          if (pair == 3 && NAUX == 2 && (m == 7 || m == 10))
+            dma_piece(s2 + 32 * (m == 10), ld_off, sd + 2 * PIECE + (m == 10) * PIECE);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {  // constant trip count (the slice bounds fold once pair and m are unrolled)
+            const int k = cnt[pair] * m / 12 + u;
+            if (k < cnt[pair] * (m + 1) / 12) mop(pair, k);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
       Bc = Bn;
       gs += 1;
     };
-    auto no_next = [](int) {};
+    static constexpr int CNT_NONE[4] = {0, 0, 0, 0};
+    auto no_mop = [](int, int) {};
 
-    // epilogue of one dword (two values) of k step j of the finished layer in P; lw = its chain layer (wave-uniform),
-    // raw = DSP layer 0 (the chain input itself is the B operand).  Side values from this wave's LDS ring slot `ss`.
+    // Epilogue of k step j of the finished layer in P (chain layer lw, wave-uniform; raw = chain layer 0 is fed by the chain
+    // input itself): 8 values, four stages of micro-operations in round-major order (rmlp.hip: consecutive operations
+    // independent).  Side values from this wave's LDS ring slot `ss` (two / four 16-byte reads).
+    //   stage 0: y, h (and a2), x = 100 h, e = exp(-x), the four operations of the small-x series of 1 - e^{-x}
+    //   stage 1: 1 - e, series select, y * sp', + a2, raw / skip-layer selects                           -> r[8]
+    //   stage 2 / 3: limb split of r[0..3] / r[4..7], 16-byte store
     rsrc_t ors = make_rsrc(nullptr, 0);
-    f32x4 keep = {0.f, 0.f, 0.f, 0.f};
-    auto epi = [&](int j, int c, int ss, bool raw, bool skip, Limbs& out) {
+    struct EpiState { float y[8], h[8], x2[8], e[8], ser[8], r[8]; uint32_t w[2][8]; };
+    static constexpr int CNT_DSP[4] = {64, A2 ? 40 : 32, 23, 23};
+    auto epi_mop = [&](int j, int ss, bool raw, bool skip, int stage, int k, Limbs& out, EpiState& st) {
       const int nt = j >> 1, q = j & 1;
-      const int f0 = 16 * j + 8 * (c >> 1) + 4 * hh + 2 * (c & 1);
-      const float* sp = side_rd + ss * (SIDE_SLOT / 4) + (c >> 1) * (PIECE / 4) + 2 * (c & 1);
-      const f32x2 hv = *reinterpret_cast<const f32x2*>(sp);
-      f32x2 xv = {0.f, 0.f};
-      if (NAUX == 2) xv = *reinterpret_cast<const f32x2*>(sp + 2 * (PIECE / 4));
-      float r[2];
+      const int rd = k >> 3, i = k & 7;
+      if (stage == 0) {
+        if (rd == 0) {
+          st.y[i] = P[nt][8 * q + i];
+          if ((i & 3) == 0) {  // this value and the next three: one 16-byte read of the side fragment(s)
+            const float* sp = side_rd + ss * (SIDE_SLOT / 4) + (i >> 2) * (PIECE / 4);
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(sp);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const float y = P[nt][8 * q + 2 * c + i];
-        float v = y * dsp(hv[i]);
-        if (A2) v += xv[i];
-        r[i] = raw ? y : v;
-      }
-      if (j >= 13) {  // skip layer (chain layer 3), columns 217..: the raw products (d / d skip input) are stored
+            for (int v = 0; v < 4; ++v) st.h[i + v] = hv[v];
+            if (A2) {
+              const f32x4 xv = *reinterpret_cast<const f32x4*>(sp + 2 * (PIECE / 4));
 #pragma unroll
-        for (int i = 0; i < 2; ++i) r[i] = (skip && f0 + i >= SKIP_OUT) ? P[nt][8 * q + 2 * c + i] : r[i];
+              for (int v = 0; v < 4; ++v) st.x2[i + v] = xv[v];
+            }
+          }
+        } else if (rd == 1) st.e[i] = -144.26950408889634f * st.h[i];
+        else if (rd == 2) st.e[i] = __builtin_amdgcn_exp2f(st.e[i]);
+        else if (rd == 3) st.h[i] = 100.0f * st.h[i];
+        else if (rd == 4) st.ser[i] = fmaf(st.h[i], -0.041666668f, 0.16666667f);
+        else if (rd == 5) st.ser[i] = fmaf(-st.h[i], st.ser[i], 0.5f);
+        else if (rd == 6) st.ser[i] = fmaf(-st.h[i], st.ser[i], 1.0f);
+        else st.ser[i] = st.h[i] * st.ser[i];
+      } else if (stage == 1) {
+        if (rd == 0) st.e[i] = 1.0f - st.e[i];
+        else if (rd == 1) st.e[i] = (st.h[i] < 0.05f) ? st.ser[i] : st.e[i];
+        else if (rd == 2) st.r[i] = st.y[i] * st.e[i];
+        else if (A2 && rd == 3) st.r[i] = st.r[i] + st.x2[i];
+        else {
+          float r = raw ? st.y[i] : st.r[i];
+          if (j >= 13) {  // skip layer (chain layer 3), columns 217..: the raw products (d / d skip input) are stored
+            const int f = 16 * j + 8 * (i >> 2) + 4 * hh + (i & 3);
+            r = (skip && f >= SKIP_OUT) ? st.y[i] : r;
+          }
+          st.r[i] = r;
+        }
+      } else {
+        const int h2 = stage - 2;
+        if (k == 22) {
+          const f32x4 v = {st.r[4 * h2], st.r[4 * h2 + 1], st.r[4 * h2 + 2], st.r[4 * h2 + 3]};
+          store4(v, ors, st_off + (16 * j + 8 * h2) * 4);
+          return;
+        }
+        const int d = k & 1, op = k >> 1;
+        const float x0 = st.r[4 * h2 + 2 * d], x1 = st.r[4 * h2 + 2 * d + 1];
+        uint32_t* w = st.w[d];
+        if (op == 0) w[0] = fbits(x0) & 0xffff0000u;
+        else if (op == 1) w[1] = fbits(x1) & 0xffff0000u;
+        else if (op == 2) w[2] = fbits(x0 - bitsf(w[0]));
+        else if (op == 3) w[3] = fbits(x1 - bitsf(w[1]));
+        else if (op == 4) w[4] = w[2] & 0xffff0000u;
+        else if (op == 5) w[5] = w[3] & 0xffff0000u;
+        else if (op == 6) w[6] = fbits(bitsf(w[2]) - bitsf(w[4]));
+        else if (op == 7) w[7] = fbits(bitsf(w[3]) - bitsf(w[5]));
+        else if (op == 8) out.l[0][2 * h2 + d] = __builtin_amdgcn_perm(fbits(x1), fbits(x0), 0x07060302u);
+        else if (op == 9) out.l[1][2 * h2 + d] = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
+        else out.l[2][2 * h2 + d] = __builtin_amdgcn_perm(w[7], w[6], 0x07060302u);
       }
-      put_limbs(out, c, split2(r[0], r[1]));
-      keep[2 * (c & 1)] = r[0];
-      keep[2 * (c & 1) + 1] = r[1];
-      if (c & 1) store4(keep, ors, st_off + (16 * j + 8 * (c >> 1)) * 4);
     };
 
     for (int l = 0; l < L; ++l) {
@@ -340,14 +364,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
       ors = make_rsrc(raw ? nullptr : a.out[lwc], nbytes);
       const int t0 = 16 * l;
+      EpiState st;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) epi(0, c, 0, raw, skip, Bc);
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < 64; ++k)
+          if (k < CNT_DSP[c]) epi_mop(0, 0, raw, skip, c, k, Bc, st);
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         if (j + 1 < 16)
-          kstep(t0 + j, j, [&](int c) { epi(j + 1, c, (j + 1) & 3, raw, skip, Bn); });
+          kstep(t0 + j, j, CNT_DSP, [&](int c, int k) { epi_mop(j + 1, (j + 1) & 3, raw, skip, c, k, Bn, st); });
         else
-          kstep(t0 + j, j, no_next);
+          kstep(t0 + j, j, CNT_NONE, no_mop);
       }
     }
 

@@ -214,7 +214,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int s = 0; s < 4; ++s) dma_step<DMAV>(a.wpack, lane16, s, s, wave);
 
-  constexpr int VPER = HEAD ? 2 : 4;  // VALU instructions of the next step's epilogue per MFMA (12 MFMAs per group)
   f32x16 P[8], Q[8];
   u32x4 A[2][6];  // weight fragments of two n-tiles x three limbs, double-buffered
   Limbs Bc, Bn;
@@ -224,27 +223,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int i = 0; i < 6; ++i) dst[i] = *reinterpret_cast<const u32x4*>(base + i * PIECE);
   };
-  // `piece(i)` (i = 0..2) issues one DMA piece behind MFMAs 2, 6 and 10 of the group: an LDS-DMA instruction holds the
-  // wave's issue for longer than one MFMA runs, so the six pieces of a k step are spread over the 24 MFMAs that follow the
-  // rendezvous instead of standing in one block in front of them (where the matrix pipe drains)
-  auto mfma12 = [&](int pair, const u32x4 (&af)[6], const Limbs& b, auto&& piece) {
-#pragma unroll
-    for (int pr = 0; pr < 6; ++pr) {
-      const int wl = (pr == 2 || pr == 3) ? 1 : (pr == 5 ? 2 : 0);  // (w limb, act limb): 00 01 10 11 02 20
-      const int al = (pr == 1 || pr == 3) ? 1 : (pr == 4 ? 2 : 0);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        Q[2 * pair + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[3 * t + wl]),
-                                                                 __builtin_bit_cast(bf16x8, b.l[al]), Q[2 * pair + t],
-                                                                 0, 0, 0);
-        // MFMAs and vector-memory operations may not cross this point (VALU, SALU, LDS may): the DMA pieces below keep their
-        // place between the MFMAs
-        __builtin_amdgcn_sched_barrier(0x786);
-      }
-      if ((pr & 1) == 0) piece(pr >> 1);
-    }
-  };
-  auto no_piece = [](int) {};
   auto init_bias = [&](int layer) {
     const float* bl = reinterpret_cast<const float*>(smem + OFF_BIAS) + layer * 256 + 4 * hh;
 #pragma unroll
@@ -296,44 +274,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       first = 0;
     }
 
-    // One k step of the layer being accumulated into Q.  `t` = step index in the block's stream (slot t % RING).
-    // nextB(c) produces dword c (two values) of the NEXT step's limbs into Bn; it is spread over the four MFMA groups.
-    auto kstep = [&](int t, auto&& nextB) {
+    // One k step of the layer being accumulated into Q (`t` = step index in the block's stream, ring slot t % RING), with an
+    // EXPLICIT schedule: the step is 4 groups x 12 MFMAs, and behind every MFMA stands a fixed slice of everything else
+    // -- one fragment read for the next group (gaps 0..5), one DMA piece (gaps 1, 5, 9 of the two groups behind the
+    // rendezvous), and cnt[group] / 12 micro-operations of the next step's epilogue (mop(group, k), k = 0 .. cnt - 1, in
+    // order) -- closed by a full scheduling barrier.  With one wave per SIMD the wave must be back at the next MFMA within
+    // the 32 cycles the current one runs; left to the scheduler the epilogue's VALU clustered in runs of 15 - 30
+    // instructions between runs of back-to-back MFMAs and the matrix pipe drained in every one of them.
+    auto kstep = [&](int t, const int (&cnt)[4], auto&& mop) {
       const int slot = t % RING;
 #pragma unroll
       for (int pair = 0; pair < 4; ++pair) {
-        if (pair < 3) {
-          read_pair(slot, pair + 1, A[(pair + 1) & 1]);
-        } else {
-          read_pair((t + 1) % RING, 0, A[0]);  // landed: this step's mid barrier
-        }
         if (pair == 2) {  // mid-step rendezvous: step t + 1 complete in LDS, slot of step t - 1 free
           R6_WAIT_VM(12);
           __builtin_amdgcn_s_barrier();
         }
-        if (pair >= 2) {  // behind the rendezvous: step t + 4 into the slot step t - 1 used, three pieces per group
-          const char* src = a.wpack + (long)((t + 4) % NSTEP) * SLOT + wave * (6 * PIECE) + (pair - 2) * (3 * PIECE);
-          const uint32_t dst = (uint32_t)(((t + 4) % RING) * SLOT + wave * (6 * PIECE) + (pair - 2) * (3 * PIECE));
-          mfma12(pair, A[pair & 1], Bc, [&](int i) { dma_piece(src + i * PIECE, lane16, dst + i * PIECE); });
-        } else {
-          mfma12(pair, A[pair & 1], Bc, no_piece);
-        }
-        nextB(pair);
-        // placement inside the group: the fragment reads for the next group first (their latency runs under this group's
-        // MFMAs), then one MFMA / a few VALU of the next step's epilogue alternating; the six DMA issues of the
-        // rendezvous group go between MFMAs as well
-        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        const char* rd = ring_lane + (pair < 3 ? slot * SLOT + (pair + 1) * (6 * PIECE) : ((t + 1) % RING) * SLOT);
+        const char* src = a.wpack + (long)((t + 4) % NSTEP) * SLOT + wave * (6 * PIECE) + (pair & 1) * (3 * PIECE);
+        const uint32_t dst = (uint32_t)(((t + 4) % RING) * SLOT + wave * (6 * PIECE) + (pair & 1) * (3 * PIECE));
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x2, VPER, 0);
-          if (pair == 2 && (i & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
+        for (int m = 0; m < 12; ++m) {
+          const int pr = m >> 1, tl = m & 1;
+          const int wl = (pr == 2 || pr == 3) ? 1 : (pr == 5 ? 2 : 0);  // (w limb, act limb): 00 01 10 11 02 20
+          const int al = (pr == 1 || pr == 3) ? 1 : (pr == 4 ? 2 : 0);
+          Q[2 * pair + tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[pair & 1][3 * tl + wl]),
+                                                                    __builtin_bit_cast(bf16x8, Bc.l[al]), Q[2 * pair + tl],
+                                                                    0, 0, 0);
+          if (m < 6) A[(pair + 1) & 1][m] = *reinterpret_cast<const u32x4*>(rd + m * PIECE);
+          if (pair >= 2 && (m & 3) == 1) dma_piece(src + (m >> 2) * PIECE, lane16, dst + (m >> 2) * PIECE);
+#pragma unroll
+          for (int u = 0; u < 6; ++u) {  // constant trip count (the slice bounds fold once pair and m are unrolled)
+            const int k = cnt[pair] * m / 12 + u;
+            if (k < cnt[pair] * (m + 1) / 12) mop(pair, k);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
       Bc = Bn;
     };
-    auto no_next = [](int) {};
+    static constexpr int CNT_NONE[4] = {0, 0, 0, 0};
+    auto no_mop = [](int, int) {};
 
     // ---- layer 0: B limbs straight from the embedding (natural k order 16 j + 8 hh + e) ----
     auto emb_limbs = [&](int j, int c, Limbs& out) {
@@ -343,12 +323,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     init_bias(0);
 #pragma unroll
     for (int c = 0; c < 4; ++c) emb_limbs(0, c, Bc);
+    static constexpr int CNT_EMB[4] = {1, 1, 1, 1};
 #pragma unroll
     for (int j = 0; j < L0S; ++j) {
       if (j + 1 < L0S)
-        kstep(j, [&](int c) { emb_limbs(j + 1, c, Bn); });
+        kstep(j, CNT_EMB, [&](int c, int) { emb_limbs(j + 1, c, Bn); });
       else
-        kstep(j, no_next);
+        kstep(j, CNT_NONE, no_mop);
     }
 
     // ---- layers 1..7: input = softplus of the previous layer's accumulators ----
@@ -357,25 +338,75 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     rsrc_t hrs = make_rsrc(nullptr, 0);
     const uint32_t hbytes = (uint32_t)(a.P * a.ldh * 4);
     const uint32_t hvoff = (uint32_t)(((p0 + li) * a.ldh + 4 * hh) * 4);
-    // dword c of k step j = (nt, q): values P[nt][8 q + 2 c], +1 = features 32 nt + 16 q + 8 (c / 2) + 4 hh + 2 (c % 2), +1
-    auto act_limbs = [&](int layer, int j, int c, Limbs& out, f32x4& keep) {
+    // Epilogue of k step j = (nt, q) of the finished layer: its 8 values P[nt][8 q + i] (features 32 nt + 16 q + 8 (i / 4) +
+    // 4 hh + i % 4), as FOUR stages (one per MFMA group of the running k step) of micro-operations in ROUND-MAJOR order:
+    // micro-operation k of a stage = round k / 8 on value k % 8, so consecutive micro-operations are independent and a
+    // dependent pair (exp -> add -> log -> fma -> and -> sub ...) is eight apart -- with one wave per SIMD nothing else
+    // would hide a dependent VALU chain's latency.
+    //   stage 0: y, |y| c, e = exp2(.), 1 + e (training: + the three operations of the log1p series)
+    //   stage 1: log2, max(y, 0), softplus (training: series select, threshold select), skip-layer override  -> r[8]
+    //   stage 2 / 3: limb split of r[0..3] / r[4..7] (two dwords each, the two dwords' operations alternating), store
+    struct EpiState { float y[8], u[8], e[8], ser[8], r[8]; uint32_t w[2][8]; };
+    static constexpr int CNT_SP[4] = {HEAD ? 32 : 64, HEAD ? 24 : 48, 22 + (STORE ? 1 : 0), 22 + (STORE ? 1 : 0)};
+    auto epi_mop = [&](int layer, int j, int stage, int k, Limbs& out, EpiState& st) {
       const int nt = j >> 1, q = j & 1;
-      const int f0 = 32 * nt + 16 * q + 8 * (c >> 1) + 4 * hh + 2 * (c & 1);
-      float v0 = HEAD ? sp_fast(P[nt][8 * q + 2 * c]) : sp_train(P[nt][8 * q + 2 * c]);
-      float v1 = HEAD ? sp_fast(P[nt][8 * q + 2 * c + 1]) : sp_train(P[nt][8 * q + 2 * c + 1]);
-      if (j >= 13) {  // skip connection: columns 217.. of layer 3's output are the embedding (shape_net.py:122-123)
-        const bool sk = layer == 4;
-        const int m0 = f0 - SKIP_OUT;
-        const float e0 = embw[li * EMB_STR + (m0 < 0 ? 0 : m0)], e1 = embw[li * EMB_STR + (m0 + 1 < 0 ? 0 : m0 + 1)];
-        v0 = (sk && m0 >= 0) ? e0 : v0;
-        v1 = (sk && m0 + 1 >= 0) ? e1 : v1;
-      }
-      put_limbs(out, c, split2(v0, v1));
-      if (STORE) {
-        keep[2 * (c & 1)] = v0;
-        keep[2 * (c & 1) + 1] = v1;
-        if (c & 1)  // four consecutive features of this lane's point: one 16-byte store of h_{layer-1}
-          store4(keep, hrs, hvoff + (32 * nt + 16 * q + 8 * (c >> 1)) * 4);
+      const int rd = k >> 3, i = k & 7;
+      if (stage == 0) {
+        if (rd == 0) st.y[i] = P[nt][8 * q + i];
+        else if (rd == 1) st.e[i] = -144.26950408889634f * fabsf(st.y[i]);
+        else if (rd == 2) st.e[i] = __builtin_amdgcn_exp2f(st.e[i]);
+        else if (rd == 3) st.u[i] = 1.0f + st.e[i];
+        else if (rd == 4) st.ser[i] = fmaf(st.e[i], 0.33333334f, -0.5f);
+        else if (rd == 5) st.ser[i] = fmaf(st.e[i], st.ser[i], 1.0f);
+        else if (rd == 6) st.e[i] = 0.01f * st.e[i];
+        else st.ser[i] = st.e[i] * st.ser[i];
+      } else if (stage == 1) {
+        if (rd == 0) st.u[i] = __builtin_amdgcn_logf(st.u[i]);
+        else if (rd == 1) st.r[i] = relu1(st.y[i]);
+        else if (HEAD) {
+          float r = fmaf(0.0069314718056f, st.u[i], st.r[i]);
+          if (j >= 13) {  // skip connection: columns 217.. of layer 3's output are the embedding (shape_net.py:122-123)
+            const int m = 32 * nt + 16 * q + 8 * (i >> 2) + 4 * hh + (i & 3) - SKIP_OUT;
+            const float ev = embw[li * EMB_STR + (m < 0 ? 0 : m)];
+            r = (layer == 4 && m >= 0) ? ev : r;
+          }
+          st.r[i] = r;
+        } else if (rd == 2) {
+          st.u[i] = 0.0069314718056f * st.u[i];
+        } else if (rd == 3) {  // e > 1e-3 (e was scaled by 0.01 in stage 0): log(1 + e) is accurate; else the series
+          st.u[i] = (st.e[i] > 1e-5f) ? st.u[i] : st.ser[i];
+        } else if (rd == 4) {
+          st.r[i] = st.r[i] + st.u[i];
+        } else {
+          float r = (st.y[i] > 0.2f) ? st.y[i] : st.r[i];
+          if (j >= 13) {
+            const int m = 32 * nt + 16 * q + 8 * (i >> 2) + 4 * hh + (i & 3) - SKIP_OUT;
+            const float ev = embw[li * EMB_STR + (m < 0 ? 0 : m)];
+            r = (layer == 4 && m >= 0) ? ev : r;
+          }
+          st.r[i] = r;
+        }
+      } else {
+        const int h2 = stage - 2;
+        if (k == 22) {  // STORE: the four consecutive features of this half
+          const f32x4 v = {st.r[4 * h2], st.r[4 * h2 + 1], st.r[4 * h2 + 2], st.r[4 * h2 + 3]};
+          store4(v, hrs, hvoff + (32 * nt + 16 * q + 8 * h2) * 4);
+          return;
+        }
+        const int d = k & 1, op = k >> 1;  // dword d of this half (values 4 h2 + 2 d, + 1), operation op = 0..10
+        const float x0 = st.r[4 * h2 + 2 * d], x1 = st.r[4 * h2 + 2 * d + 1];
+        uint32_t* w = st.w[d];  // w[0..1] high parts, w[2..3] first remainders, w[4..5] their high parts, w[6..7] second remainders
+        if (op == 0) w[0] = fbits(x0) & 0xffff0000u;
+        else if (op == 1) w[1] = fbits(x1) & 0xffff0000u;
+        else if (op == 2) w[2] = fbits(x0 - bitsf(w[0]));
+        else if (op == 3) w[3] = fbits(x1 - bitsf(w[1]));
+        else if (op == 4) w[4] = w[2] & 0xffff0000u;
+        else if (op == 5) w[5] = w[3] & 0xffff0000u;
+        else if (op == 6) w[6] = fbits(bitsf(w[2]) - bitsf(w[4]));
+        else if (op == 7) w[7] = fbits(bitsf(w[3]) - bitsf(w[5]));
+        else if (op == 8) out.l[0][2 * h2 + d] = __builtin_amdgcn_perm(fbits(x1), fbits(x0), 0x07060302u);
+        else if (op == 9) out.l[1][2 * h2 + d] = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
+        else out.l[2][2 * h2 + d] = __builtin_amdgcn_perm(w[7], w[6], 0x07060302u);
       }
     };
     for (int layer = 1; layer < 8; ++layer) {
@@ -389,16 +420,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
       init_bias(layer);
       const int t0 = L0S + (layer - 1) * LKS;
-      f32x4 keep;
+      EpiState st;
       if (STORE) hrs = make_rsrc(a.h[layer - 1], hbytes);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) act_limbs(layer, 0, c, Bc, keep);
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < 64; ++k)
+          if (k < CNT_SP[c]) epi_mop(layer, 0, c, k, Bc, st);
 #pragma unroll
       for (int j = 0; j < LKS; ++j) {
         if (j + 1 < LKS)
-          kstep(t0 + j, [&](int c) { act_limbs(layer, j + 1, c, Bn, keep); });
+          kstep(t0 + j, CNT_SP, [&](int c, int k) { epi_mop(layer, j + 1, c, k, Bn, st); });
         else
-          kstep(t0 + j, no_next);
+          kstep(t0 + j, CNT_NONE, no_mop);
       }
     }
     // ---- output of layer 7 ----
