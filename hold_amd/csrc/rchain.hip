@@ -6,6 +6,8 @@
 //
 //   v_{l-1} = (M_j v_l) * sp'(aux1_j) [+ aux2_j]          7 layers, input v_7 [P][256]
 //   (the semantics of hold_chain / hold_chain_x6, mode DSP, skip_layer = 3, include/hold_hip.h)
+// Used for the sweep WITHOUT the additive side input (d sdf / d a_l of the normal path; 150 vs 134 TF-eq); with aux2
+// (3 KiB per point and layer) it measured 113 vs 124 TF-eq for hold_chain_x6 and the host keeps that sweep there.
 // The ascending second-order sweep (mode DBWD: two side inputs and two results per layer) was built in this structure too
 // and measured SLOWER than hold_chain_x6 (85 vs 108 TF-eq, matrix pipe 22 % busy, 57 % of the wave time stalled at issue):
 // a lane owns a POINT here, so side inputs and results move as 32-byte row fragments -- four L2 requests per 128-byte
