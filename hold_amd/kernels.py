@@ -143,7 +143,7 @@ def trunk_r6(xc, P, wpack_r6, bias8, barf_w, h):
         arr = (C.c_void_p * 8)(*[t[r0:].data_ptr() for t in h])
         e0 = _g._prof_begin()
         call("hold_trunk_r6", ptr(xc[r0:]), _ld(xc), n, ptr(wpack_r6), ptr(bias8), ptr(barf_w), arr, ld)
-        _g._prof_end(e0, 2.0 * n * (40 * 256 + 6 * 65536 + 217 * 256), "chain_kernel")
+        _g._prof_end(e0, 2.0 * n * (40 * 256 + 6 * 65536 + 217 * 256), "trunk_r6_kernel")
 
 
 CHAIN_SOFTPLUS, CHAIN_DSP, CHAIN_DBWD = 0, 1, 2
@@ -191,7 +191,7 @@ def chain(mode, P, x_in, wpack, n_layers, first_chunks, skip_layer=-1, side=None
         d.ld = ld if ld is not None else 256
         e0 = _g._prof_begin()
         call("hold_chain_r6" if r6 else ("hold_chain" if wpack_x6 is None else "hold_chain_x6"), C.byref(d))
-        _g._prof_end(e0, 2.0 * (r1 - r0) * 256 * (8 * first_chunks + 256 * (n_layers - 1)), "chain_kernel")
+        _g._prof_end(e0, 2.0 * (r1 - r0) * 256 * (8 * first_chunks + 256 * (n_layers - 1)), "rchain_kernel" if r6 else "chain_kernel")
 
 
 def seed_dsp(h, w, N, P, t):
