@@ -18,8 +18,11 @@ f = glob.glob("/tmp/pmc_$c/**/*counter_collection.csv", recursive=True)
 agg = collections.defaultdict(lambda: [0, 0.0])
 if f:
     for r in csv.DictReader(open(f[0])):
-        m = re.search(r"(?:anonymous namespace\)::)?(\w+)(?:<|\()", r["Kernel_Name"].replace("void ", ""))
-        k = m.group(1) if m else r["Kernel_Name"][:40]
+        nm = r["Kernel_Name"].replace("void ", "")
+        m = re.search(r"(?:anonymous namespace\)::)?(\w+)(<[^>]*>)?(?:\()", nm)
+        k = m.group(1) if m else nm[:40]
+        if m and m.group(2) and k in ("rmlp_kernel", "rchain_kernel", "chain_x6_kernel"):
+            k += m.group(2).replace(" ", "")  # instantiations of the trunk kernels are different sweeps
         agg[k][0] += 1
         agg[k][1] += float(r["Counter_Value"])
 out = {k: {"launches": v[0], "sum": v[1], "avg_per_launch": v[1] / v[0]} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]}
