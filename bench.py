@@ -57,6 +57,14 @@ def parse():
     ap.add_argument("--two-hands", action="store_true", help="ARCTIC-style scene (right + left + object), config C4")
     ap.add_argument("--fp32-mfma", action="store_true", help="true-fp32 MFMA everywhere (no split-precision kernels)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--op-sites", default=None, metavar="PATH",
+                    help="diagnostic: count the non-view torch operators of ONE extra step by the hold_amd source line that "
+                         "issued them (TorchDispatchMode; run after the timed steps) and write the table to PATH")
+    ap.add_argument("--sync-debug", default=None, metavar="PATH",
+                    help="diagnostic: write the call sites of every host<->device synchronisation of the timed steps to PATH")
+    ap.add_argument("--torch-profile", default=None, metavar="PATH",
+                    help="diagnostic: run the timed steps under torch.profiler and write the per-operator call counts / "
+                         "host and device times to PATH (the step time of such a run is perturbed; not a bench line)")
     ap.add_argument("--no-refine", action="store_true", help="--mode c3: skip the pose-refinement leg")
     ap.add_argument("--no-freeze", action="store_true",
                     help="let Adam move the weights during the run (default: the flat parameter bucket is restored after "
@@ -288,6 +296,22 @@ def main():
     for node in net.nodes.values():
         node.ray_sampler.sum_iters = node.ray_sampler.n_calls = 0
     calls0 = _L.CALLS
+    if args.sync_debug and rank == 0:
+        import collections, traceback, warnings
+        sync_sites = collections.Counter()
+        def _show(message, category, filename, lineno, file=None, line=None):
+            if "synchroniz" not in str(message):
+                return
+            st = [f for f in traceback.extract_stack()[:-1] if "/hold_amd/" in f.filename or f.filename.endswith("bench.py")]
+            sync_sites[" <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in reversed(st[-4:]))] += 1
+        warnings.showwarning = _show
+        warnings.simplefilter("always")
+        torch.cuda.set_sync_debug_mode("warn")
+    tprof = None
+    if args.torch_profile and rank == 0:
+        from torch.profiler import ProfilerActivity, profile
+        tprof = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True)
+        tprof.__enter__()
     t0 = time.perf_counter()
     rays = 0
     loss = 0.0
@@ -295,6 +319,58 @@ def main():
         loss = step(args.warmup + i)
         rays += rays_per_step
     torch.cuda.synchronize()
+    if args.sync_debug and rank == 0:
+        torch.cuda.set_sync_debug_mode("default")
+        with open(args.sync_debug, "w") as f:
+            f.write(f"# host synchronisation sites over {args.steps} steps of --mode {args.mode} (count, call chain)\n")
+            for site, n in sync_sites.most_common():
+                f.write(f"{n:6d}  {site}\n")
+    if args.op_sites and rank == 0:
+        import collections, traceback
+        from torch.utils._python_dispatch import TorchDispatchMode
+        VIEWS = ("slice", "as_strided", "view", "select", "expand", "permute", "transpose", "reshape", "unsqueeze", "squeeze",
+                 "t.", "detach", "alias", "empty", "_unsafe_view", "unbind", "split", "narrow", "size", "stride", "is_", "sym_")
+        sites = collections.defaultdict(collections.Counter)
+
+        class _Count(TorchDispatchMode):
+            def __torch_dispatch__(self, func, types, a=(), kw=None):
+                name = str(func).replace("aten.", "")
+                if not name.startswith(VIEWS):
+                    st = [f for f in traceback.extract_stack() if "/hold_amd/" in f.filename or f.filename.endswith("bench.py")]
+                    st = [f for f in st if "__torch_dispatch__" not in f.name]
+                    site = f"{os.path.basename(st[-1].filename)}:{st[-1].lineno} {st[-1].name}" if st else "(autograd engine)"
+                    sites[site][name] += 1
+                return func(*a, **(kw or {}))
+
+        with _Count():
+            step(args.warmup + args.steps)
+        torch.cuda.synchronize()
+        with open(args.op_sites, "w") as f:
+            tot = sum(sum(c.values()) for c in sites.values())
+            f.write(f"# non-view torch operators of one --mode {args.mode} step by issuing source line: {tot} in all\n")
+            for site, c in sorted(sites.items(), key=lambda kv: -sum(kv[1].values())):
+                f.write(f"{sum(c.values()):6d}  {site}  {dict(c.most_common(5))}\n")
+    if tprof is not None:
+        tprof.__exit__(None, None, None)
+        ka = tprof.key_averages()
+        with open(args.torch_profile, "w") as f:
+            f.write(f"# {args.steps} steps of --mode {args.mode}; sorted by call count\n")
+            f.write(ka.table(sort_by="count", row_limit=120, max_name_column_width=70))
+            f.write("\n# sorted by device time\n")
+            f.write(ka.table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=70))
+            # device-launching aten operators by the hold_amd / bench source line that issued them
+            import collections
+            sites = collections.defaultdict(lambda: [0, 0.0, collections.Counter()])
+            for e in tprof.key_averages(group_by_stack_n=12):
+                if not e.key.startswith("aten::") or e.self_device_time_total <= 0:
+                    continue
+                fr = [x for x in e.stack if "/hold_amd/" in x or "bench.py" in x]
+                site = fr[0].split("/")[-1] if fr else "(autograd engine / no python frame)"
+                a = sites[site]
+                a[0] += e.count; a[1] += e.self_device_time_total; a[2][e.key] += e.count
+            f.write("\n# device-launching aten calls by source line: calls, device us, operators\n")
+            for site, a in sorted(sites.items(), key=lambda kv: -kv[1][0])[:150]:
+                f.write(f"{a[0]:6d} {a[1]:10.0f}  {site}  {dict(a[2].most_common(4))}\n")
     if dist.is_initialized():
         dist.barrier()
     dt = time.perf_counter() - t0

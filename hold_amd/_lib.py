@@ -50,6 +50,15 @@ class ChainDesc(C.Structure):
     ]
 
 
+class WnLayer(C.Structure):
+    _fields_ = [("v", C.c_void_p), ("g", C.c_void_p), ("w", C.c_void_p), ("dw", C.c_void_p), ("dv", C.c_void_p),
+                ("dg", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32), ("ldv", C.c_int32), ("ldw", C.c_int32)]
+
+
+class WnDesc(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("accumulate", C.c_int32), ("layers", WnLayer * 16)]
+
+
 _lib = None
 
 
@@ -115,7 +124,9 @@ SIGNATURES = {
     "hold_frame_bcast": [_P, _I, _L, _L, _P, _I, _I, _P],
     "hold_copy_cols": [_P, _I, _P, _I, _I, _L, _I, _P],
     "hold_bg_points": [_P, _P, _P, _I, _L, _F, _P, _I, _P],
-    "hold_rowdot": [_P, _I, _P, _I, _F, _L, _P, _I, _P],
+    "hold_weight_norm_fwd": [C.POINTER(WnDesc), _P],
+    "hold_weight_norm_bwd": [C.POINTER(WnDesc), _P],
+    "hold_rowdot": [_P, _I, _P, _I, _F, _P, _L, _P, _I, _P],
     "hold_seed_dsp": [_P, _I, _P, _I, _L, _P, _I, _P],
     "hold_colsum": [_P, _I, _I, _L, _P, _P],
     "hold_wcolsum": [_P, _I, _I, _L, _P, _P, _I, _P, _P],
@@ -148,7 +159,7 @@ SIGNATURES = {
     "hold_mt_vertices": [_P, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P],
     "hold_mt_triangles": [_P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P],
     "hold_fused_sdf_x6": [_P, _I, _L, _P, _P, _P, _F, _P, _P, _I, _P],
-    "hold_fused_sdf_r6": [_P, _I, _L, _P, _P, _P, _F, _P, _P, _I, _P],
+    "hold_fused_sdf_r6": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _I, _P],
     "hold_trunk_r6": [_P, _I, _L, _P, _P, _P, C.POINTER(C.c_void_p), _I, _P],
     "hold_mano_lbs_fwd": [C.POINTER(ManoModel), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "hold_mano_lbs_bwd": [C.POINTER(ManoModel), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
@@ -196,6 +207,15 @@ def call(name, *args):
     code = getattr(L, name)(*args, stream_ptr())
     if code != 0:
         raise RuntimeError(f"libholdhip: {name} failed with code {code}")
+
+
+def h2d(t, device):
+    """host tensor -> device without draining the stream: a pageable-memory copy is synchronous (it waits for everything
+    queued before it), a copy out of pinned memory is ordered on the stream like a kernel.  torch's caching host allocator
+    keeps the pinned block alive until the copy has run."""
+    if torch.device(device).type == "cuda":
+        return t.pin_memory().to(device, non_blocking=True)
+    return t.to(device)
 
 
 def stream_ptr():

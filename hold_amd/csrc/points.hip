@@ -768,7 +768,7 @@ __global__ void bg_points_kernel(const float* __restrict__ cam, const float* __r
 
 // out[p] = sum_k A[p][k] * w[k] + b   (one wave per row, K <= 256*... any K multiple of 4)
 __global__ void rowdot_kernel(const float* __restrict__ A, int lda, const float* __restrict__ w, int K, float b,
-                              long P, float* __restrict__ out, int ldo) {
+                              const float* __restrict__ b_dev, long P, float* __restrict__ out, int ldo) {
   const int lane = threadIdx.x & 63;
   const long p = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (p >= P) return;
@@ -780,7 +780,7 @@ __global__ void rowdot_kernel(const float* __restrict__ A, int lda, const float*
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
-  if (lane == 0) out[p * ldo] = acc + b;
+  if (lane == 0) out[p * ldo] = acc + (b_dev ? b + *b_dev : b);
 }
 
 // t[p][n] = w[n] * softplus'(h[p][n])   (start of the reverse sweep: u_7 = W_8[sdf row])
@@ -815,12 +815,12 @@ extern "C" int hold_bg_points(const float* cam_loc, const float* ray_dirs, const
   return ok();
 }
 
-extern "C" int hold_rowdot(const float* A, int32_t lda, const float* w, int32_t K, float b, int64_t P, float* out,
-                           int32_t ldo, hold_stream_t st) {
+extern "C" int hold_rowdot(const float* A, int32_t lda, const float* w, int32_t K, float b, const float* b_dev, int64_t P,
+                           float* out, int32_t ldo, hold_stream_t st) {
   if (!A || !w || !out || (K & 3) || (lda & 3)) return HOLD_E_ARG;
   if (P == 0) return HOLD_OK;
   hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, (hipStream_t)st, A, lda, w, K, b,
-                     (long)P, out, ldo);
+                     b_dev, (long)P, out, ldo);
   return ok();
 }
 

@@ -148,7 +148,9 @@ __device__ __forceinline__ void dma_piece(const char* src, uint32_t voff, uint32
 
 #define RC_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
-template <bool A2>
+// ABL: developer-build timing ablations (results are garbage): 2 no in-loop stores, 3 the stores' bytes as lane-linear
+// 1 KiB pieces, 4 the side loads' bytes as lane-linear 1 KiB pieces, 5 both
+template <bool A2, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rchain_kernel(RCArgs a) {
   constexpr int NAUX = A2 ? 2 : 1;           // side matrices per layer
   constexpr int NOUT = 1;                    // result matrices per layer
@@ -201,7 +203,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const long row = blk * BPTS + wave * 32 + li;  // this lane's point
     const long crow = row < a.P ? row : a.P - 1;    // clamped for the DMA reads (rows >= P: results dropped by the stores)
     const uint32_t st_off = (uint32_t)((row * a.ld + 4 * hh) * 4);   // stores: unclamped, the buffer range check drops them
-    const uint32_t ld_off = (uint32_t)((crow * a.ld + 4 * hh) * 4);  // side DMA source
+    uint32_t ld_off = (uint32_t)((crow * a.ld + 4 * hh) * 4);  // side DMA source
+    const uint32_t lin_off = (uint32_t)((blk * BPTS + wave * 32) * a.ld * 4) + lane16;
+    if (ABL >= 4) ld_off = lin_off;
 
     // ---- chain input: v_7 rows into the accumulator layout, P[nt][4 g + k] = in[row][32 nt + 8 g + 4 hh + k] ----
     {
@@ -237,8 +241,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const uint32_t wdst = (uint32_t)(fslot * SLOT + wave * (6 * PIECE));
       const int jc = (jp + 4) & 15;
       const uint32_t sd = side_dst0 + (jp & 3) * SIDE_SLOT;
-      const char* s1 = reinterpret_cast<const char*>((jp < 12 ? lo1 : hi1) + 16 * jc);
-      const char* s2 = reinterpret_cast<const char*>((jp < 12 ? lo2 : hi2) + 16 * jc);
+      const char* s1 = reinterpret_cast<const char*>((jp < 12 ? lo1 : hi1) + (ABL >= 4 ? 512 : 16) * jc);
+      const char* s2 = reinterpret_cast<const char*>((jp < 12 ? lo2 : hi2) + (ABL >= 4 ? 512 : 16) * jc);
+      constexpr int SECOND = ABL >= 4 ? 1024 : 32;
 #pragma unroll
       for (int pair = 0; pair < 4; ++pair) {
         if (pair == 2) {  // rendezvous: the weights of step gs + 1 have landed in every wave; slot gs - 1 is free
@@ -256,9 +261,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                                     0, 0, 0);
           if (m < 6) A[(pair + 1) & 1][m] = *reinterpret_cast<const u32x4*>(rd + m * PIECE);
           if (pair == 2 && (m & 1) == 0) dma_piece(wsrc + (m >> 1) * PIECE, lane16, wdst + (m >> 1) * PIECE);
-          if (pair == 3 && (m == 1 || m == 4)) dma_piece(s1 + 32 * (m == 4), ld_off, sd + (m == 4) * PIECE);
+          if (pair == 3 && (m == 1 || m == 4)) dma_piece(s1 + SECOND * (m == 4), ld_off, sd + (m == 4) * PIECE);
           if (pair == 3 && NAUX == 2 && (m == 7 || m == 10))
-            dma_piece(s2 + 32 * (m == 10), ld_off, sd + 2 * PIECE + (m == 10) * PIECE);
+            dma_piece(s2 + SECOND * (m == 10), ld_off, sd + 2 * PIECE + (m == 10) * PIECE);
 #pragma unroll
           for (int u = 0; u < 8; ++u) {  // constant trip count (the slice bounds fold once pair and m are unrolled)
             const int k = cnt[pair] * m / 12 + u;
@@ -323,6 +328,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int h2 = stage - 2;
         if (k == 22) {
           const f32x4 v = {st.r[4 * h2], st.r[4 * h2 + 1], st.r[4 * h2 + 2], st.r[4 * h2 + 3]};
+          if (ABL == 2) return;
+          if (ABL == 3 || ABL == 5) {
+            store4(v, ors, lin_off + (2 * j + h2) * 1024);
+            return;
+          }
           store4(v, ors, st_off + (16 * j + 8 * h2) * 4);
           return;
         }
@@ -426,6 +436,20 @@ static int rchain_launch(const RCArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const long blocks = (a.P + BPTS - 1) / BPTS;
+#ifdef HOLD_DEV
+  if (const char* v = getenv("HOLD_R6_ABL")) {
+    const dim3 grid((unsigned)(blocks < n_cu ? blocks : n_cu));
+#define RC_ABL(N)                                                                                                          \
+  if (v[0] == '0' + N) {                                                                                                   \
+    if (hipFuncSetAttribute((const void*)rchain_kernel<A2, N>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) \
+      return HOLD_E_LAUNCH;                                                                                                \
+    hipLaunchKernelGGL((rchain_kernel<A2, N>), grid, dim3(256), lds, s, a);                                                \
+    return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;                                                      \
+  }
+    RC_ABL(2) RC_ABL(3) RC_ABL(4) RC_ABL(5)
+#undef RC_ABL
+  }
+#endif
   hipLaunchKernelGGL((rchain_kernel<A2>), dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(256), lds, s, a);
   return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
 }

@@ -56,7 +56,7 @@ struct R6Args {
   const char* wpack;    // hold_trunk_r6_pack_bytes() bytes, [NSTEP][24 pieces][64 lanes][8 bf16]
   const float* bias;    // [8][256]
   const float* w8;      // [256] sdf row of lin8 (HEAD)
-  float b8;
+  const float* b8;      // device scalar: bias of the sdf row (HEAD)
   const float* barf;    // [39] or null
   float* sdf; int lds;  // HEAD output
   float* h[8]; int ldh; // STORE outputs ([P][ldh], columns 0..255)
@@ -205,6 +205,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const uint32_t lane16 = lane * 16;
   float* embw = reinterpret_cast<float*>(smem + OFF_EMB) + wave * (32 * EMB_STR);
   const char* ring_lane = smem + lane * 16;
+  const float b8 = HEAD ? *a.b8 : 0.f;  // read on the device: a host copy of a trained parameter costs a stream drain
 
   // ---- once per workgroup: biases (+ the sdf row) into LDS, the first four k steps into the ring ----
   for (int i = tid; i < 8 * 256; i += 256) reinterpret_cast<float*>(smem + OFF_BIAS)[i] = a.bias[i];
@@ -390,6 +391,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int h2 = stage - 2;
         if (k == 22) {  // STORE: the four consecutive features of this half
           const f32x4 v = {st.r[4 * h2], st.r[4 * h2 + 1], st.r[4 * h2 + 2], st.r[4 * h2 + 3]};
+          if (DMAV == 2) return;  // developer-build ablation: no activation stores
+          if (DMAV == 3) {        // developer-build ablation: the same bytes as lane-linear 1 KiB stores (wrong layout)
+            store4(v, hrs, (uint32_t)(p0 * a.ldh * 4) + lane16 + (4 * nt + 2 * q + h2) * 1024);
+            return;
+          }
           store4(v, hrs, hvoff + (32 * nt + 16 * q + 8 * h2) * 4);
           return;
         }
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             store4(v, h7rs, hvoff + (32 * nt + 8 * g) * 4);
         }
       if (HEAD) {
-        const float s = part + __shfl_xor(part, 32) + a.b8;
+        const float s = part + __shfl_xor(part, 32) + b8;
         if (hh == 0 && prow_ok) a.sdf[prow * a.lds] = s;
       }
     }
@@ -487,6 +493,18 @@ static int rmlp_launch(const R6Args& a, bool head, bool store, hipStream_t s) {
   const dim3 grid((unsigned)(blocks < n_cu ? blocks : n_cu));
 #ifdef HOLD_DEV
   if (const char* v = getenv("HOLD_R6_DMA")) {
+    if ((v[0] == '2' || v[0] == '3') && store && !head) {
+      static bool set2 = false;
+      if (!set2 && (hipFuncSetAttribute((const void*)rmlp_kernel<false, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        LDS_BYTES) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)rmlp_kernel<false, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        LDS_BYTES) != hipSuccess))
+        return HOLD_E_LAUNCH;
+      set2 = true;
+      if (v[0] == '2') hipLaunchKernelGGL((rmlp_kernel<false, true, 2>), grid, dim3(256), LDS_BYTES, s, a);
+      else hipLaunchKernelGGL((rmlp_kernel<false, true, 3>), grid, dim3(256), LDS_BYTES, s, a);
+      return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+    }
     if (v[0] == '1' && head && !store) {
       static bool set1 = false;
       if (!set1 && hipFuncSetAttribute((const void*)rmlp_kernel<true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -509,9 +527,9 @@ static int rmlp_launch(const R6Args& a, bool head, bool store, hipStream_t s) {
 
 // SDF-only query of the sampler (the contract of hold_fused_sdf_x6 with the register-resident trunk).
 extern "C" int hold_fused_sdf_r6(const float* xc, int32_t ldx, int64_t P, const void* wpack_r6, const float* bias,
-                                 const float* w8, float b8, const float* barf_w, float* sdf, int32_t ld_sdf,
+                                 const float* w8, const float* b8, const float* barf_w, float* sdf, int32_t ld_sdf,
                                  hold_stream_t st) {
-  if (!xc || !wpack_r6 || !bias || !w8 || !sdf || ldx < 3 || ld_sdf < 1 || P < 0) return HOLD_E_ARG;
+  if (!xc || !wpack_r6 || !bias || !w8 || !b8 || !sdf || ldx < 3 || ld_sdf < 1 || P < 0) return HOLD_E_ARG;
   if (((uintptr_t)wpack_r6 & 15) || ((uintptr_t)w8 & 15) || ((uintptr_t)bias & 15)) return HOLD_E_ARG;
   if (P == 0) return HOLD_OK;
   R6Args a = {};

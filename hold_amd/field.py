@@ -34,11 +34,17 @@ USE_R6_BWD = os.environ.get("HOLD_R6_BWD", "1") != "0"  # ... and for the descen
 RIN_FEAT, RIN_X, RIN_N, RIN_POSE, RIN_TIME = 0, 256, 259, 262, 270
 
 
+_RIN_PERM = {}
+
+
 def rin_perm(rin_dim, device=None):
     """our rin column j holds the reference's rendering-net input column rin_perm[j]
     (reference order: xc 0:3, normal 3:6, pose 6:14, feature 14:270, time 270:302; texture_net.py:60-83)"""
-    idx = list(range(14, 270)) + list(range(0, 14)) + list(range(270, rin_dim))
-    return torch.tensor(idx, dtype=torch.long, device=device)
+    key = (rin_dim, str(device))
+    if key not in _RIN_PERM:
+        idx = list(range(14, 270)) + list(range(0, 14)) + list(range(270, rin_dim))
+        _RIN_PERM[key] = torch.tensor(idx, dtype=torch.long, device=device)
+    return _RIN_PERM[key]
 
 
 def pad4(n):
@@ -121,6 +127,27 @@ def split_limbs(w, n=3):
     return out
 
 
+# layouts of the limb packs, applied to ALREADY split limbs l3 = [3 limbs, ...] (any dtype: pack_plan() runs them on index
+# tensors to derive the gather that builds a pack in one launch)
+def _lay_x6(l3, K):
+    return l3.reshape(3, 8, 32, K // 16, 2, 8).permute(3, 0, 1, 4, 2, 5).reshape(-1)
+
+
+def _lay_x6_stack(l3):
+    L = l3.shape[1]
+    return l3.reshape(3, L, 8, 32, 16, 2, 8).permute(1, 4, 0, 2, 5, 3, 6).reshape(-1)
+
+
+def _lay_r6_0(l3):
+    return l3.reshape(3, 8, 32, 3, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(-1)
+
+
+def _lay_r6_stack(l3):
+    L = l3.shape[1]
+    g = l3[:, :, :, r6_kmap(l3.device)]  # [3 t, L, 256 out, 16 j, 2 h, 8 e]
+    return g.reshape(3, L, 8, 32, 16, 2, 8).permute(1, 4, 2, 0, 5, 3, 6).reshape(-1)
+
+
 def pack_x6(W8, first_k=48):
     """limb pack of hold_fused_sdf_x6 / hold_chain_x6 (include/hold_hip.h) from up to 8 matrices W8[l] ([<=256, K_l]; the
     first one zero-padded to first_k = 48 columns for the 40-wide embedding input, or 256): bf16 tensor,
@@ -130,26 +157,29 @@ def pack_x6(W8, first_k=48):
         K = first_k if l == 0 else 256
         m = torch.zeros(256, K, device=wl.device)
         m[:wl.shape[0], :wl.shape[1]] = wl
-        limbs = torch.stack(split_limbs(m))  # [3, 256, K] bf16
-        parts.append(limbs.reshape(3, 8, 32, K // 16, 2, 8).permute(3, 0, 1, 4, 2, 5).reshape(-1))
+        parts.append(_lay_x6(torch.stack(split_limbs(m)), K))  # limbs [3, 256, K] bf16
     return torch.cat(parts).contiguous()
 
 
 def pack_x6_stack(S):
     """pack_x6 of L zero-padded [256, 256] matrices given as one [L, 256, 256] tensor (same layout, a dozen device ops
     for all of them instead of a dozen per matrix)"""
-    L = S.shape[0]
-    limbs = torch.stack(split_limbs(S))  # [3, L, 256, 256] bf16: (t, L, 32 nt + i, 16 step + 8 h + e)
-    return limbs.reshape(3, L, 8, 32, 16, 2, 8).permute(1, 4, 0, 2, 5, 3, 6).reshape(-1)
+    return _lay_x6_stack(torch.stack(split_limbs(S)))  # limbs [3, L, 256, 256] bf16: (t, L, 32 nt + i, 16 step + 8 h + e)
+
+
+_KMAP = {}
 
 
 def r6_kmap(device=None):
     """virtual k order of hold_trunk_r6 for the 256-wide layers: kmap[j, h, e] = input feature that element e of lane half h
     holds in k step j = the register order of the previous layer's v_mfma_f32_32x32x16_bf16 outputs (csrc/rmlp.hip)"""
-    j = torch.arange(16, device=device).view(16, 1, 1)
-    h = torch.arange(2, device=device).view(1, 2, 1)
-    e = torch.arange(8, device=device).view(1, 1, 8)
-    return 32 * (j // 2) + 16 * (j % 2) + 8 * (e // 4) + 4 * h + e % 4
+    key = str(device)
+    if key not in _KMAP:
+        j = torch.arange(16, device=device).view(16, 1, 1)
+        h = torch.arange(2, device=device).view(1, 2, 1)
+        e = torch.arange(8, device=device).view(1, 1, 8)
+        _KMAP[key] = 32 * (j // 2) + 16 * (j % 2) + 8 * (e // 4) + 4 * h + e % 4
+    return _KMAP[key]
 
 
 def pack_r6(w0, S):
@@ -158,20 +188,43 @@ def pack_r6(w0, S):
     dev = S.device
     m0 = torch.zeros(256, 48, device=dev)
     m0[:, :w0.shape[1]] = w0
-    l0 = torch.stack(split_limbs(m0))  # [3, 256, 48] = (t, 32 nt + i, 16 j + 8 h + e)
-    p0 = l0.reshape(3, 8, 32, 3, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(-1)
-    lk = torch.stack(split_limbs(S))  # [3, 7, 256, 256]
-    g = lk[:, :, :, r6_kmap(dev)]  # [3 t, 7 L, 256 out, 16 j, 2 h, 8 e]
-    pk = g.reshape(3, 7, 8, 32, 16, 2, 8).permute(1, 4, 2, 0, 5, 3, 6).reshape(-1)
-    return torch.cat([p0, pk]).contiguous()
+    p0 = _lay_r6_0(torch.stack(split_limbs(m0)))  # limbs [3, 256, 48] = (t, 32 nt + i, 16 j + 8 h + e)
+    return torch.cat([p0, _lay_r6_stack(torch.stack(split_limbs(S)))]).contiguous()
 
 
 def pack_r6_stack(S):
     """hold_chain_r6 (DSP) stream of L [256, 256] matrices: every layer in the virtual k order (r6_kmap)"""
-    L = S.shape[0]
-    lk = torch.stack(split_limbs(S))  # [3, L, 256, 256]
-    g = lk[:, :, :, r6_kmap(S.device)]  # [3 t, L, 256 out, 16 j, 2 h, 8 e]
-    return g.reshape(3, L, 8, 32, 16, 2, 8).permute(1, 4, 2, 0, 5, 3, 6).reshape(-1).contiguous()
+    return _lay_r6_stack(torch.stack(split_limbs(S))).contiguous()
+
+
+_PLANS = {}
+
+
+def pack_plan(K0, device):
+    """int32 gather indices that build every fragment / limb pack of the trunk from ONE flat source
+    src = [w0 zero-padded to [256, 48] | S [7, 256, 256]] and its three bf16 limbs [3, N]: a pack is a fixed permutation
+    of (limb, element), so it is derived once by running the pack's layout on an index tensor and is then one
+    index_select per pack and step -- a training step at the reference's 1 280-ray batch re-packs once per step and
+    spent ~600 small launches doing so layer by layer."""
+    key = (K0, str(device))
+    if key not in _PLANS:
+        n0, ns = 256 * 48, 7 * 65536
+        N = n0 + ns
+        I0 = torch.arange(n0, device=device).view(256, 48)
+        IS = n0 + torch.arange(ns, device=device).view(7, 256, 256)
+        ISTf = IS.transpose(1, 2).flip(0)  # descending sweeps: layer j = W_{7-j}^T
+        l3 = lambda I: torch.stack([I + t * N for t in range(3)])
+        i32 = lambda t: t.to(torch.int32).contiguous()
+        frag0 = I0[:, :K0].reshape(8, 32, K0 // 8, 2, 4).permute(2, 0, 3, 1, 4).reshape(-1)
+        _PLANS[key] = dict(
+            N=N,
+            fused=i32(torch.cat([frag0, frag_pack_stack(IS)])),
+            chain_bwd=i32(frag_pack_stack(ISTf)),
+            fused_x6=i32(torch.cat([_lay_x6(l3(I0), 48), _lay_x6_stack(l3(IS))])),
+            trunk_r6=i32(torch.cat([_lay_r6_0(l3(I0)), _lay_r6_stack(l3(IS))])),
+            chain_bwd_x6=i32(_lay_x6_stack(l3(ISTf))),
+            chain_bwd_r6=i32(_lay_r6_stack(l3(ISTf))))
+    return _PLANS[key]
 
 
 def frag_pack_stack(S):
@@ -181,28 +234,29 @@ def frag_pack_stack(S):
     return S.reshape(L, 8, 32, 32, 2, 4).permute(0, 3, 1, 4, 2, 5).reshape(-1)
 
 
-def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
+def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool, trunk=None):
     """iw/ib: 9 effective ImplicitNet weights/biases ([out,in] as nn.Linear); rw/rb: 5 RenderingNet ones (or None).
     Returns the re-laid-out (and, for sweeps that contract over the output index, transposed) copies the
     kernels read.  The seven 256-wide trunk layers are handled as ONE [7, 256, 256] tensor (the per-layer entries of
     pk["W"] / pk["WT"] are views of it): ~70 small device ops per pack instead of ~290 -- what a 1 280-ray training
     step, which packs once per step, spends its host time on."""
     dev = iw[0].device
+    if trunk is not None:  # the ImplicitNet part was packed already (same weights): add the RenderingNet's
+        return _pack_render(dict(trunk), spec, rw, rb, need_bwd, dev)
     pk = {}
-    w0 = torch.zeros(256, spec.K0, device=dev)
-    w0[:, :spec.E] = iw[0][:, :spec.E]  # the 45 MANO pose-cond columns multiply zeros (shape_net.py:104-106)
-    S = torch.zeros(7, 256, 256, device=dev)  # trunk layers 1..7, rows zero-padded to 256 (layer 3 has 217)
-    for l in range(1, 8):
-        src = iw[l] / math.sqrt(2) if l == 4 else iw[l]  # cat([x, input]) / sqrt(2) folded into the weight
-        S[l - 1, :src.shape[0]] = src
+    pad = torch.nn.functional.pad
+    w0 = pad(iw[0][:, :spec.E], (0, spec.K0 - spec.E))  # the 45 MANO pose-cond columns multiply zeros (shape_net.py:104-106)
+    # trunk layers 1..7, rows zero-padded to 256 (layer 3 has 217); cat([x, input]) / sqrt(2) folded into lin4's weight
+    S = torch.stack([(lambda m: m if m.shape[0] == 256 else pad(m, (0, 0, 0, 256 - m.shape[0])))(
+        iw[l] / math.sqrt(2) if l == 4 else iw[l]) for l in range(1, 8)])
     w8 = torch.cat([iw[8][1:], iw[8][:1]], 0).contiguous()  # rows: feat(256) then sdf
     W = [w0] + [S[l - 1][:iw[l].shape[0]] for l in range(1, 8)] + [w8]
     pk["W"] = W
     pk["b"] = [b.contiguous() for b in ib[:8]] + [torch.cat([ib[8][1:], ib[8][:1]]).contiguous()]
     pk["iw0_cols"] = iw[0].shape[1]
     pk["w8_sdf"] = iw[8][0].contiguous()
-    pk["b8_sdf"] = ib[8][0]
-    pk["b8_sdf_f"] = float(ib[8][0])  # the one host read of a pack (kernel scalar argument)
+    pk["b8_sdf"] = ib[8][:1].contiguous()  # stays on the device (hold_fused_sdf_r6 reads it there); the scalar-argument
+    # entry points (hold_fused_sdf / _x6) take float(pk["b8_sdf"]) at their call sites -- a host read drains the stream
     pk["W8_feat"], pk["b8_feat"] = w8[:256], pk["b"][8][:256]  # lin8 without its sdf row (a 257th column costs a whole tile)
     # transposes [K_l][pad4(N_l)] for the sweeps that contract over the output index
     ST = S.transpose(1, 2).contiguous()  # [7][k][n], columns n >= N_l zero
@@ -211,26 +265,26 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
     pk["WT"] = [w0.t().contiguous()] + [ST[l - 1][:, :pad4(iw[l].shape[0])] for l in range(1, 8)] + [wt8]
     pk["WT8_feat"] = w8[:256].t().contiguous()  # [k = 256 trunk units][n = 256 feature rows]: lin8's input gradient
     # fragment-ordered pack for the fused SDF-only kernel (hold_fused_sdf)
-    frag0 = w0.reshape(8, 32, spec.K0 // 8, 2, 4).permute(2, 0, 3, 1, 4).reshape(-1)
-    bias8 = torch.zeros(8, 256, device=dev)
-    full = [l for l in range(8) if pk["b"][l].shape[0] == 256]
-    bias8[full] = torch.stack([pk["b"][l] for l in full])
-    for l in range(8):
-        if l not in full:
-            bias8[l, :pk["b"][l].shape[0]] = pk["b"][l]
-    pk["fused"] = (torch.cat([frag0, frag_pack_stack(S)]), bias8)
-    if config.x6():
-        pk["fused_x6"] = torch.cat([pack_x6([w0]), pack_x6_stack(S)])
-        pk["trunk_r6"] = pack_r6(w0, S)
-    # descending sweeps (hold_chain DSP): layer j contracts over the outputs of trunk layer l = 7 - j, M_j = W_l^T
-    STf = ST.flip(0)
-    pk["chain_bwd"] = frag_pack_stack(STf)
-    if config.x6():  # limb packs of the same matrices for hold_chain_x6 (the forward-type sweeps share the sampler trunk's)
+    bias8 = torch.stack([b if b.shape[0] == 256 else torch.nn.functional.pad(b, (0, 256 - b.shape[0])) for b in pk["b"][:8]])
+    # every fragment / limb pack = one gather from the flat source (pack_plan); the descending sweeps' matrices
+    # (hold_chain DSP: layer j contracts over the outputs of trunk layer l = 7 - j, M_j = W_l^T) come from the same source
+    plan = pack_plan(spec.K0, dev)
+    src = torch.cat([torch.nn.functional.pad(w0, (0, 48 - spec.K0)).reshape(-1), S.reshape(-1)])
+    pk["fused"] = (src.index_select(0, plan["fused"]), bias8)
+    pk["chain_bwd"] = src.index_select(0, plan["chain_bwd"])
+    if config.x6():  # limb packs (the forward-type sweeps of hold_chain_x6 share the sampler trunk's)
+        limbs = torch.stack(split_limbs(src)).reshape(-1)  # [3 N] bf16
+        pk["fused_x6"] = limbs.index_select(0, plan["fused_x6"])
+        pk["trunk_r6"] = limbs.index_select(0, plan["trunk_r6"])
         pk["chain_fwd_x6"] = pk["fused_x6"]
-        pk["chain_bwd_x6"] = pack_x6_stack(STf)
-        pk["chain_bwd_r6"] = pack_r6_stack(STf)
+        pk["chain_bwd_x6"] = limbs.index_select(0, plan["chain_bwd_x6"])
+        pk["chain_bwd_r6"] = limbs.index_select(0, plan["chain_bwd_r6"])
     if rw is None:  # implicit net only (ImplicitNet.forward / gradient)
         return pk
+    return _pack_render(pk, spec, rw, rb, need_bwd, dev)
+
+
+def _pack_render(pk, spec, rw, rb, need_bwd, dev):
     r0 = torch.zeros(256, spec.Kr, device=dev)
     r0[:, :spec.rin_dim] = rw[0][:, rin_perm(spec.rin_dim, dev)]
     R = [r0, rw[1].contiguous(), rw[2].contiguous(), rw[3].contiguous(), rw[4].contiguous()]
@@ -319,18 +373,18 @@ class NodeField:
         self.gen += 1  # overwrites the pooled canonical points a pending backward would read
         xc, _ = self._deform(x, P, ppf, dfm, want_w=False)
         if FUSED_SDF and USE_R6 and "trunk_r6" in pk:
-            K.fused_sdf_r6(xc, P, pk["trunk_r6"], pk["fused"][1], pk["w8_sdf"], pk["b8_sdf_f"], barf_w, out_sdf)
+            K.fused_sdf_r6(xc, P, pk["trunk_r6"], pk["fused"][1], pk["w8_sdf"], pk["b8_sdf"], barf_w, out_sdf)
             return
         if FUSED_SDF and "fused_x6" in pk:
-            K.fused_sdf_x6(xc, P, pk["fused_x6"], pk["fused"][1], pk["w8_sdf"], pk["b8_sdf_f"], barf_w, out_sdf)
+            K.fused_sdf_x6(xc, P, pk["fused_x6"], pk["fused"][1], pk["w8_sdf"], float(pk["b8_sdf"]), barf_w, out_sdf)
             return
         if FUSED_SDF:
             wpack, bias8 = pk["fused"]
-            K.fused_sdf(xc, P, wpack, bias8, pk["w8_sdf"], pk["b8_sdf_f"], barf_w, out_sdf)
+            K.fused_sdf(xc, P, wpack, bias8, pk["w8_sdf"], float(pk["b8_sdf"]), barf_w, out_sdf)
             return
         # layer-by-layer variant (ping-pong activations: two [P,256] buffers + the skip buffer stay live)
         _, h = self._trunk(pk, xc, P, barf_w, keep_all=False)
-        K.rowdot(h[7], pk["w8_sdf"], 256, pk["b8_sdf_f"], P, out_sdf)
+        K.rowdot(h[7], pk["w8_sdf"], 256, pk["b8_sdf"], P, out_sdf)
 
     # ------------------------------------------------------------------ full forward
     def forward(self, pk, x, P, ppf, dfm, barf_w, pose_embed, time_code, training):
@@ -343,7 +397,7 @@ class NodeField:
         sdf = pool.get("sdf", P, 1)
         # lin8 = 256 feature rows as a full-tile GEMM + the sdf row as a row dot (N = 257 would add a 256-wide tile for it)
         G.gemm_nt(h[7], pk["W8_feat"], rin[:, RIN_FEAT:RIN_FEAT + FEAT], bias=pk["b8_feat"], N=256)
-        K.rowdot(h[7], pk["w8_sdf"], 256, pk["b8_sdf_f"], P, sdf)
+        K.rowdot(h[7], pk["w8_sdf"], 256, pk["b8_sdf"], P, sdf)
         # ---- reverse sweep: t_l = d sdf / d a_l, ge = d sdf / d embed, g = d sdf / d xc ----
         WT = pk["WT"]
         # t[3] always has its own buffer: its columns 217..219 are K-padding of the next GEMM and must stay zero

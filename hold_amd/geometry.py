@@ -134,7 +134,9 @@ class PointInSpace:
         self.local_sigma = local_sigma
 
     def get_points(self, pc_input, local_sigma=None, global_ratio=0.125):
-        gs = self.global_sigma_xyz.to(pc_input.device)
+        if self.global_sigma_xyz.device != pc_input.device:  # moved once (every host -> device copy drains the stream)
+            self.global_sigma_xyz = self.global_sigma_xyz.to(pc_input.device)
+        gs = self.global_sigma_xyz
         B, N, D = pc_input.shape
         local = pc_input + torch.randn_like(pc_input) * (self.local_sigma if local_sigma is None else local_sigma)
         glob = torch.rand(B, int(N * global_ratio), D, device=pc_input.device) * (gs * 2) - gs

@@ -12,7 +12,10 @@ from __future__ import annotations
 
 import math
 
+import ctypes as C
+
 import numpy as np
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -89,7 +92,10 @@ class BarfEmbedder(Embedder):
     def weights(self, device):
         if self.no_barf:
             return None
-        return self.barf_weights.to(device=device, dtype=torch.float32).contiguous()
+        key = (str(device), self._iter_host)
+        if getattr(self, "_w_dev", (None, None))[0] != key:  # one upload per schedule step, not one per query
+            self._w_dev = (key, _lib_h2d(self.barf_weights.to(torch.float32).contiguous(), device))
+        return self._w_dev[1]
 
 
 def _lin(inn, out, weight_norm):
@@ -103,6 +109,11 @@ def _pack_key(modules, training):
             tuple((p._version, p.data_ptr()) for m in modules for p in m.parameters()))
 
 
+def _lib_h2d(t, device):
+    from ._lib import h2d
+    return h2d(t, device)
+
+
 def _eff(lin):
     """effective weight of a (possibly weight-normed) Linear, differentiable w.r.t. weight_g / weight_v."""
     if hasattr(lin, "weight_g"):
@@ -112,52 +123,73 @@ def _eff(lin):
 
 
 class _WeightNormFn(torch.autograd.Function):
-    """w_l = v_l * (g_l / ||v_l||_row) for ALL weight-normed layers of a net in a handful of launches: layers of equal
-    fan-in are concatenated along the rows (forward: cat, norm, div, mul; backward: cat, two reductions' worth of
-    elementwise ops), where autograd's per-layer graph costs ~10 tiny kernels per layer and direction.  Same forward
-    arithmetic per element as `_eff`; backward dv = s*D - v*(t*g/n^3), dg = t/n with t = rowsum(D*v), n = ||v||, s = g/n."""
+    """w_l = v_l * (g_l / ||v_l||_row) for ALL weight-normed layers of a net: one launch per direction
+    (hold_weight_norm_fwd / _bwd, csrc/wnorm.hip) where autograd's per-layer graph costs ~10 tiny kernels per layer and
+    direction.  Backward: t = rowsum(D * v), n = ||v||: dg = t / n, dv = D g / n - v t g / n^3.
+
+    Parameters that live in FlatAdam's gradient bucket (``p._hold_bucket``, set by FlatAdam) get their gradients ADDED into
+    ``p.grad`` by the kernel itself and ``None`` is returned to autograd for them -- no per-parameter AccumulateGrad
+    launch; ``torch.autograd.grad`` w.r.t. such a parameter therefore sees None (use ``.backward()`` / ``p.grad``)."""
 
     @staticmethod
     def forward(ctx, L, *vg):
+        from . import _lib
         vs, gs = vg[:L], vg[L:]
-        groups = {}
-        for i, v in enumerate(vs):
-            groups.setdefault(v.shape[1], []).append(i)
-        outs, saved, meta = [None] * L, [], []
-        for K, idx in groups.items():
-            V = torch.cat([vs[i] for i in idx], 0) if len(idx) > 1 else vs[idx[0]]
-            G = torch.cat([gs[i] for i in idx], 0) if len(idx) > 1 else gs[idx[0]]
-            n = V.norm(dim=1, keepdim=True)
-            S = G / n
-            W = V * S
-            off = 0
-            for i in idx:
-                r = vs[i].shape[0]
-                outs[i] = W[off:off + r]
-                off += r
-            saved += [V, G, n, S]
-            meta.append(idx)
-        ctx.save_for_backward(*saved)
-        ctx.meta, ctx.rows = meta, [v.shape[0] for v in vs]
+        dev = vs[0].device
+        assert L <= 16 and all(v.is_cuda and v.is_contiguous() and v.dtype == torch.float32 for v in vs), \
+            "weight normalisation runs on the HIP kernels only (hold_amd has no CPU path)"
+        sizes = [(v.numel() + 63) // 64 * 64 for v in vs]
+        flat = torch.empty(sum(sizes), device=dev)  # every effective matrix 256-byte aligned in ONE allocation
+        outs, off = [], 0
+        d = _lib.WnDesc()
+        d.n_layers, d.accumulate = L, 0
+        for i, (v, g) in enumerate(zip(vs, gs)):
+            w = flat[off:off + v.numel()].view(v.shape)
+            off += sizes[i]
+            outs.append(w)
+            l = d.layers[i]
+            l.v, l.g, l.w = v.data_ptr(), g.data_ptr(), w.data_ptr()
+            l.rows, l.cols, l.ldv, l.ldw = v.shape[0], v.shape[1], v.shape[1], v.shape[1]
+        _lib.call("hold_weight_norm_fwd", C.byref(d))
+        ctx.save_for_backward(*vs, *gs)
+        ctx.L = L
+        ctx.set_materialize_grads(False)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *dW):
-        L = len(ctx.rows)
-        dv, dg = [None] * L, [None] * L
+        from . import _lib
+        L = ctx.L
         sv = ctx.saved_tensors
-        for gi, idx in enumerate(ctx.meta):
-            V, G, n, S = sv[4 * gi:4 * gi + 4]
-            parts = [dW[i] if dW[i] is not None else torch.zeros(ctx.rows[i], V.shape[1], device=V.device) for i in idx]
-            D = torch.cat(parts, 0) if len(parts) > 1 else parts[0]
-            t = (D * V).sum(1, keepdim=True)
-            dG = t / n
-            dV = D * S - V * (t * G / (n * n * n))
-            off = 0
-            for i in idx:
-                r = ctx.rows[i]
-                dv[i], dg[i] = dV[off:off + r], dG[off:off + r]
-                off += r
+        vs, gs = sv[:L], sv[L:]
+        direct = [dW[i] is not None and getattr(vs[i], "_hold_bucket", False) and vs[i].grad is not None
+                  and getattr(gs[i], "_hold_bucket", False) and gs[i].grad is not None for i in range(L)]
+        dv, dg = [None] * L, [None] * L
+        for mode in (True, False):  # one launch for the layers accumulated in place, one for those returned to autograd
+            idx = [i for i in range(L) if dW[i] is not None and direct[i] == mode]
+            if not idx:
+                continue
+            d = _lib.WnDesc()
+            d.n_layers, d.accumulate = len(idx), int(mode)
+            if not mode:  # results carved out of one allocation, 256-byte aligned pieces
+                sizes = [(vs[i].numel() + 63) // 64 * 64 for i in idx]
+                flat = torch.empty(sum(sizes) + sum((vs[i].shape[0] + 63) // 64 * 64 for i in idx), device=vs[0].device)
+                off = 0
+            for j, i in enumerate(idx):
+                v, g, D = vs[i], gs[i], dW[i].contiguous()
+                l = d.layers[j]
+                if mode:
+                    tv, tg = v.grad, g.grad
+                else:
+                    tv = flat[off:off + v.numel()].view(v.shape)
+                    off += sizes[j]
+                    tg = flat[off:off + v.shape[0]].view(g.shape)
+                    off += (v.shape[0] + 63) // 64 * 64
+                    dv[i], dg[i] = tv, tg
+                assert tv.is_contiguous() and tg.is_contiguous()
+                l.v, l.g, l.dw, l.dv, l.dg = v.data_ptr(), g.data_ptr(), D.data_ptr(), tv.data_ptr(), tg.data_ptr()
+                l.rows, l.cols, l.ldv, l.ldw = v.shape[0], v.shape[1], v.shape[1], v.shape[1]
+            _lib.call("hold_weight_norm_bwd", C.byref(d))
         return (None, *dv, *dg)
 
 
@@ -260,7 +292,7 @@ class ImplicitNet(nn.Module):
         xc[:, :3] = x
         out = torch.empty(P, 1, device=x.device)
         wpack, bias8 = pk["fused"]
-        K.fused_sdf(xc, P, wpack, bias8, pk["w8_sdf"], pk["b8_sdf_f"], self.embedder_obj.weights(x.device), out)
+        K.fused_sdf(xc, P, wpack, bias8, pk["w8_sdf"], float(pk["b8_sdf"]), self.embedder_obj.weights(x.device), out)
         return out.view(P)
 
     def gradient(self, x, cond=None):
@@ -298,6 +330,14 @@ class LaplaceDensity(nn.Module):
 
     def get_beta(self):
         return self.beta.abs() + self.beta_min
+
+    def beta_host(self):
+        """the value of get_beta() as a Python float (kernel scalar arguments, the sampler's convergence test): ONE device
+        read per parameter update instead of one per use -- every read drains the stream"""
+        key = (config.weights_epoch(), self.beta._version, self.beta.data_ptr())
+        if getattr(self, "_host", (None, None))[0] != key:
+            self._host = (key, float(self.beta.detach().abs() + self.beta_min))
+        return self._host[1]
 
 
 class GenericParams(nn.Module):
@@ -455,11 +495,11 @@ class _ImplicitFn(torch.autograd.Function):
 
 class _CompositeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, S, n_rays, class_ids, want_w, *args):
+    def forward(ctx, S, n_rays, class_ids, want_w, betas, *args):
         n = len(class_ids)
         z, sdf, color, normal, beta = (args[i * n:(i + 1) * n] for i in range(5))
         dev = sdf[0].device
-        betas = [float(b) for b in beta]
+        betas = [float(b) for b in (beta if betas is None else betas)]  # host values of `beta` (kernel scalars)
         sdf = [s.contiguous() for s in sdf]
         color = [c if c.stride(-1) == 1 else c.contiguous() for c in color]
         normal = [c if c.stride(-1) == 1 else c.contiguous() for c in normal]
@@ -497,7 +537,7 @@ class _CompositeFn(torch.autograd.Function):
         d_beta = torch.zeros(3, device=dev)
         K.composite_bwd(d, d_node, d_comp, d_sem, d_sdf, d_color, d_normal, d_beta)
         d_sdf = [t.view(-1) for t in d_sdf]
-        return (None, None, None, None, *([None] * n), *d_sdf, *d_color, *d_normal, *[d_beta[i] for i in range(n)])
+        return (None, None, None, None, None, *([None] * n), *d_sdf, *d_color, *d_normal, *[d_beta[i] for i in range(n)])
 
 
 class _BackgroundFn(torch.autograd.Function):
@@ -564,7 +604,7 @@ class Node(nn.Module):
     def _gradient_samples(self, sampler, centers, num, local_sigma, global_ratio):
         """compute_gradient_samples (volsdf_utils.py:19-48): randperm(V)[:num] centres (CPU generator, as the
         reference), one Gaussian copy each + global_ratio * num uniform box samples -> d sdf / d x with graph."""
-        idx = torch.randperm(centers.shape[1])[:num].to(centers.device)
+        idx = _lib_h2d(torch.randperm(centers.shape[1])[:num], centers.device)
         sample = sampler.get_points(torch.index_select(centers, 1, idx), local_sigma=local_sigma,
                                     global_ratio=global_ratio)
         return sample, self.eikonal_grad(sample)
@@ -589,8 +629,10 @@ class Node(nn.Module):
         # step, and every eval forward between optimiser steps, reuses it)
         key = _pack_key((self.implicit_network, self.rendering_network), training)
         if self._pk is None or self._pk_key != key:
-            with torch.no_grad():
-                self._pk = pack_weights(self.spec, weights[0:9], weights[9:18], weights[18:23], weights[23:28], training)
+            with torch.no_grad():  # the trunk's part is shared with ImplicitNet.forward / gradient (one re-layout per step)
+                trunk = self.implicit_network._pack(self.spec, weights[0:9], weights[9:18])
+                self._pk = pack_weights(self.spec, weights[0:9], weights[9:18], weights[18:23], weights[23:28], training,
+                                        trunk=trunk)
             self._pk_key = key
         # ---- sampler (no grad; sampler toggles net.eval()/train() in the reference, a no-op for these nets) ----
         if z_override is None:
@@ -602,7 +644,7 @@ class Node(nn.Module):
                 def sdf_query(x, P, out):
                     field.sdf_only(pk, x, P, P // tfs.shape[0], dfm, barf_w, out)
 
-                z_vals = self.ray_sampler.sample_z(sdf_query, ray_dirs, cam_loc, self.density.get_beta().item(),
+                z_vals = self.ray_sampler.sample_z(sdf_query, ray_dirs, cam_loc, self.density.beta_host(),
                                                    training, rng)
         else:
             z_vals = z_override.contiguous()
@@ -979,7 +1021,8 @@ class HOLDNet(nn.Module):
             S = fac[ids[0]]["z_vals"].shape[1]
             args = ([fac[i]["z_vals"] for i in ids] + [fac[i]["sdf"] for i in ids] + [fac[i]["color"] for i in ids] +
                     [fac[i]["normal"] for i in ids] + [self.nodes[i].density.get_beta() for i in ids])
-            res = _CompositeFn.apply(S, N, [self.nodes[i].class_id for i in ids], True, *args)
+            res = _CompositeFn.apply(S, N, [self.nodes[i].class_id for i in ids], True,
+                                     [self.nodes[i].density.beta_host() for i in ids], *args)
             comp, sem, w = res[0], res[1], res[2]
 
             def unpack(o, prefix, cls=None):

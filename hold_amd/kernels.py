@@ -96,7 +96,11 @@ def bg_points(cam_loc, ray_dirs, depth, S, R, out):
 
 
 def rowdot(A, w, K, b, P, out):
-    call("hold_rowdot", ptr(A), _ld(A), ptr(w), K, float(b), P, ptr(out), _ld(out))
+    """out[p] = A[p][:K] . w + b; b a Python float or a one-element device tensor (read by the kernel: no host copy)"""
+    if torch.is_tensor(b):
+        call("hold_rowdot", ptr(A), _ld(A), ptr(w), K, 0.0, ptr(b), P, ptr(out), _ld(out))
+    else:
+        call("hold_rowdot", ptr(A), _ld(A), ptr(w), K, float(b), None, P, ptr(out), _ld(out))
 
 
 def fused_sdf(xc, P, wpack, bias8, w8, b8, barf_w, out_sdf):
@@ -119,11 +123,13 @@ def fused_sdf_x6(xc, P, wpack_x6, bias8, w8, b8, barf_w, out_sdf):
 
 
 def fused_sdf_r6(xc, P, wpack_r6, bias8, w8, b8, barf_w, out_sdf):
-    """register-resident trunk (csrc/rmlp.hip) with the contract of fused_sdf_x6; wpack_r6 from field.pack_r6."""
+    """register-resident trunk (csrc/rmlp.hip) with the contract of fused_sdf_x6; wpack_r6 from field.pack_r6; b8 = a
+    one-element DEVICE tensor (the kernel reads the scalar itself)."""
     assert wpack_r6.numel() * wpack_r6.element_size() == _lib.lib().hold_trunk_r6_pack_bytes()
+    assert b8.is_cuda and b8.numel() == 1 and b8.dtype == torch.float32
     from . import gemm as _g
     e0 = _g._prof_begin()
-    call("hold_fused_sdf_r6", ptr(xc), _ld(xc), P, ptr(wpack_r6), ptr(bias8), ptr(w8), float(b8), ptr(barf_w),
+    call("hold_fused_sdf_r6", ptr(xc), _ld(xc), P, ptr(wpack_r6), ptr(bias8), ptr(w8), ptr(b8), ptr(barf_w),
          ptr(out_sdf), _ld(out_sdf))
     _g._prof_end(e0, 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256), "fused_sdf_kernel")
 

@@ -87,6 +87,7 @@ class _ManoLbsFn(torch.autograd.Function):
                   _lib.ptr(tfs), _lib.ptr(v_posed))
         ctx.mm, ctx.args, ctx.keep = mm, args, (hl, server)
         ctx.mark_non_differentiable(v_posed)
+        ctx.set_materialize_grads(False)  # unused outputs arrive as None in backward: no zero fill, no device read to test
         return verts, jnts, tfs, v_posed
 
     @staticmethod
@@ -168,19 +169,40 @@ class MANOServer(nn.Module):
         return self.forward(get("scene_scale").view(-1).repeat(B), get("transl"), full_pose, get("betas").repeat(B, 1))
 
 
+_Q2M = {}
+
+
+def _q2m_consts(device):
+    """constants of the quaternion -> matrix map as two gathers of the outer product q q^T (flattened [16], order r i j k):
+    entry e of the matrix = [e on the diagonal] + two_s * (sa[e] * qq[ia[e]] + sb[e] * qq[ib[e]])"""
+    key = str(device)
+    if key not in _Q2M:
+        r, i, j, k = 0, 1, 2, 3
+        P = lambda a, b: 4 * a + b
+        terms = [((j, j, -1.0), (k, k, -1.0)), ((i, j, 1.0), (k, r, -1.0)), ((i, k, 1.0), (j, r, 1.0)),
+                 ((i, j, 1.0), (k, r, 1.0)), ((i, i, -1.0), (k, k, -1.0)), ((j, k, 1.0), (i, r, -1.0)),
+                 ((i, k, 1.0), (j, r, -1.0)), ((j, k, 1.0), (i, r, 1.0)), ((i, i, -1.0), (j, j, -1.0))]
+        t = lambda v, dt: torch.tensor(v, dtype=dt, device=device)
+        _Q2M[key] = (t([P(a[0], a[1]) for a, _ in terms], torch.long), t([a[2] for a, _ in terms], torch.float32),
+                     t([P(b[0], b[1]) for _, b in terms], torch.long), t([b[2] for _, b in terms], torch.float32),
+                     t([1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0], torch.float32))
+    return _Q2M[key]
+
+
 def axis_angle_to_matrix(aa):
-    """common/rot.py:105-138,777-805."""
+    """common/rot.py:105-138,777-805 (axis-angle -> quaternion -> matrix).  The nine matrix entries are formed from two
+    gathers of q q^T instead of entry by entry: the same products and sums (bit-identical results), a dozen launches
+    instead of ~55 per call and direction."""
     angles = torch.norm(aa, p=2, dim=-1, keepdim=True)
     half = angles * 0.5
     small = angles.abs() < 1e-6
     soa = torch.where(small, 0.5 - (angles * angles) / 48,
                       torch.sin(half) / torch.where(small, torch.ones_like(angles), angles))
     q = torch.cat([torch.cos(half), aa * soa], -1)
-    r, i, j, k = torch.unbind(q, -1)
-    two_s = 2.0 / (q * q).sum(-1)
-    o = torch.stack((1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
-                     two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
-                     two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
+    two_s = 2.0 / (q * q).sum(-1, keepdim=True)
+    ia, sa, ib, sb, eye = _q2m_consts(aa.device)
+    qq = (q.unsqueeze(-1) * q.unsqueeze(-2)).reshape(q.shape[:-1] + (16,))
+    o = eye + two_s * (qq.index_select(-1, ia) * sa + qq.index_select(-1, ib) * sb)
     return o.reshape(q.shape[:-1] + (3, 3))
 
 
@@ -210,7 +232,9 @@ class ObjectModel(nn.Module):
         scene_scale = torch.ones(B, device=dev) if scene_scale is None else scene_scale.view(B).to(dev)
         R = axis_angle_to_matrix(rot.to(dev)).view(B, 3, 3)
         top = torch.cat([R, trans.to(dev).view(B, 3, 1)], 2)
-        bottom = torch.tensor([0.0, 0.0, 0.0, 1.0], device=dev, dtype=dt).view(1, 1, 4).expand(B, 1, 4)
+        if getattr(self, "_bottom", None) is None or self._bottom.device != dev or self._bottom.dtype != dt:
+            self._bottom = torch.tensor([0.0, 0.0, 0.0, 1.0], device=dev, dtype=dt).view(1, 1, 4)  # one upload, not one per call
+        bottom = self._bottom.expand(B, 1, 4)
         tf = torch.cat([top, bottom], 1)
         sm = torch.diag_embed(torch.cat([scene_scale[:, None].expand(B, 3), torch.ones(B, 1, device=dev)], 1))
         om = torch.diag(torch.cat([self.obj_scale.expand(3), torch.ones(1, device=dev)]))[None]

@@ -71,6 +71,9 @@ class FlatAdam:
                 self.flat[off:off + k].copy_(p.reshape(-1))
                 p.data = self.flat[off:off + k].view(p.shape)
                 p.grad = self.grad[off:off + k].view(p.shape)
+                # backward kernels that produce a parameter's gradient may ADD it into p.grad themselves instead of
+                # returning it to autograd (hold_net._WeightNormFn): one launch for a whole net, no AccumulateGrad per tensor
+                p._hold_bucket = True
         self.step_count = 0
 
     ALIGN = 64  # floats

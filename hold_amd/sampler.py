@@ -30,7 +30,8 @@ class UniformSampler:
             upper = torch.cat([mids, z[..., -1:]], -1)
             lower = torch.cat([z[..., :1], mids], -1)
             if t_rand is None:
-                t_rand = torch.rand(z.shape).to(dev)  # CPU generator, as the reference (:76)
+                from ._lib import h2d
+                t_rand = h2d(torch.rand(z.shape), dev)  # CPU generator, as the reference (:76)
             z = lower + (upper - lower) * t_rand
         return z
 
@@ -79,7 +80,8 @@ class ErrorBoundSampler:
 
     def _rand(self, shape, dev):
         if self.rng_device == "cpu":
-            return torch.rand(shape).to(dev)
+            from ._lib import h2d
+            return h2d(torch.rand(shape), dev)
         return torch.rand(shape, device=dev)
 
     def get_z_vals(self, sdf_fn, deformer, implicit_network, ray_dirs, cam_loc, density_fn, is_training, deform_info):
@@ -92,7 +94,8 @@ class ErrorBoundSampler:
         from .hold_net import ImplicitNet
         tfs = deform_info["tfs"]
         B = tfs.shape[0]
-        beta0 = density_fn.get_beta().item() if hasattr(density_fn, "get_beta") else float(density_fn)
+        beta0 = (density_fn.beta_host() if hasattr(density_fn, "beta_host") else
+                 density_fn.get_beta().item() if hasattr(density_fn, "get_beta") else float(density_fn))
         if sdf_fn is VU.sdf_func_with_deformer and isinstance(implicit_network, ImplicitNet):
             # fast path: KNN inverse LBS + the fused LDS-resident trunk, no [P,257] intermediate
             fld = implicit_network._field(ray_dirs.device, "sampler")
@@ -182,7 +185,9 @@ class ErrorBoundSampler:
                 idx = (perm(S) if callable(perm) else perm)[:nx]
             else:
                 idx = torch.linspace(0, S - 1, nx).long()
-            idx = idx.to(device=dev, dtype=torch.int32)
+            from ._lib import h2d
+            idx = idx.to(torch.int32)
+            idx = idx if idx.device == torch.device(dev) else h2d(idx, dev)
         else:
             idx = None
         out = torch.empty(N, ns + 2 + nx, device=dev)

@@ -160,9 +160,10 @@ int hold_copy_cols(const float* src, int32_t lds, float* dst, int32_t ldd, int32
 /* NeRF++ inverted-sphere re-parameterisation (background.py:102-135): out[p] = (unit xyz, 1/r) */
 int hold_bg_points(const float* cam_loc, const float* ray_dirs, const float* depth, int32_t S, int64_t n_rays, float R,
                    float* out, int32_t ldo, hold_stream_t stream);
-/* out[p] = A[p][:K] . w + b  (sdf-only last layer of ImplicitNet for the no-grad sampler queries) */
-int hold_rowdot(const float* A, int32_t lda, const float* w, int32_t K, float b, int64_t P, float* out, int32_t ldo,
-                hold_stream_t stream);
+/* out[p] = A[p][:K] . w + b (+ *b_dev when b_dev != NULL: a bias that is a trained parameter stays on the device)
+ * (sdf row of ImplicitNet's last layer) */
+int hold_rowdot(const float* A, int32_t lda, const float* w, int32_t K, float b, const float* b_dev, int64_t P, float* out,
+                int32_t ldo, hold_stream_t stream);
 /* t[p][n] = w[n] * softplus'(h[p][n]): seed of the d sdf/d x reverse sweep (volsdf_utils.py:89-96) */
 int hold_seed_dsp(const float* h, int32_t ldh, const float* w, int32_t N, int64_t P, float* t, int32_t ldt,
                   hold_stream_t stream);
@@ -317,13 +318,15 @@ int hold_fused_sdf_x6(const float* xc, int32_t ldx, int64_t P, const void* wpack
  *   k steps 3 + 16 (l - 1) + j, j = 0..15 = layer l = 1..7 (rows / scaling as for hold_fused_sdf):
  *                    limb_t(W_l)[32 nt + i][32 (j / 2) + 16 (j % 2) + 8 (e / 4) + 4 h + e % 4]
  *   (the order in which a lane holds the previous layer's outputs after v_mfma_f32_32x32x16_bf16).
- * hold_fused_sdf_r6: the contract of hold_fused_sdf_x6 (the sampler's SDF query).
+ * hold_fused_sdf_r6: the contract of hold_fused_sdf_x6 (the sampler's SDF query), except that b8 -- the bias of lin8's sdf
+ *   row, a trained parameter -- is read on the device (pointer to one float): a host copy costs the training step a
+ *   stream drain per node.
  * hold_trunk_r6: training forward, h[l] [P][ldh] (l = 0..7) = softplus outputs of lin0..lin7, columns 217..255 of h[3] =
  *   the embedding (skip concat); replaces embed + hold_chain_x6(SOFTPLUS) of the forward trunk.
  * ---------------------------------------------------------------------------------------- */
 int64_t hold_trunk_r6_pack_bytes(void);
 int hold_fused_sdf_r6(const float* xc, int32_t ldx, int64_t P, const void* wpack_r6, const float* bias, const float* w8,
-                      float b8, const float* barf_w, float* sdf, int32_t ld_sdf, hold_stream_t stream);
+                      const float* b8, const float* barf_w, float* sdf, int32_t ld_sdf, hold_stream_t stream);
 int hold_trunk_r6(const float* xc, int32_t ldx, int64_t P, const void* wpack_r6, const float* bias, const float* barf_w,
                   float* const* h, int32_t ldh, hold_stream_t stream);
 
@@ -377,6 +380,31 @@ int hold_chain_x6(const hold_chain_desc* d, hold_stream_t stream);
  * The ascending second-order sweep (mode DBWD) stays on hold_chain_x6: see the header of rchain.hip. */
 int64_t hold_chain_r6_pack_bytes(void);
 int hold_chain_r6(const hold_chain_desc* d, hold_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight normalisation of all layers of a net in one launch per direction (hold_amd/csrc/wnorm.hip): every Linear of
+ * ImplicitNet / RenderingNet is torch.nn.utils.weight_norm'ed (code/src/networks/shape_net.py:79-80, texture_net.py:40-41),
+ * w = v * (g / ||v||_row).  fwd: layers[l].w [rows][ldw] out.  bwd: dw in ([rows][ldw]; NULL = this layer received no
+ * gradient and is skipped), dv [rows][ldv] / dg [rows] out -- stored, or with accumulate != 0 ADDED (the optimiser's flat
+ * gradient bucket is written directly: no per-parameter accumulation launches).  t = <dw, v>, n = ||v||:
+ * dg = t / n, dv = dw g / n - v t g / n^3.
+ * ---------------------------------------------------------------------------------------- */
+#define HOLD_WN_MAX_LAYERS 16
+typedef struct {
+  const float* v;  /* [rows][ldv] direction parameter (weight_v) */
+  const float* g;  /* [rows] magnitude parameter (weight_g) */
+  float* w;        /* fwd out [rows][ldw] */
+  const float* dw; /* bwd in  [rows][ldw] or NULL */
+  float* dv;       /* bwd out [rows][ldv] */
+  float* dg;       /* bwd out [rows] */
+  int32_t rows, cols, ldv, ldw;
+} hold_wn_layer;
+typedef struct {
+  int32_t n_layers, accumulate;
+  hold_wn_layer layers[HOLD_WN_MAX_LAYERS];
+} hold_wn_desc;
+int hold_weight_norm_fwd(const hold_wn_desc* d, hold_stream_t stream);
+int hold_weight_norm_bwd(const hold_wn_desc* d, hold_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training loss-target geometry without kaolin (hold_amd/csrc/geometry.hip):

@@ -29,8 +29,9 @@ for P in PS:
     xc = torch.zeros(P, 4, device=dev); xc[:, :3] = torch.rand(P, 3, device=dev) * 1.6 - 0.8
     out = torch.empty(P, 1, device=dev); out2 = torch.empty(P, 1, device=dev)
     flops = 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256)
-    ms = timeit(lambda: K.fused_sdf_x6(xc, P, pk["fused_x6"], bias8, pk["w8_sdf"], pk["b8_sdf_f"], None, out))
-    ms2 = timeit(lambda: K.fused_sdf_r6(xc, P, pk["trunk_r6"], bias8, pk["w8_sdf"], pk["b8_sdf_f"], None, out2))
+    b8f = float(pk["b8_sdf"])
+    ms = timeit(lambda: K.fused_sdf_x6(xc, P, pk["fused_x6"], bias8, pk["w8_sdf"], b8f, None, out))
+    ms2 = timeit(lambda: K.fused_sdf_r6(xc, P, pk["trunk_r6"], bias8, pk["w8_sdf"], pk["b8_sdf"], None, out2))
     print(f"sdf query P={P}: x6p {ms:.3f} ms {flops / ms / 1e9:.1f} TF-eq | r6 {ms2:.3f} ms {flops / ms2 / 1e9:.1f} TF-eq | "
           f"max diff {float((out - out2).abs().max()):.2e}", flush=True)
     if P * 256 * 4 * 9 < 60e9:

@@ -51,8 +51,7 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool):
     pk["b"] = [b.contiguous() for b in ib[:8]] + [torch.cat([ib[8][1:], ib[8][:1]]).contiguous()]
     pk["iw0_cols"] = iw[0].shape[1]
     pk["w8_sdf"] = iw[8][0].contiguous()
-    pk["b8_sdf"] = ib[8][0]
-    pk["b8_sdf_f"] = float(ib[8][0])  # the one host read of a pack (kernel scalar argument)
+    pk["b8_sdf"] = ib[8][:1]
     pk["W8_feat"], pk["b8_feat"] = w8[:256], pk["b"][8][:256]  # lin8 without its sdf row (a 257th column costs a whole tile)
     # transposes [K_l][pad4(N_l)] for the sweeps that contract over the output index
     WT = []

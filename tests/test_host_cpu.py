@@ -215,30 +215,3 @@ def test_render_input_column_permutation_is_a_bijection_onto_the_reference_order
         back = torch.empty_like(g)
         back[:, perm] = g[:, perm][:, torch.arange(rin_dim)]
         assert torch.equal(back, g)
-
-
-def test_stacked_weight_norm_matches_per_layer_autograd():
-    """hold_net._effective_all (one autograd.Function for all weight-normed layers of a net) against the per-layer
-    v * (g / ||v||) graph: forward bit-identical, gradients to rounding"""
-    import torch
-    import torch.nn as nn
-    from hold_amd import hold_net as H
-    torch.manual_seed(0)
-    lins = [nn.utils.weight_norm(nn.Linear(k, n)) for n, k in [(256, 84), (256, 256), (217, 256), (257, 256), (3, 256)]]
-    lins.append(nn.Linear(8, 5))  # a plain layer passes through
-    with torch.no_grad():
-        for l in lins[:5]:
-            l.weight_g.mul_(torch.rand_like(l.weight_g) + 0.5)
-    ref, new = [H._eff(l) for l in lins], H._effective_all(lins)
-    assert all(torch.equal(a, b) for a, b in zip(ref, new))
-    cot = [torch.randn_like(r) for r in ref]
-    ps = [p for l in lins for p in l.parameters()]
-    g1 = torch.autograd.grad(sum((a * c).sum() for a, c in zip(ref, cot)), ps, allow_unused=True)
-    g2 = torch.autograd.grad(sum((a * c).sum() for a, c in zip(new[:4], cot[:4])), ps, allow_unused=True)  # one output unused
-    g3 = torch.autograd.grad(sum((a * c).sum() for a, c in zip(H._effective_all(lins), cot)), ps, allow_unused=True)
-    for a, b in zip(g1, g3):
-        assert (a is None) == (b is None)
-        if a is not None:
-            assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max() + 1e-12)
-    unused = [i for i, p_ in enumerate(ps) if p_ is lins[4].weight_v][0]
-    assert g2[unused] is not None and float(g2[unused].abs().max()) == 0.0  # an unused layer gets zero, not a wrong, gradient

@@ -66,7 +66,7 @@ def test_fused_sdf_r6_matches_fp64_and_x6(P, barf):
     xc = xc.to(dev)
     big = torch.full((P + 130, 1), 9.0, device=dev)
     out = big[:P]
-    K.fused_sdf_r6(xc, P, F.pack_r6(w0, S), bias, w8, 0.25, bw, out)
+    K.fused_sdf_r6(xc, P, F.pack_r6(w0, S), bias, w8, torch.full((1,), 0.25, device=xc.device), bw, out)
     torch.cuda.synchronize()
     assert torch.all(big[P:] == 9.0)
     hs = _ref(xc[:, :3], w0, S, bias, bw)
