@@ -599,7 +599,7 @@ template <int KT, int X6 = 0, int NBUF = 2>  // X6: 0 fp32 MFMA, 1 bf16 x 6 limb
 __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restrict__ R, int ldr,
                                                            const float* __restrict__ X, int ldx, int P, int N, int K,
                                                            int splits, float* __restrict__ part,
-                                                           float* __restrict__ part_b) {
+                                                           float* __restrict__ part_b, int remap) {
   constexpr int BKW = 64 * KT;              // block width along k
   constexpr int PC = (KT == 4) ? 16 : 32;   // rows (reduction index) per stage
   constexpr int STEPS = PC / 2;
@@ -613,7 +613,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restri
   const int wn = wave >> 1, wk = wave & 1;
   const int hh = lane >> 5, li = lane & 31;
   const int ntn = (N + 127) / 128, ntk = (K + BKW - 1) / BKW;
-  const int tile = blockIdx.x % (ntn * ntk), split = blockIdx.x / (ntn * ntk);
+  // blockIdx -> (tile, split).  The tiles of one split read the same rows of R / X (each its own columns of one operand,
+  // ALL columns of the other): workgroup b runs on XCD b % 8 and every XCD has its own L2, so the tiles of a split are
+  // numbered 8 apart -- same XCD, dispatched back to back -- and the shared operand comes out of that L2 for all tiles
+  // but the first instead of crossing the fabric once per tile (PMC, round 2: 1.5x the algorithmic bytes fetched).
+  const int T = ntn * ntk;
+  int tile = blockIdx.x % T, split = blockIdx.x / T;
+  if (remap) {
+    const int full = (splits / 8) * 8 * T;
+    if ((int)blockIdx.x < full) {
+      const int r = blockIdx.x % (8 * T);
+      tile = r / 8;
+      split = (blockIdx.x / (8 * T)) * 8 + (r % 8);
+    } else {
+      const int idx = blockIdx.x - full;
+      tile = idx % T;
+      split = (splits / 8) * 8 + idx / T;
+    }
+  }
   const int n0 = (tile / ntk) * 128, k0 = (tile % ntk) * BKW;
   const long chunks = ((long)P + PC - 1) / PC;
   const long cper = (chunks + splits - 1) / splits;
@@ -1076,6 +1093,10 @@ static int wgrad_impl(const float* R, int32_t ldr, const float* X, int32_t ldx, 
 #ifdef HOLD_DEV
   if (getenv("HOLD_WGRAD_DIRECT")) lds_ok = false;
 #endif
+  int remap = 1;
+#ifdef HOLD_DEV
+  if (const char* w = getenv("HOLD_WGRAD_REMAP")) remap = atoi(w);
+#endif
   bool x6_wide = K > 128;  // 128 n x 256 k tiles: 6 fragment splits per 48 MFMAs instead of 4 per 24
 #ifdef HOLD_DEV
   if (const char* w = getenv("HOLD_WGRAD_X6_TILE")) x6_wide = atoi(w) == 256;
@@ -1089,29 +1110,29 @@ static int wgrad_impl(const float* R, int32_t ldr, const float* X, int32_t ldx, 
     if (const char* nb = getenv("HOLD_WGRAD_NBUF")) deep = atoi(nb) == 3;
     if (deep)
       hipLaunchKernelGGL((wgrad_lds_kernel<4, 2, 3>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K,
-                         splits, part, part_b);
+                         splits, part, part_b, remap);
 #endif
     if (!deep)
       hipLaunchKernelGGL((wgrad_lds_kernel<4, 2>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits,
-                         part, part_b);
+                         part, part_b, remap);
   } else if (lds_ok && mode != 0) {  // split-precision path (128 x 128 tiles)
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
     if (mode == 2)
       hipLaunchKernelGGL((wgrad_lds_kernel<2, 2>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits,
-                         part, part_b);
+                         part, part_b, remap);
     else
       hipLaunchKernelGGL((wgrad_lds_kernel<2, 1>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits,
-                         part, part_b);
+                         part, part_b, remap);
   } else if (lds_ok && K > 128) {
     const int tiles = ((N + 127) / 128) * ((K + 255) / 256);
     const long ch = ((long)P + 15) / 16;
     if (splits > ch) splits = (int)(ch > 0 ? ch : 1);
     hipLaunchKernelGGL((wgrad_lds_kernel<4>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits,
-                       part, part_b);
+                       part, part_b, remap);
   } else if (lds_ok) {
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
     hipLaunchKernelGGL((wgrad_lds_kernel<2>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits,
-                       part, part_b);
+                       part, part_b, remap);
   } else {
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
     hipLaunchKernelGGL(wgrad_kernel, dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits, part,
