@@ -14,8 +14,10 @@
 // Skip layer (the 217 | 39 split of layer 3 -> 4): SOFTPLUS / DBWD take columns 217.. of the next input from the 40-wide
 // side matrix (embedding / its cotangent); DSP leaves the raw products (d / d embedding) in columns 217.. of its output.
 //
-// Roofline: fp32 MFMA (v_mfma_f32_32x32x2_f32); algorithmic HBM bytes per point and layer = 1 KiB per side input +
-// 1 KiB per stored result (2 KiB SOFTPLUS... see DESIGN.md), against 1 KiB more for the layer-by-layer GEMM.
+// Roofline: the MFMA pipe -- fp32 (v_mfma_f32_32x32x2_f32, 157 TFLOP/s) for hold_chain, bf16 (six limb products on
+// v_mfma_f32_32x32x16_bf16 per algorithmic product, 2.5 PFLOP/s) for hold_chain_x6; algorithmic HBM bytes per point and
+// layer = 1 KiB per side input + 1 KiB per stored result (SOFTPLUS 1, DSP 2, DSP + a2 3, DBWD 4 KiB),
+// against 1 KiB more for the layer-by-layer GEMM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
