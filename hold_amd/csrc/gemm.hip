@@ -1078,6 +1078,10 @@ extern "C" int64_t hold_wgrad_workspace_floats(int32_t N, int32_t K, int32_t spl
   return (int64_t)splits * ((int64_t)N * K + N);
 }
 
+// register-resident 256 x 256 variant (csrc/wgrad_r6.hip): fills <= max_splits partial tiles, returns their number
+int hold_wgrad_r6_partials(const float* R, int ldr, const float* X, int ldx, long P, int max_splits, float* part,
+                           float* part_b, hipStream_t s);
+
 // mode 0: fp32 MFMA; 1 / 2: split precision (3 bf16 limbs x 6 products, fp32 accumulate) with the round-to-nearest /
 // truncating limb split (both decompose the 24-bit significand exactly)
 static int wgrad_impl(const float* R, int32_t ldr, const float* X, int32_t ldx, int32_t P, int32_t N, int32_t K,
@@ -1101,7 +1105,15 @@ static int wgrad_impl(const float* R, int32_t ldr, const float* X, int32_t ldx, 
 #ifdef HOLD_DEV
   if (const char* w = getenv("HOLD_WGRAD_X6_TILE")) x6_wide = atoi(w) == 256;
 #endif
-  if (lds_ok && mode == 2 && x6_wide) {
+  bool r6 = lds_ok && mode == 2 && N == 256 && K == 256 && (P % 16) == 0 && P >= 4096;
+#ifdef HOLD_DEV
+  if (const char* w = getenv("HOLD_WGRAD_R6")) r6 = r6 && atoi(w) != 0;
+#endif
+  if (r6) {  // whole-dW workgroups, one wave per SIMD: each operand row read once, 3 VALU of limb split per MFMA
+    const int g = hold_wgrad_r6_partials(R, ldr, X, ldx, (long)P, splits, part, part_b, s);
+    if (g < 0) return g;
+    splits = g;
+  } else if (lds_ok && mode == 2 && x6_wide) {
     const int tiles = ((N + 127) / 128) * ((K + 255) / 256);
     const long ch = ((long)P + 15) / 16;
     if (splits > ch) splits = (int)(ch > 0 ? ch : 1);

@@ -1,0 +1,276 @@
+// Weight gradient of a 256 x 256 layer with the register-resident recipe of rmlp.hip (gfx950):
+//   part[g][n][k] = sum over workgroup g's points of R[p][n] X[p][k]      (+ part_b[g][n] = sum R[p][n])
+// ONE wave per SIMD; the four waves of a workgroup own the four 128 x 128 quadrants of the WHOLE dW (16 accumulator tiles =
+// 256 accumulator registers each), so every row of R and X crosses the fabric once (the 128 x 256 tiles of
+// wgrad_lds_kernel read X twice) and a fragment's limb split serves 24 MFMAs instead of 12 (3 VALU per MFMA, not 4.5).
+// Split-precision arithmetic of hold_wgrad_x6: both operands split exactly into three bf16 limbs (truncation), six limb
+// products on v_mfma_f32_32x32x16_bf16, fp32 accumulation.
+//
+// A step = 16 points.  Raw rows [16][256] of R and of X go to a 4-slot LDS ring by LDS-DMA (32 KiB per step, three steps
+// ahead; each wave requests eight 1 KiB rows, the 16-byte chunk index XOR-swizzled by the row half on the SOURCE address so
+// that the column reads of the two lane halves hit disjoint banks).  An MFMA operand fragment = one column, 8 consecutive
+// points per lane half: 8 ds_read_b32 + 36 VALU (split) per fragment, 8 fragments per wave and step, prepared for step
+// t + 1 behind the 96 MFMAs of step t with the explicit per-gap schedule of rmlp.hip (one MFMA, then a fixed slice of
+// reads / split micro-operations / DMA pieces, closed by a scheduling barrier); ONE workgroup barrier per step.
+// Roofline: bf16 MFMA pipe (6 limb products per algorithmic product); HBM 2 KiB per point (each operand row once).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hold_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int NST = 4;            // ring slots
+constexpr int STAGE = 32 * 1024;  // one step: R rows [16][256] fp32, then X rows [16][256]
+constexpr int LDS_BYTES = NST * STAGE;
+
+struct WArgs {
+  const float* R; int ldr;
+  const float* X; int ldx;
+  long nsteps;   // full 16-point steps (P / 16)
+  int spw;       // steps per workgroup
+  float* part;   // [G][256][256]
+  float* part_b; // [G][256] or null
+};
+
+__device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ float bitsf(uint32_t x) { return __builtin_bit_cast(float, x); }
+
+// one 1 KiB row piece: lane l fetches 16 bytes at src + voff(l), they land lane-linear at LDS byte dst (M0)
+__device__ __forceinline__ void dma_piece(const char* src, uint32_t voff, uint32_t dst) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1"
+      :
+      : "v"(voff), "s"(src), "s"(dst)
+      : "memory");
+}
+#define WG_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+struct Limbs8 { u32x4 l[8][3]; };  // fragments 0..3 = columns of R (MFMA A operand), 4..7 = columns of X (B operand)
+
+// state of one fragment while it is being split: the 8 raw values and the intermediate remainders, as 4 value pairs
+struct Frag { float x[8]; u32x2 r1[4], r2[4]; };
+
+// micro-operation k (0..35) of the truncation split of fragment f: operation k / 4 on value pair k % 4 (consecutive
+// micro-operations are independent).  Per pair: p1 = high halves of x; r1 = x - hi(x); p2 = high halves of r1;
+// r2 = r1 - hi(r1); p3 = high halves of r2.
+// Every result is made opaque (empty asm with a "+v" operand): pure VALU code has no side effects, so without the pin LLVM
+// sinks the whole split to its first use -- the next step's MFMAs -- instead of leaving it in the slices of this step.
+__device__ __forceinline__ void pin(uint32_t& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void split_mop(Frag& s, u32x4 (&out)[3], int k) {
+  const int op = k >> 2, j = k & 3;
+  const f32x2 v = {s.x[2 * j], s.x[2 * j + 1]};
+  const u32x2 xb = __builtin_bit_cast(u32x2, v);
+  uint32_t t0, t1;
+  if (op == 0) { t0 = __builtin_amdgcn_perm(xb[1], xb[0], 0x07060302u); pin(t0); out[0][j] = t0; }
+  else if (op == 1) { t0 = xb[0] & 0xffff0000u; pin(t0); s.r2[j][0] = t0; }
+  else if (op == 2) { t0 = xb[1] & 0xffff0000u; pin(t0); s.r2[j][1] = t0; }
+  else if (op == 3) {
+    const u32x2 r = __builtin_bit_cast(u32x2, v - __builtin_bit_cast(f32x2, s.r2[j]));
+    t0 = r[0]; t1 = r[1]; pin(t0); pin(t1);
+    s.r1[j][0] = t0; s.r1[j][1] = t1;
+  }
+  else if (op == 4) { t0 = __builtin_amdgcn_perm(s.r1[j][1], s.r1[j][0], 0x07060302u); pin(t0); out[1][j] = t0; }
+  else if (op == 5) { t0 = s.r1[j][0] & 0xffff0000u; pin(t0); s.r2[j][0] = t0; }
+  else if (op == 6) { t0 = s.r1[j][1] & 0xffff0000u; pin(t0); s.r2[j][1] = t0; }
+  else if (op == 7) {
+    const u32x2 r = __builtin_bit_cast(u32x2, __builtin_bit_cast(f32x2, s.r1[j]) - __builtin_bit_cast(f32x2, s.r2[j]));
+    t0 = r[0]; t1 = r[1]; pin(t0); pin(t1);
+    s.r2[j][0] = t0; s.r2[j][1] = t1;
+  }
+  else { t0 = __builtin_amdgcn_perm(s.r2[j][1], s.r2[j][0], 0x07060302u); pin(t0); out[2][j] = t0; }
+}
+
+// schedule of the preparation of step t + 1 behind the 96 MFMAs of step t: fragment f's reads occupy the gaps
+// [rs(f), rs(f) + 8), its 36 split micro-operations the window [ws(f), ws(f + 1)) -- three gaps behind its last read
+constexpr int rs(int f) { return 85 * f / 8; }
+constexpr int ws(int f) { return 11 + 85 * f / 8; }
+
+template <bool BIAS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wgrad_r6_kernel(WArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, li = lane & 31;
+  const int wn = wave >> 1, wk = wave & 1;  // this wave's quadrant: rows n = 128 wn .., columns k = 128 wk ..
+  const long s0 = (long)blockIdx.x * a.spw;
+  const long s1 = s0 + a.spw < a.nsteps ? s0 + a.spw : a.nsteps;
+
+  // ---- LDS-DMA of this wave's eight rows of a step: waves 0, 1 -> R rows 0..7 / 8..15, waves 2, 3 -> X rows
+  const float* M = (wave >> 1) ? a.X : a.R;
+  const long ldm = (wave >> 1) ? a.ldx : a.ldr;
+  const uint32_t dvoff = (uint32_t)((lane ^ (8 * (wave & 1))) * 16);  // chunk swizzle: rows 8..15 swap 32-column halves
+  const long rowb = ldm * 4;                                            // bytes between rows
+  const char* mrow0 = reinterpret_cast<const char*>(M) + (wave & 1) * 8 * rowb;  // this wave's first row of step 0
+  const uint32_t dst0 = (uint32_t)((wave >> 1) * 16384 + (wave & 1) * 8 * 1024);
+  // rows of step u (beyond the range: the last step again, which keeps the vmcnt arithmetic uniform); p walks the rows
+  auto step_src = [&](long u) { return mrow0 + (u < s1 ? u : s1 - 1) * 16 * rowb; };
+  // ---- fragment reads: column c = 32 f' + li of the wave's 128 (f' = 0..3), rows 8 hh .. 8 hh + 7 of the 16; the row
+  // half's swizzle flips bit 5 of the column = bit 7 of the byte address, so fragment f' is an XOR of the base address
+  const uint32_t rdA = (uint32_t)((8 * hh) * 1024 + ((128 * wn + li) ^ (32 * hh)) * 4);
+  const uint32_t rdB = (uint32_t)(16384 + (8 * hh) * 1024 + ((128 * wk + li) ^ (32 * hh)) * 4);
+  auto frag_addr = [&](int f, uint32_t slot_base) {
+    return smem + slot_base + ((f < 4 ? rdA : rdB) ^ (uint32_t)((f & 3) << 7));
+  };
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum[2] = {0.f, 0.f};  // BIAS: column sums of the R fragments 2 wk, 2 wk + 1 of this wave's n range
+
+  if (s0 < s1) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const char* p = step_src(s0 + u);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dma_piece(p + i * rowb, dvoff, (uint32_t)((int)((s0 + u) % NST) * STAGE) + dst0 + i * 1024);
+    }
+    const char* dptr = step_src(s0 + 3);  // rows of the step requested during the running one
+    WG_WAIT_VM(16);
+    __builtin_amdgcn_s_barrier();
+
+    Limbs8 L0, L1;
+    Frag fs[2];
+    // column sums of R for the bias gradient: wave (wn, wk) keeps those of the fragments 2 wk, 2 wk + 1 -- branch-free (a
+    // wave-uniform 0 / 1 factor): a branch here would end the scheduling region and make the LDS wait counts pessimistic
+    // (and 0 for the rows prepared during the LAST step: they are the re-read of that step, not new points)
+    float sel[2] = {wk == 0 ? 1.f : 0.f, wk == 1 ? 1.f : 0.f};
+    auto bias_add = [&](int f, const Frag& s) {
+      if (BIAS && f < 4) {
+        const f32x2 p0 = {s.x[0], s.x[1]}, p1 = {s.x[2], s.x[3]}, p2 = {s.x[4], s.x[5]}, p3 = {s.x[6], s.x[7]};
+        const f32x2 q = (p0 + p1) + (p2 + p3);
+        bsum[f & 1] = fmaf(sel[f >> 1], q[0] + q[1], bsum[f & 1]);
+      }
+    };
+    {  // limbs of the first step (not overlapped)
+      const uint32_t sb = (uint32_t)((int)(s0 % NST) * STAGE);
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        const char* p = frag_addr(f, sb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fs[0].x[e] = *reinterpret_cast<const float*>(p + e * 1024);
+        bias_add(f, fs[0]);
+#pragma unroll
+        for (int k = 0; k < 36; ++k) split_mop(fs[0], L0.l[f], k);
+      }
+    }
+
+    // One step: 96 MFMAs on the limbs C of step t; behind each a slice of the preparation of step t + 1 into N.
+    auto step = [&](long t, Limbs8& C, Limbs8& N) {
+      WG_WAIT_VM(8);  // the rows of step t + 1 have landed (younger: the eight pieces of step t + 2)
+      __builtin_amdgcn_s_barrier();  // ... in every wave; and every wave is done reading the slot of step t
+      const uint32_t sb = (uint32_t)((int)((t + 1) % NST) * STAGE);
+      const uint32_t db = (uint32_t)((int)((t + 3) % NST) * STAGE) + dst0;
+      const char* p = dptr;
+      dptr = (t + 4 < s1) ? dptr + 16 * rowb : dptr;
+      if (BIAS && t + 1 >= s1) sel[0] = sel[1] = 0.f;
+#pragma unroll
+      for (int m = 0; m < 96; ++m) {
+        const int aa = m / 24, pr = (m % 24) / 4, bb = m % 4;  // four accumulators in rotation
+        const int il = (pr == 2 || pr == 3) ? 1 : (pr == 5 ? 2 : 0);  // (R limb, X limb): 00 01 10 11 02 20
+        const int jl = (pr == 1 || pr == 3) ? 1 : (pr == 4 ? 2 : 0);
+        acc[aa][bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, C.l[aa][il]),
+                                                              __builtin_bit_cast(bf16x8, C.l[4 + bb][jl]), acc[aa][bb], 0, 0, 0);
+        if (m % 12 == 5) {
+          dma_piece(p, dvoff, db + (m / 12) * 1024);
+          p += rowb;
+        }
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+          if (m >= rs(f) && m < rs(f) + 8) {
+            const int e = m - rs(f);
+            fs[f & 1].x[e] = *reinterpret_cast<const float*>(frag_addr(f, sb) + e * 1024);
+          }
+          const int w0 = ws(f), w1 = ws(f + 1) < 96 ? ws(f + 1) : 96, len = w1 - w0;
+          if (m >= w0 && m < w1) {
+            if (m == w0) bias_add(f, fs[f & 1]);
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+              const int k = 36 * (m - w0) / len + u;
+              if (k < 36 * (m - w0 + 1) / len) split_mop(fs[f & 1], N.l[f], k);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+
+    for (long t = s0; t < s1; t += 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) asm volatile("" : "+a"(acc[i][j][r]));  // the accumulators live in the AGPR half
+      step(t, L0, L1);
+      if (t + 1 < s1) step(t + 1, L1, L0);
+    }
+    WG_WAIT_VM(0);  // no LDS-DMA may still be in flight when the workgroup's LDS is released
+  }
+
+  // ---- partial sums of this workgroup: lane (hh, li) holds column k = 128 wk + 32 b + li, rows 8 g + 4 hh + r ----
+  float* out = a.part + (long)blockIdx.x * 65536;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = 128 * wn + 32 * i + 8 * (r >> 2) + 4 * hh + (r & 3);
+        out[n * 256 + 128 * wk + 32 * j + li] = acc[i][j][r];
+      }
+  if (BIAS) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float s = bsum[q] + __shfl_xor(bsum[q], 32);
+      if (hh == 0) a.part_b[(long)blockIdx.x * 256 + 128 * wn + 32 * (2 * wk + q) + li] = s;
+    }
+  }
+}
+
+}  // namespace
+
+// Called by hold_wgrad_x6 (gemm.hip) for N == K == 256, P a multiple of 16: fills part[G][256][256] (and part_b[G][256])
+// with G <= max_splits workgroup partials and returns G (< 0: error); the caller reduces them.
+int hold_wgrad_r6_partials(const float* R, int ldr, const float* X, int ldx, long P, int max_splits, float* part,
+                           float* part_b, hipStream_t s) {
+  static int n_cu = 0;
+  static bool attr_set = false;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return HOLD_E_LAUNCH;
+    n_cu = prop.multiProcessorCount;
+  }
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)wgrad_r6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+            hipSuccess ||
+        hipFuncSetAttribute((const void*)wgrad_r6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+            hipSuccess)
+      return HOLD_E_LAUNCH;
+    attr_set = true;
+  }
+  WArgs a;
+  a.R = R; a.ldr = ldr; a.X = X; a.ldx = ldx; a.nsteps = P / 16; a.part = part; a.part_b = part_b;
+  long G = n_cu < max_splits ? n_cu : max_splits;
+  if (G > a.nsteps) G = a.nsteps;
+  a.spw = (int)((a.nsteps + G - 1) / G);
+  G = (a.nsteps + a.spw - 1) / a.spw;  // every workgroup owns at least one step
+  if (part_b)
+    hipLaunchKernelGGL((wgrad_r6_kernel<true>), dim3((unsigned)G), dim3(256), LDS_BYTES, s, a);
+  else
+    hipLaunchKernelGGL((wgrad_r6_kernel<false>), dim3((unsigned)G), dim3(256), LDS_BYTES, s, a);
+  return hipGetLastError() == hipSuccess ? (int)G : HOLD_E_LAUNCH;
+}

@@ -102,6 +102,39 @@ def test_wgrad(P, N, K):
     assert ((db.double() - refb).abs().max() / refb.abs().max()).item() < 1e-5
 
 
+@pytest.mark.parametrize("P,ldr,ldx,bias", [(4096, 256, 256, True), (4144, 256, 256, False), (200000, 256, 256, True),
+                                            (65536 + 16, 304, 272, True)])
+def test_wgrad_256x256_whole_layer_workgroups(P, ldr, ldx, bias):
+    """the register-resident 256 x 256 weight gradient (csrc/wgrad_r6.hip: taken by hold_wgrad_x6 for N = K = 256 and P a
+    multiple of 16 >= 4096) against fp64 -- row strides wider than the matrix, with / without the bias sums, accumulate"""
+    import hold_amd
+    from hold_amd import gemm
+    if hold_amd.precision() != "f32x6":
+        pytest.skip("split-precision path")
+    dev = _dev()
+    torch.manual_seed(P)
+    Rb = torch.randn(P, ldr, device=dev)
+    Xb = torch.randn(P, ldx, device=dev)
+    R, X = Rb[:, :256], Xb[:, :256]
+    dW = torch.ones(256, 256, device=dev)
+    db = torch.ones(256, device=dev) if bias else None
+    gemm.wgrad(R, X, dW, db, accumulate=True)
+    ref = R.double().t() @ X.double() + 1
+    assert ((dW.double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
+    if bias:
+        refb = R.double().sum(0) + 1
+        assert ((db.double() - refb).abs().max() / refb.abs().max()).item() < 1e-5
+    # structured operands: a wrong row / column / limb pairing cannot hide behind random cancellation
+    R.zero_(); X.zero_()
+    R[:, 37] = 1.0
+    X[:, 201] = torch.arange(P, device=dev, dtype=torch.float32) % 7 + 0.123456789
+    dW2 = torch.empty(256, 256, device=dev)
+    gemm.wgrad(R, X, dW2, None)
+    ref2 = torch.zeros(256, 256, dtype=torch.float64)
+    ref2[37, 201] = float(X[:, 201].double().sum())
+    assert float((dW2.double().cpu() - ref2).abs().max()) < 1e-6 * ref2[37, 201]
+
+
 def test_fused_sdf_matches_layered_path():
     """hold_fused_sdf (LDS-resident 8-layer trunk) against the layer-by-layer GEMM path on the same weights."""
     import numpy as np
