@@ -188,6 +188,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
 
+    # stdout carries exactly ONE line, the JSON result of rank 0: native libraries write there too (RCCL prints a version
+    # banner to stdout when its communicator comes up), so file descriptor 1 is pointed at stderr for the run and the
+    # result goes out through a duplicate of the original descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     force_dist = os.environ.get("HOLD_FORCE_DIST") == "1"  # exercise the RCCL path with a single rank (testing)
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -511,7 +518,7 @@ def main():
         if not args.no_cpu_baseline and world == 1 and args.mode == "train" and not args.two_hands:
             res["cpu_baseline"] = cpu_baseline(sc, sd_np, args.cpu_threads)
             res["config"]["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
-        print(json.dumps(res))
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 
