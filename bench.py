@@ -449,11 +449,13 @@ def main():
                 a[2] += 1
             if args.shape_report:
                 json.dump(gemm_shapes(prof), open(args.shape_report, "w"), indent=1)
-            split = {"fused_sdf_kernel", "wgrad_kernel", "chain_kernel", "gemm_nt_kernel", "trunk_r6_kernel", "rchain_kernel"} if x6 else set()
+            split = {"fused_sdf_kernel", "wgrad_kernel", "chain_kernel", "gemm_nt_kernel", "trunk_r6_kernel", "rchain_kernel", "rgemm_kernel"} if x6 else set()
             labels = {"gemm_nt_kernel": ("gemm_nt_kernel<x6> (one layer per launch, 3-limb split on v_mfma_f32_32x32x16_bf16)"
                                          if x6 else "gemm_nt_kernel (one layer per launch, v_mfma_f32_32x32x2_f32)"),
                       "trunk_r6_kernel": "rmlp_kernel<STORE> (forward trunk, 8 layers per launch, register-resident, 3-limb split on "
                                          "v_mfma_f32_32x32x16_bf16)",
+                      "rgemm_kernel": "rgemm_kernel (rendering-net layers, their input gradients, lin8 features: one 256-wide layer "
+                                      "per launch, register-resident, 3-limb split on v_mfma_f32_32x32x16_bf16)",
                       "rchain_kernel": "rchain_kernel (descending sweep of the normal path, 7 layers per launch, register-resident, "
                                        "3-limb split on v_mfma_f32_32x32x16_bf16)",
                       "chain_kernel": ("chain_x6_kernel (first-order backward and second-order sweeps: 7-8 trunk layers per launch, "
@@ -462,7 +464,8 @@ def main():
                       "fused_sdf_kernel": ("rmlp_kernel<HEAD> (sampler SDF queries: register-resident trunk, 3-limb split on "
                                            "v_mfma_f32_32x32x16_bf16)"
                                            if x6 else "fused_sdf_pipe_kernel (sampler SDF queries, v_mfma_f32_32x32x2_f32)"),
-                      "wgrad_kernel": ("wgrad_lds_kernel<x6> (weight gradients, 3-limb split on v_mfma_f32_32x32x16_bf16)"
+                      "wgrad_kernel": ("wgrad_r6_kernel + wgrad_lds_kernel<x6> (weight gradients: whole-dW register-resident "
+                                       "workgroups for the 256x256 layers, LDS tiles otherwise; 3-limb split on v_mfma_f32_32x32x16_bf16)"
                                        if x6 else "wgrad_lds_kernel (weight gradients, v_mfma_f32_32x32x2_f32)")}
             ent = {}
             for name, (t_, fl_, n_) in agg.items():

@@ -124,6 +124,7 @@ SIGNATURES = {
     "hold_frame_bcast": [_P, _I, _L, _L, _P, _I, _I, _P],
     "hold_copy_cols": [_P, _I, _P, _I, _I, _L, _I, _P],
     "hold_bg_points": [_P, _P, _P, _I, _L, _F, _P, _I, _P],
+    "hold_gemm_r6": [_P, _I, _L, _P, _I, _P, _I, _P, _I, _P, _I, _P],
     "hold_weight_norm_fwd": [C.POINTER(WnDesc), _P],
     "hold_weight_norm_bwd": [C.POINTER(WnDesc), _P],
     "hold_rowdot": [_P, _I, _P, _I, _F, _P, _L, _P, _I, _P],
@@ -174,6 +175,8 @@ def _declare(L):
     L.hold_fused_sdf_pack_floats.restype = C.c_int64
     L.hold_fused_sdf_x6_pack_bytes.restype = C.c_int64
     L.hold_trunk_r6_pack_bytes.restype = C.c_int64
+    L.hold_gemm_r6_pack_bytes.restype = C.c_int64
+    L.hold_gemm_r6_pack_bytes.argtypes = [C.c_int32]
     L.hold_chain_r6_pack_bytes.restype = C.c_int64
     L.hold_chain_pack_floats.argtypes = [C.c_int32, C.c_int32]
     L.hold_chain_pack_floats.restype = C.c_int64

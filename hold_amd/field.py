@@ -31,6 +31,7 @@ USE_CHAIN = os.environ.get("HOLD_CHAIN", "1") != "0"
 # register-resident trunk (csrc/rmlp.hip) for the sampler queries and the training forward trunk (f32x6 arithmetic only)
 USE_R6 = os.environ.get("HOLD_R6", "1") != "0"
 USE_R6_BWD = os.environ.get("HOLD_R6_BWD", "1") != "0"  # ... and for the descending sweeps (csrc/rchain.hip)
+USE_R6_GEMM = os.environ.get("HOLD_R6_GEMM", "1") != "0"  # ... and for the rendering net's layers / lin8 (csrc/rgemm.hip)
 RIN_FEAT, RIN_X, RIN_N, RIN_POSE, RIN_TIME = 0, 256, 259, 262, 270
 
 
@@ -197,7 +198,49 @@ def pack_r6_stack(S):
     return _lay_r6_stack(torch.stack(split_limbs(S))).contiguous()
 
 
+def pack_gemm_r6(W):
+    """limb pack of hold_gemm_r6 (include/hold_hip.h) for one matrix W [N <= 256, K in 256..320]: K padded to KS = 4 ceil(K/64)
+    k steps, the k index in the register order of an accumulator tile (r6_kmap continued to KS steps)"""
+    N, K = W.shape
+    KS = (K + 63) // 64 * 4
+    m = torch.zeros(256, 16 * KS, device=W.device)
+    m[:N, :K] = W
+    return _lay_gemm_r6(torch.stack(split_limbs(m)), KS).contiguous()
+
+
+def _gemm_kmap(KS, device):
+    j = torch.arange(KS, device=device).view(KS, 1, 1)
+    h = torch.arange(2, device=device).view(1, 2, 1)
+    e = torch.arange(8, device=device).view(1, 1, 8)
+    return 16 * j + 8 * (e // 4) + 4 * h + e % 4
+
+
+def _lay_gemm_r6(l3, KS):
+    g = l3[:, :, _gemm_kmap(KS, l3.device)]  # [3 t, 256 out, KS j, 2 h, 8 e]
+    return g.reshape(3, 8, 32, KS, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(-1)
+
+
 _PLANS = {}
+_RPLANS = {}
+
+
+def render_plan(Kr, need_bwd, device):
+    """gather indices of the hold_gemm_r6 packs of the rendering net from the flat source
+    [R0 zero-padded to [256, 320] | R1 | R2 | R3 (| R1^T | R2^T | R3^T)] (see pack_plan)"""
+    key = (Kr, bool(need_bwd), str(device))
+    if key not in _RPLANS:
+        n0 = 256 * 320
+        nm = 6 if need_bwd else 3
+        N = n0 + nm * 65536
+        l3 = lambda I: torch.stack([I + t * N for t in range(3)])
+        I0 = torch.arange(n0, device=device).view(256, 320)
+        parts = [_lay_gemm_r6(l3(I0), 20)]
+        for q in range(nm):
+            parts.append(_lay_gemm_r6(l3(n0 + q * 65536 + torch.arange(65536, device=device).view(256, 256)), 16))
+        _RPLANS[key] = dict(N=N, idx=torch.cat(parts).to(torch.int32).contiguous(),
+                            sizes=[p.numel() for p in parts])
+    return _RPLANS[key]
+
 
 
 def pack_plan(K0, device):
@@ -212,6 +255,8 @@ def pack_plan(K0, device):
         N = n0 + ns
         I0 = torch.arange(n0, device=device).view(256, 48)
         IS = n0 + torch.arange(ns, device=device).view(7, 256, 256)
+        I8 = n0 + ns + torch.arange(65536, device=device).view(256, 256)  # lin8's 256 feature rows (appended to the source)
+        N += 65536
         ISTf = IS.transpose(1, 2).flip(0)  # descending sweeps: layer j = W_{7-j}^T
         l3 = lambda I: torch.stack([I + t * N for t in range(3)])
         i32 = lambda t: t.to(torch.int32).contiguous()
@@ -223,7 +268,8 @@ def pack_plan(K0, device):
             fused_x6=i32(torch.cat([_lay_x6(l3(I0), 48), _lay_x6_stack(l3(IS))])),
             trunk_r6=i32(torch.cat([_lay_r6_0(l3(I0)), _lay_r6_stack(l3(IS))])),
             chain_bwd_x6=i32(_lay_x6_stack(l3(ISTf))),
-            chain_bwd_r6=i32(_lay_r6_stack(l3(ISTf))))
+            chain_bwd_r6=i32(_lay_r6_stack(l3(ISTf))),
+            w8_feat_r6=i32(_lay_gemm_r6(l3(I8), 16)))
     return _PLANS[key]
 
 
@@ -269,7 +315,7 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool, trunk=None):
     # every fragment / limb pack = one gather from the flat source (pack_plan); the descending sweeps' matrices
     # (hold_chain DSP: layer j contracts over the outputs of trunk layer l = 7 - j, M_j = W_l^T) come from the same source
     plan = pack_plan(spec.K0, dev)
-    src = torch.cat([torch.nn.functional.pad(w0, (0, 48 - spec.K0)).reshape(-1), S.reshape(-1)])
+    src = torch.cat([torch.nn.functional.pad(w0, (0, 48 - spec.K0)).reshape(-1), S.reshape(-1), w8[:256].reshape(-1)])
     pk["fused"] = (src.index_select(0, plan["fused"]), bias8)
     pk["chain_bwd"] = src.index_select(0, plan["chain_bwd"])
     if config.x6():  # limb packs (the forward-type sweeps of hold_chain_x6 share the sampler trunk's)
@@ -279,6 +325,7 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool, trunk=None):
         pk["chain_fwd_x6"] = pk["fused_x6"]
         pk["chain_bwd_x6"] = limbs.index_select(0, plan["chain_bwd_x6"])
         pk["chain_bwd_r6"] = limbs.index_select(0, plan["chain_bwd_r6"])
+        pk["w8_feat_r6"] = limbs.index_select(0, plan["w8_feat_r6"])  # hold_gemm_r6 pack of lin8's feature rows
     if rw is None:  # implicit net only (ImplicitNet.forward / gradient)
         return pk
     return _pack_render(pk, spec, rw, rb, need_bwd, dev)
@@ -293,6 +340,16 @@ def _pack_render(pk, spec, rw, rb, need_bwd, dev):
     if need_bwd:
         RT123 = torch.stack(R[1:4]).transpose(1, 2).contiguous()
         pk["RT"] = [r0.t().contiguous(), RT123[0], RT123[1], RT123[2], None]  # the head's input gradient: hold_head3_bwd
+    if config.x6() and spec.Kr <= 320 and spec.Kr % 16 == 0:  # hold_gemm_r6 packs: lin0..3 (and lin1..3 transposed), one gather
+        plan = render_plan(spec.Kr, need_bwd, dev)
+        mats = [torch.nn.functional.pad(r0, (0, 320 - spec.Kr)).reshape(-1), R[1].reshape(-1), R[2].reshape(-1), R[3].reshape(-1)]
+        if need_bwd:
+            mats.append(RT123.reshape(-1))
+        limbs = torch.stack(split_limbs(torch.cat(mats))).reshape(-1)
+        packs = limbs.index_select(0, plan["idx"]).split(plan["sizes"])
+        pk["R_r6"] = list(packs[:4])
+        if need_bwd:
+            pk["RT_r6"] = [None] + list(packs[4:7])
     return pk
 
 
@@ -396,7 +453,10 @@ class NodeField:
         rin = pool.get("rin", P, sp.Kr)
         sdf = pool.get("sdf", P, 1)
         # lin8 = 256 feature rows as a full-tile GEMM + the sdf row as a row dot (N = 257 would add a 256-wide tile for it)
-        G.gemm_nt(h[7], pk["W8_feat"], rin[:, RIN_FEAT:RIN_FEAT + FEAT], bias=pk["b8_feat"], N=256)
+        if USE_R6_GEMM and "w8_feat_r6" in pk:
+            G.gemm_r6(h[7], pk["w8_feat_r6"], rin[:, RIN_FEAT:RIN_FEAT + FEAT], K=256, bias=pk["b8_feat"])
+        else:
+            G.gemm_nt(h[7], pk["W8_feat"], rin[:, RIN_FEAT:RIN_FEAT + FEAT], bias=pk["b8_feat"], N=256)
         K.rowdot(h[7], pk["w8_sdf"], 256, pk["b8_sdf"], P, sdf)
         # ---- reverse sweep: t_l = d sdf / d a_l, ge = d sdf / d embed, g = d sdf / d xc ----
         WT = pk["WT"]
@@ -420,10 +480,15 @@ class NodeField:
         # ---- rendering net ----
         R, rb = pk["R"], pk["rb"]
         r = [pool.get(f"r{l}", P, 256) for l in range(4)]
-        G.gemm_nt(rin, R[0], r[0], bias=rb[0], epi=G.EPI_RELU, K=sp.Kr)
-        G.gemm_nt(r[0], R[1], r[1], bias=rb[1], epi=G.EPI_RELU)
-        G.gemm_nt(r[1], R[2], r[2], bias=rb[2], epi=G.EPI_RELU)
-        G.gemm_nt(r[2], R[3], r[3], bias=rb[3], epi=G.EPI_RELU)
+        if USE_R6_GEMM and "R_r6" in pk:
+            G.gemm_r6(rin, pk["R_r6"][0], r[0], K=sp.Kr, bias=rb[0], epi=G.R6_RELU)
+            for l in (1, 2, 3):
+                G.gemm_r6(r[l - 1], pk["R_r6"][l], r[l], K=256, bias=rb[l], epi=G.R6_RELU)
+        else:
+            G.gemm_nt(rin, R[0], r[0], bias=rb[0], epi=G.EPI_RELU, K=sp.Kr)
+            G.gemm_nt(r[0], R[1], r[1], bias=rb[1], epi=G.EPI_RELU)
+            G.gemm_nt(r[1], R[2], r[2], bias=rb[2], epi=G.EPI_RELU)
+            G.gemm_nt(r[2], R[3], r[3], bias=rb[3], epi=G.EPI_RELU)
         rgb = pool.get("rgb", P, 4)
         G.head3_fwd(r[3], R[4], rb[4], rgb)  # 3-output head: a streaming kernel, not a 3/256-full GEMM tile
         self.saved = dict(P=P, ppf=ppf, xc=xc, w_def=w_def, w_c=w_c, in0=in0, h=h, t=t, ge=ge, g=g, rin=rin, r=r,
@@ -613,7 +678,10 @@ class NodeField:
         for l in (3, 2, 1):
             G.wgrad(cur, r[l - 1], dR[l], dRb[l])
             nxt = rr[0] if cur is rr[1] else rr[1]
-            G.gemm_nt(cur, RT[l], nxt, epi=G.EPI_MUL_DRELU, aux1=r[l - 1])
+            if USE_R6_GEMM and "RT_r6" in pk:
+                G.gemm_r6(cur, pk["RT_r6"][l], nxt, K=256, epi=G.R6_MASK, aux=r[l - 1])
+            else:
+                G.gemm_nt(cur, RT[l], nxt, epi=G.EPI_MUL_DRELU, aux1=r[l - 1])
             cur = nxt
         G.wgrad(cur, rin, dR[0], dRb[0], K=sp.Kr)
         d_rin = pool.get("d_rin", P, sp.Kr)

@@ -36,6 +36,26 @@ def _ld(t):
     return t.stride(0)
 
 
+R6_NONE, R6_RELU, R6_MASK = 0, 1, 2
+
+
+def gemm_r6(A, wpack, out, *, K, bias=None, epi=R6_NONE, aux=None):
+    """out[:, :256] = epi(A[:, :K] @ W.T + bias) with the register-resident kernel (hold_gemm_r6, csrc/rgemm.hip); wpack from
+    field.pack_gemm_r6(W).  epi: R6_NONE, R6_RELU, R6_MASK (out = y * (aux > 0), no bias).  Split-precision arithmetic."""
+    P = A.shape[0]
+    L = _lib.lib()
+    assert wpack.numel() * wpack.element_size() == L.hold_gemm_r6_pack_bytes(K), (wpack.shape, K)
+    ldmax = max(_ld(A), _ld(out), _ld(aux) if aux is not None else 0)
+    rows = max(128, ((1 << 32) // (4 * ldmax) - 256) // 128 * 128)  # 32-bit offsets inside the kernel: split by rows
+    e0 = _prof_begin()
+    for r0 in range(0, P, rows):
+        n = min(P, r0 + rows) - r0
+        check(L.hold_gemm_r6(ptr(A[r0:]), _ld(A), n, ptr(wpack), K, ptr(bias), int(epi), ptr(None if aux is None else aux[r0:]),
+                             0 if aux is None else _ld(aux), ptr(out[r0:]), _ld(out), stream_ptr()), "hold_gemm_r6")
+    _prof_end(e0, 2.0 * P * 256 * K, "rgemm_kernel")
+    return out
+
+
 def gemm_nt(A, W, out, *, bias=None, epi=EPI_NONE, alpha=1.0, N=None, K=None, n_split=None, out_raw=None,
             aux1=None, aux2=None, out2=None, accumulate=False, r1_row=None, r1_col=None):
     """out[:, :N] = epi(alpha * A[:, :K] @ W[:N, :K].T + bias).  All tensors are 2-D fp32 CUDA views with unit

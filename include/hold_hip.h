@@ -382,6 +382,19 @@ int64_t hold_chain_r6_pack_bytes(void);
 int hold_chain_r6(const hold_chain_desc* d, hold_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * One 256-wide layer with the register-resident structure (hold_amd/csrc/rgemm.hip): the rendering net's layers
+ * (code/src/networks/texture_net.py:95-101), their input gradients and lin8's feature rows (shape_net.py:128-130) --
+ * C[P][256] (row stride ldc) = epi(A[P][K] . W^T + bias), epilogue 0 none, 1 ReLU, 2 multiply by (aux > 0) (no bias);
+ * arithmetic of hold_gemm_nt_x6.  K a multiple of 16 in 256 .. 320.
+ * wpack: hold_gemm_r6_pack_bytes(K) bytes of bf16, [KS k steps j][8 n-tiles nt][3 limbs t][2 halves h][32 rows i][8 e] =
+ *   limb_t(W)[32 nt + i][16 j + 8 (e / 4) + 4 h + e % 4], KS = 4 ceil(K / 64), zero for columns >= K and rows >= N.
+ * 32-bit offsets: P * max(lda, ldc, ld_aux) * 4 < 2^32 (the caller splits by rows).
+ * ---------------------------------------------------------------------------------------- */
+int64_t hold_gemm_r6_pack_bytes(int32_t K);
+int hold_gemm_r6(const float* A, int32_t lda, int64_t P, const void* wpack, int32_t K, const float* bias, int32_t epilogue,
+                 const float* aux, int32_t ld_aux, float* C, int32_t ldc, hold_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Weight normalisation of all layers of a net in one launch per direction (hold_amd/csrc/wnorm.hip): every Linear of
  * ImplicitNet / RenderingNet is torch.nn.utils.weight_norm'ed (code/src/networks/shape_net.py:79-80, texture_net.py:40-41),
  * w = v * (g / ||v||_row).  fwd: layers[l].w [rows][ldw] out.  bwd: dw in ([rows][ldw]; NULL = this layer received no

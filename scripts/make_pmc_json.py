@@ -11,19 +11,21 @@ W = json.load(open(os.path.join(src, "WRITE_SIZE.json")))
 # <STORE>: the counter CSV keys carry no template arguments, so its traffic is reported under its own entry too)
 groups = {"fused_sdf_kernel": ["rmlp_kernel<true,false,0>", "fused_sdf_x6p_kernel", "fused_sdf_pipe_kernel", "fused_sdf_kernel"],
           "trunk_r6_kernel": ["rmlp_kernel<false,true,0>"],
-          "rchain_kernel": ["rchain_kernel<false>", "rchain_kernel<true>"],
+          "rchain_kernel": ["rchain_kernel<false,0>", "rchain_kernel<true,0>", "rchain_kernel<false>", "rchain_kernel<true>"],
+          "rgemm_kernel": ["rgemm_kernel<0>", "rgemm_kernel<1>", "rgemm_kernel<2>"],
           "chain_kernel": ["chain_x6_kernel<1,true,16>", "chain_x6_kernel<2,true,3>", "chain_x6_kernel<1,false,16>",
                            "chain_x6_kernel<0,false,3>", "chain_kernel"],
           "sampler_beta_kernel": ["sampler_beta_kernel"], "sampler_sample_kernel": ["sampler_sample_kernel"],
           "composite_fwd_kernel": ["composite_fwd_kernel"], "composite_bwd_kernel": ["composite_bwd_kernel"],
           "gemm_nt_kernel": ["gemm_nt_kernel"],
-          "wgrad_kernel": ["wgrad_lds_kernel", "wgrad_kernel"]}
+          "wgrad_kernel": ["wgrad_r6_kernel<true>", "wgrad_r6_kernel<false>", "wgrad_r6_kernel", "wgrad_lds_kernel", "wgrad_kernel"]}
 notes = {
     "fused_sdf_kernel": "sampler queries: 16 B in (xc row) + 4 B out per point; the 2.8 MiB limb pack stays in L2",
     "chain_kernel": "hold_chain_x6: the first-order backward sweep (DSP + a2: reads 2 + writes 1 KiB per point and layer, 7 layers) and "
                     "the second-order sweep (DBWD: reads 2 + writes 2 KiB, 8 layers) of one node-chunk (P = 1.61 M points)",
     "trunk_r6_kernel": "forward trunk: 16 B in per point, 8 x 1 KiB of h stores out",
     "rchain_kernel": "descending sweep of the normal path: 1 KiB in (chain input) + per layer 1 KiB side in, 1 KiB out, 7 layers",
+    "rgemm_kernel": "rendering-net layers / dgrad / lin8 features: 4 (K + 256) B per point (+ 1 KiB mask operand)",
     "gemm_nt_kernel": "per-layer GEMMs (rendering net fwd+bwd, lin8 features, d/d embedding, background): (K + N) * 4 B per "
                       "point (+ N * 4 B per aux operand of the MUL_DSP / DRELU epilogues)",
     "wgrad_kernel": "dW[N,K] = R^T X over P = 1.61 M points: (N + K) * 4 B per point = 2 KiB (3.3 GB) for the 256x256 layers; "

@@ -21,7 +21,7 @@ if f:
         nm = r["Kernel_Name"].replace("void ", "")
         m = re.search(r"(?:anonymous namespace\)::)?(\w+)(<[^>]*>)?(?:\()", nm)
         k = m.group(1) if m else nm[:40]
-        if m and m.group(2) and k in ("rmlp_kernel", "rchain_kernel", "chain_x6_kernel"):
+        if m and m.group(2) and k in ("rmlp_kernel", "rchain_kernel", "chain_x6_kernel", "rgemm_kernel", "wgrad_r6_kernel"):
             k += m.group(2).replace(" ", "")  # instantiations of the trunk kernels are different sweeps
         agg[k][0] += 1
         agg[k][1] += float(r["Counter_Value"])

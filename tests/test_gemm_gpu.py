@@ -285,3 +285,33 @@ def test_colour_head_kernels(P, K):
     dW2, db42 = torch.empty(3, K, device=dev), torch.empty(4, device=dev)
     gemm.head3_bwd(dy, R, W, rr, dW2, db42, K=K)
     assert (dW2.double() - (rW - 1)).abs().max().item() < 2e-5 * max(1.0, rW.abs().max().item())
+
+
+@pytest.mark.parametrize("P,K,lda,ldc,epi", [(128 * 3, 256, 256, 256, "none"), (1000, 256, 256, 304, "relu"), (40000, 304, 304, 256, "relu"),
+                                             (70000, 256, 256, 256, "mask"), (33, 272, 272, 256, "none"), (300000, 256, 256, 256, "relu")])
+def test_gemm_r6_matches_fp64(P, K, lda, ldc, epi):
+    """hold_gemm_r6 (csrc/rgemm.hip: one 256-wide layer, register-resident) against fp64: K = 256 and the padded K = 272 / 304,
+    row strides wider than the matrices, ragged P, several blocks per workgroup, the three epilogues"""
+    import hold_amd
+    from hold_amd import field as F, gemm
+    if hold_amd.precision() != "f32x6":
+        pytest.skip("split-precision path")
+    dev = _dev()
+    torch.manual_seed(P + K)
+    A = torch.randn(P, lda, device=dev)
+    W = torch.randn(256, K, device=dev) / 16
+    b = torch.randn(256, device=dev) if epi != "mask" else None
+    aux = torch.randn(P, 256, device=dev) if epi == "mask" else None
+    out = torch.full((P, ldc), -7.0, device=dev)
+    gemm.gemm_r6(A[:, :K] if lda == K else A, F.pack_gemm_r6(W), out, K=K, bias=b,
+                 epi={"none": gemm.R6_NONE, "relu": gemm.R6_RELU, "mask": gemm.R6_MASK}[epi], aux=aux)
+    y = A[:, :K].double() @ W.double().t()
+    if b is not None:
+        y = y + b.double()
+    if epi == "relu":
+        y = y.clamp_min(0)
+    if epi == "mask":
+        y = y * (aux > 0)
+    assert float((out[:, :256].double() - y).abs().max()) < 3e-5 * max(1.0, float(y.abs().max()))
+    if ldc > 256:
+        assert float((out[:, 256:] + 7.0).abs().max()) == 0.0  # columns beyond the 256 outputs are not touched

@@ -47,9 +47,17 @@ def test_pack_weights_matches_the_matrix_by_matrix_layouts(kind, mode, with_rend
         new, old = F.pack_weights(*args), ref.pack_weights(*args)
         # "trunk_r6" (the stream of the register-resident trunk) has no matrix-by-matrix predecessor: its layout is held to
         # a lane-level model of the MFMA register order in tests/test_r6_pack_cpu.py
-        assert set(new) - {"trunk_r6", "chain_bwd_r6"} == set(old)
+        r6_only = {"trunk_r6", "chain_bwd_r6", "w8_feat_r6", "R_r6", "RT_r6"}
+        assert set(new) - r6_only == set(old)
         for k in old:
             _same(new[k], old[k], k)
+        if mode == "f32x6":  # hold_gemm_r6 packs (one gather for all of them) == the matrix-by-matrix packer
+            assert torch.equal(new["w8_feat_r6"], F.pack_gemm_r6(new["W8_feat"]))
+            if with_render:
+                for l in range(4):
+                    assert torch.equal(new["R_r6"][l], F.pack_gemm_r6(new["R"][l][:, :spec.Kr if l == 0 else 256])), l
+                for l in (1, 2, 3):
+                    assert torch.equal(new["RT_r6"][l], F.pack_gemm_r6(new["RT"][l])), l
         # what the kernels require of the per-layer views: unit inner stride, 16-byte aligned rows
         for k in ("W", "WT") + (("R", "RT") if with_render else ()):
             for t in new[k]:
