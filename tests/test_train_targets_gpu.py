@@ -415,3 +415,45 @@ def test_record_hip_training_output_fixture(ctx, tmp_path):
     subprocess.run([sys.executable, os.path.join(root, "scripts", "record_hip_outputs.py"), str(out)], check=True)
     z = np.load(out, allow_pickle=True)
     assert "out.right.index_off_surface" in z.files and "loss.loss" in z.files
+
+
+def test_chunked_loss_terms_add_up_to_the_unchunked_loss():
+    """ray-chunked steps (hold_amd.train.train_step): every ray-wise term of the full Loss -- rgb, semantics and the
+    opacity-sparsity mean over the OFF-SURFACE rays of the whole batch (loss_terms.py:44-56) -- must add up over the chunks
+    to the un-chunked loss, with the same gradients, in steady state (the sparsity term is normalised by the previous
+    step's whole-batch count); a chunk without a single off-surface ray contributes zero, not 0 / 0 (round-2 advisor)."""
+    from hold_amd.loss import Loss
+    dev = "cuda:0"
+    N, C = 2048, 4
+    g = torch.Generator().manual_seed(11)
+    r = lambda *s: torch.rand(*s, generator=g)
+    leaves = {"rgb": r(N, 3), "semantics": r(N, 4), "right.mask_prob": r(N), "object.mask_prob": r(N)}
+    off = {"right": r(N) > 0.5, "object": r(N) > 0.7}
+    off["object"][N // C:2 * N // C] = False  # the second chunk has no off-surface ray of this node
+    batch = {"gt.rgb": r(N, 3).to(dev), "gt.mask": torch.tensor([0, 50, 150, 250])[torch.randint(0, 4, (N,), generator=g)].to(dev)}
+
+    def run(chunks, loss_fn):
+        lv = {k: v.clone().to(dev).requires_grad_(True) for k, v in leaves.items()}
+        tot = {}
+        for c in range(chunks):
+            sl = slice(c * N // chunks, (c + 1) * N // chunks)
+            out = {k: v[sl] for k, v in lv.items()}
+            out.update({f"{n}.index_off_surface": o[sl].to(dev) for n, o in off.items()}, step=15000)
+            b = {k: v[sl] for k, v in batch.items()}
+            if chunks > 1:
+                b["hold_amd.n_total"], b["hold_amd.frame_terms"] = N, c == 0
+            ld = loss_fn(b, out)
+            ld["loss"].backward()
+            for k, v in ld.items():
+                tot[k] = tot.get(k, 0.0) + float(v.detach())
+        return tot, {k: v.grad.clone() for k, v in lv.items()}
+
+    full, g_full = run(1, Loss())
+    chunked = Loss()
+    run(C, chunked)                   # first step: populates the whole-batch counts
+    part, g_part = run(C, chunked)    # steady state
+    for k in ("loss/rgb", "loss/sem", "loss/opacity_sparse", "loss"):
+        assert math.isfinite(part[k]) and part[k] == pytest.approx(full[k], rel=2e-5), (k, part[k], full[k])
+    for k in g_full:
+        assert torch.isfinite(g_part[k]).all(), k
+        assert float((g_part[k] - g_full[k]).abs().max()) <= 2e-5 * float(g_full[k].abs().max()), k
