@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   uint32_t ax_off_cur = ax_off_prev;
   const char* Ab = reinterpret_cast<const char*>(a.A);
   const char* Xb = reinterpret_cast<const char*>(a.aux);
+  const char* wbase = a.wpack;
 
   // ---- once per workgroup: the first R3 - 1 weight steps, the input fragments of the k steps 0..3 ----
 #pragma unroll
@@ -160,8 +161,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int i = 0; i < 6; ++i) A[0][i] = *reinterpret_cast<const u32x4*>(ring_lane + i * PIECE);
-  int gs = 0;
-
   rsrc_t crs = make_rsrc(nullptr, 0);  // stores of the block held in P (none before the first block is finished)
   uint32_t cvoff = 0;
 
@@ -230,10 +229,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // behind the rendezvous the six weight pieces of stream step gs + R3 - 1, in the last group -- BEHIND them in the queue --
   // the side fragments of k step j + 4 (of the next block once j + 4 >= KS), and cnt[group] / 12 micro-operations.
   auto kstep = [&](int j, const int (&cnt)[4], auto&& mp) {
-    const int slot = gs % R3, nslot = (gs + 1) % R3, fslot = (gs + R3 - 1) % R3;
+    // KS % R3 == 0 and every block starts a new pass over the stream: ring slots are compile-time functions of j
+    const int slot = j % R3, nslot = (j + 1) % R3, fslot = (j + R3 - 1) % R3;
     int jw = j + R3 - 1;
     jw = jw >= KS ? jw - KS : jw;
-    const char* wsrc = a.wpack + (long)jw * SLOT + wave * (6 * PIECE);
+    const char* wsrc = wbase + (long)jw * SLOT + wave * (6 * PIECE);
     const uint32_t wdst = (uint32_t)(fslot * SLOT + wave * (6 * PIECE));
     const int e4 = j + 4;
     const bool wrap = e4 >= KS;
@@ -270,12 +270,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
     Bc = Bn;
-    gs += 1;
   };
   static constexpr int CNT_NONE[4] = {0, 0, 0, 0};
   auto no_mop = [](int, int) {};
 
   for (; blk * BPTS < a.P; blk += gridDim.x) {
+    // the stream bases are made opaque once per block: loop-invariant, the ~160 DMA source addresses of a block would be
+    // hoisted out of the block loop and live in spilled scalar registers (two v_readlane per DMA) instead of two s_add each
+    asm volatile("" : "+s"(wbase), "+s"(Ab), "+s"(Xb));
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
