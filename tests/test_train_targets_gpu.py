@@ -445,7 +445,7 @@ def test_chunked_loss_terms_add_up_to_the_unchunked_loss():
             ld = loss_fn(b, out)
             ld["loss"].backward()
             for k, v in ld.items():
-                tot[k] = tot.get(k, 0.0) + float(v.detach())
+                tot[k] = tot.get(k, 0.0) + float(v.detach() if torch.is_tensor(v) else v)
         return tot, {k: v.grad.clone() for k, v in lv.items()}
 
     full, g_full = run(1, Loss())
