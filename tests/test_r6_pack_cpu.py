@@ -92,3 +92,40 @@ def test_r6_stream_reproduces_the_trunk():
             a = np.concatenate([a[:, :SKIP], x[:, :39]], 1)
         a = softplus100(a @ W[layer].T[:a.shape[1]] + b[layer])
     assert np.abs(h7 - a).max() < 1e-9, np.abs(h7 - a).max()
+
+
+def test_gemm_r6_stream_reproduces_a_layer():
+    """hold_gemm_r6 (csrc/rgemm.hip) on the same lane-level model: the B operand of k step e is the lane's own row, columns
+    16 e + 8 (i / 4) + 4 hh + i % 4 (two 16-byte pieces at 16 e + 4 hh and 16 e + 8 + 4 hh); with the weight stream of
+    field.pack_gemm_r6 the accumulators must hold A . W^T + b in the layout the stores assume (register 4 g + r of tile nt =
+    output 32 nt + 8 g + 4 hh + r), for K = 256 and for the zero-padded K = 304 (20 k steps, padded steps re-read k step 0)."""
+    from hold_amd.field import pack_gemm_r6
+    g = torch.Generator().manual_seed(5)
+    lanes = np.arange(64)
+    hh, li = lanes // 32, lanes % 32
+    for K in (256, 304):
+        KS = (K + 63) // 64 * 4
+        W = torch.randn(256, K, generator=g) * 0.1
+        x = torch.randn(32, K, generator=g).numpy().astype(np.float64)  # the wave's 32 rows
+        b = torch.randn(256, generator=g).numpy().astype(np.float64)
+        pack = pack_gemm_r6(W).float().numpy().reshape(KS, 8, 3, 2, 32, 8).astype(np.float64)
+        A_frag = pack.sum(2).reshape(KS, 8, 64, 8)  # limbs add up exactly; lane = 32 h + i
+        acc = np.zeros((8, 16, 64))
+        for nt in range(8):
+            for gq in range(4):
+                for r in range(4):
+                    acc[nt, 4 * gq + r] = b[32 * nt + 8 * gq + 4 * hh + r]
+        for e in range(KS):
+            ec = e if e < K // 16 else 0  # padded k steps: the kernel requests k step 0 again (zero weights)
+            B_lane = np.zeros((64, 8))
+            for i in range(8):
+                B_lane[:, i] = x[li, 16 * ec + 8 * (i // 4) + 4 * hh + i % 4]
+            for nt in range(8):
+                mfma_32x32x16(A_frag[e, nt], B_lane, acc[nt])
+        ref = x @ W.numpy().astype(np.float64).T + b  # [32 points][256]
+        for nt in range(8):
+            for gq in range(4):
+                for r in range(4):
+                    got = acc[nt, 4 * gq + r]  # [64 lanes]: point li, output 32 nt + 8 gq + 4 hh + r
+                    want = ref[li, 32 * nt + 8 * gq + 4 * hh + r]
+                    assert np.abs(got - want).max() < 1e-4 * np.abs(ref).max(), (K, nt, gq, r)
