@@ -215,3 +215,92 @@ def test_render_input_column_permutation_is_a_bijection_onto_the_reference_order
         back = torch.empty_like(g)
         back[:, perm] = g[:, perm][:, torch.arange(rin_dim)]
         assert torch.equal(back, g)
+
+
+def _cpu_net(n_frames=4):
+    import torch
+    import hold_amd
+    from hold_amd import synthetic as syn
+    torch.manual_seed(0)
+    sc = syn.make_scene(n_frames=n_frames)
+    net = hold_amd.build_from_scene(sc, syn.make_state_dict(sc), device="cpu")
+    for node in net.nodes.values():
+        node.params.defrost()
+    return net
+
+
+def test_flat_adam_state_dict_round_trip_and_rehome():
+    """round-2 advisor: the optimiser state (moments, step count) must survive checkpoint / resume, and a parameter whose
+    storage was replaced after construction (net.to(), .float(), GenericParams.init_parameters) must be brought back into
+    the bucket instead of being silently left behind (host logic only: the update kernels themselves need the GPU)"""
+    import torch
+    from hold_amd.optim import FlatAdam
+    a = FlatAdam(_cpu_net(), lr=5e-4, clip_norm=0.5)
+    g = torch.Generator().manual_seed(1)
+    a.m.copy_(torch.randn(a.m.shape, generator=g))
+    a.v.copy_(torch.rand(a.v.shape, generator=g))
+    a.step_count = 17
+    sd = a.state_dict()
+    b = FlatAdam(_cpu_net(), lr=1e-3, clip_norm=0.0)
+    b.load_state_dict(sd)
+    assert b.step_count == 17 and torch.equal(b.m, a.m) and torch.equal(b.v, a.v)
+    assert b.lr == a.lr and b.clip_norm == a.clip_norm and tuple(b.betas) == tuple(a.betas)
+    sd["m"].zero_()  # the state dict owns copies, not views of the live buffers
+    assert float(a.m.abs().max()) > 0
+    with pytest.raises(ValueError):
+        FlatAdam(_cpu_net(n_frames=6), lr=5e-4).load_state_dict(sd)  # other pose-table sizes: another layout
+    # re-homing
+    p = b.params[3]
+    off = b.offsets[3]
+    assert p.data_ptr() == b.flat.data_ptr() + 4 * off and b.rehome() == 0
+    p.data = p.data.clone() * 2.0  # what net.float() / init_parameters do: a new storage behind the same Parameter
+    assert p.data_ptr() != b.flat.data_ptr() + 4 * off
+    want = p.data.clone()
+    assert b.rehome() == 1
+    assert p.data_ptr() == b.flat.data_ptr() + 4 * off and torch.equal(p.data, want)
+    assert torch.equal(b.flat[off:off + p.numel()].view(p.shape), want)
+
+
+def test_weight_pack_key_follows_writes_torch_cannot_see():
+    """round-2 advisor: the weight-pack cache is keyed on torch's version counters; load_state_dict, .to()/.float() and the
+    optimiser's raw-pointer update must invalidate it too (hooks / config.bump_weights_epoch)"""
+    import torch
+    from hold_amd import config
+    from hold_amd.hold_net import _pack_key
+    net = _cpu_net()
+    mod = net.nodes["object"].implicit_network
+    k0 = _pack_key((mod,), True)
+    assert _pack_key((mod,), True) == k0  # stable while nothing changes
+    with torch.no_grad():
+        mod.lin1.bias.add_(1.0)  # an in-place torch update: the version counter moves
+    k1 = _pack_key((mod,), True)
+    assert k1 != k0
+    net.load_state_dict(net.state_dict())  # post-hook
+    k2 = _pack_key((mod,), True)
+    assert k2 != k1
+    net.float()  # _apply
+    k3 = _pack_key((mod,), True)
+    assert k3 != k2
+    mod.lin1.bias.data.mul_(0.5)  # a write through .data: invisible to torch -- the documented contract is the explicit bump
+    assert _pack_key((mod,), True) == k3
+    config.bump_weights_epoch()
+    assert _pack_key((mod,), True) != k3
+
+
+def test_barf_counter_is_mirrored_on_the_host():
+    """BarfEmbedder.step() must not read its device buffer back (a host sync per node and step): the counter lives on the
+    host, the checkpointed buffer follows it, and load_state_dict re-synchronises the host copy"""
+    import torch
+    net = _cpu_net()
+    emb = net.nodes["object"].implicit_network.embedder_obj
+    it0 = emb._iter_host
+    assert int(emb.alpha_iter) == it0
+    emb.step()
+    assert emb._iter_host == it0 + 1 and int(emb.alpha_iter) == it0 + 1
+    sd = net.state_dict()
+    key = next(k for k in sd if k.endswith("nodes.object.implicit_network.embedder_obj.alpha_iter"))
+    sd[key] = torch.tensor(1234)
+    net.load_state_dict(sd)
+    assert emb._iter_host == 1234 and int(emb.alpha_iter) == 1234
+    w = emb.weights("cpu")
+    assert w is None or (w.shape[0] == 39 and bool(torch.isfinite(w).all()))
