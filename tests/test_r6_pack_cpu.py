@@ -129,3 +129,31 @@ def test_gemm_r6_stream_reproduces_a_layer():
                     got = acc[nt, 4 * gq + r]  # [64 lanes]: point li, output 32 nt + 8 gq + 4 hh + r
                     want = ref[li, 32 * nt + 8 * gq + 4 * hh + r]
                     assert np.abs(got - want).max() < 1e-4 * np.abs(ref).max(), (K, nt, gq, r)
+
+
+def test_wgrad_r6_lds_image_and_fragment_addresses():
+    """csrc/wgrad_r6.hip restated on the CPU: the LDS-DMA placement of a step's raw rows (lane l of the wave that owns row r
+    fetches the 16-byte chunk l ^ 8 (r >> 3) and it lands lane-linear) and the fragment reads (base address XOR (f << 7),
+    + 1 KiB per point) must hand lane (hh, li) of wave (wn, .) the values M[8 hh + e][128 wn + 32 f + li], e = 0..7 -- and a
+    wave-wide read of one e must touch 64 distinct banks."""
+    rows = np.arange(16 * 256, dtype=np.float64).reshape(16, 256)  # M[r][c] = 256 r + c
+    lds = np.full(16 * 1024 // 4, -1.0)  # one operand's 16 KiB image, in floats
+    for half in range(2):  # the two waves that fetch this operand: rows 8 half .. 8 half + 7
+        for piece in range(8):
+            r = 8 * half + piece
+            for l in range(64):
+                chunk = l ^ (8 * half)
+                dst = (r * 1024 + l * 16) // 4
+                lds[dst:dst + 4] = rows[r, 4 * chunk:4 * chunk + 4]
+    assert (lds >= 0).all()
+    for wn in range(2):
+        for f in range(4):
+            for e in range(8):
+                banks = set()
+                for lane in range(64):
+                    hh, li = lane // 32, lane % 32
+                    rd = (8 * hh) * 1024 + ((128 * wn + li) ^ (32 * hh)) * 4
+                    addr = (rd ^ (f << 7)) + e * 1024
+                    assert lds[addr // 4] == rows[8 * hh + e, 128 * wn + 32 * f + li], (wn, f, e, lane)
+                    banks.add((addr // 4) % 64)
+                assert len(banks) == 64, (wn, f, e)
