@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 matrix)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 matrix, same guide
 HBM_PEAK_GBPS = 8000.0  # HBM3E spec (6.3 TB/s achievable by a float4 copy), same guide
-ROUND = "r03"
+ROUND = "r04"
 
 
 def parse():
@@ -150,7 +150,7 @@ def flop_per_ray(node_ids, mean_iters, S, n0, training):
 def gemm_shapes(prof):
     """aggregate the live launch timings by kernel and (flops per launch) bucket"""
     out = {}
-    for e0, e1, fl, name in prof:
+    for e0, e1, fl, name, _nb in prof:
         key = f"{name}:{fl:.3e}"
         a = out.setdefault(key, [0, 0.0, 0.0])
         a[0] += 1
@@ -163,11 +163,12 @@ def gemm_shapes(prof):
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the separate rocprofv3 --pmc passes of this same command
     (scripts/pmc.sh -> profiles/<round>_pmc_traffic.json, FETCH_SIZE doubled per the gfx950 calibration)."""
-    for rnd in (ROUND, "r02", "r01"):
+    for rnd in (ROUND,):  # only this round's passes: the kernel families of earlier rounds are other kernels
         f = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
         if os.path.exists(f):
             k = json.load(open(f)).get("kernels", {}).get(kernel)
-            return (k.get("hbm_bytes_per_launch") if k else None), os.path.basename(f)
+            if k:
+                return k.get("hbm_bytes_per_launch"), os.path.basename(f)
     return None, None
 
 
@@ -381,7 +382,12 @@ def main():
     if dist.is_initialized():
         dist.barrier()
     dt = time.perf_counter() - t0
+    rank_ms = [dt / args.steps * 1e3]
     if dist.is_initialized():
+        # per-rank step times (the first multi-GPU record checks itself: a straggler or a rank that did no work shows here)
+        tl = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(dist.get_world_size())]
+        dist.all_gather(tl, torch.tensor([dt], device=dev, dtype=torch.float64))
+        rank_ms = [float(x) / args.steps * 1e3 for x in tl]
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -437,28 +443,36 @@ def main():
                                        "all-reduce, one RCCL all-reduce (sum) of the flat gradient bucket)"
                                        if (args.split == "rays" and world > 1 and args.mode != "c3") else
                                        f"dp{world} (frames sharded, one RCCL all-reduce of the flat gradient bucket)"),
+                       "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+                       "collective_backend": dist.get_backend() if dist.is_initialized() else None,
+                       "per_rank_ms_per_step": rank_ms,
                        "loss": float(loss), "precision": hold_amd.precision(),
                        "steps_per_s": args.steps / dt},
         }
         if prof:
             agg, hbm = {}, {}
-            for e0, e1, fl, name in prof:
-                a = (hbm if name.startswith("hbm:") else agg).setdefault(name, [0.0, 0.0, 0])
+            for e0, e1, fl, name, nb in prof:
+                a = (hbm if name.startswith("hbm:") else agg).setdefault(name, [0.0, 0.0, 0, 0.0])
                 a[0] += e0.elapsed_time(e1) * 1e-3
                 a[1] += fl
                 a[2] += 1
+                a[3] += nb
             if args.shape_report:
                 json.dump(gemm_shapes(prof), open(args.shape_report, "w"), indent=1)
-            split = {"fused_sdf_kernel", "wgrad_kernel", "chain_kernel", "gemm_nt_kernel", "trunk_r6_kernel", "rchain_kernel", "rgemm_kernel"} if x6 else set()
+            split = {"fused_sdf_kernel", "wgrad_kernel", "chain_kernel", "gemm_nt_kernel", "trunk_r6_kernel", "rchain_kernel",
+                     "rchain_a2_kernel", "rgemm_kernel"} if x6 else set()
             labels = {"gemm_nt_kernel": ("gemm_nt_kernel<x6> (one layer per launch, 3-limb split on v_mfma_f32_32x32x16_bf16)"
                                          if x6 else "gemm_nt_kernel (one layer per launch, v_mfma_f32_32x32x2_f32)"),
                       "trunk_r6_kernel": "rmlp_kernel<STORE> (forward trunk, 8 layers per launch, register-resident, 3-limb split on "
                                          "v_mfma_f32_32x32x16_bf16)",
                       "rgemm_kernel": "rgemm_kernel (rendering-net layers, their input gradients, lin8 features: one 256-wide layer "
                                       "per launch, register-resident, 3-limb split on v_mfma_f32_32x32x16_bf16)",
-                      "rchain_kernel": "rchain_kernel (descending sweep of the normal path, 7 layers per launch, register-resident, "
-                                       "3-limb split on v_mfma_f32_32x32x16_bf16)",
-                      "chain_kernel": ("chain_x6_kernel (first-order backward and second-order sweeps: 7-8 trunk layers per launch, "
+                      "rchain_kernel": "rtile_kernel<DSP> (descending sweep of the normal path, 7 layers per launch, register-resident, "
+                                       "side I/O as whole 128-byte lines through LDS, 3-limb split on v_mfma_f32_32x32x16_bf16)",
+                      "rchain_a2_kernel": "rtile_kernel<DSP+a2> (first-order backward sweep, 7 layers per launch, register-resident, "
+                                          "two side inputs as whole lines through LDS, 3-limb split on v_mfma_f32_32x32x16_bf16)",
+                      "chain_kernel": ("chain_x6_kernel (second-order ascending sweep DBWD [+ any sweep not routed to the "
+                                       "register-resident kernels]: 7-8 trunk layers per launch, "
                                        "LDS-resident, 3-limb split on v_mfma_f32_32x32x16_bf16)" if x6 else
                                        "chain_kernel (7-8 trunk layers per launch, LDS-resident, v_mfma_f32_32x32x2_f32)"),
                       "fused_sdf_kernel": ("rmlp_kernel<HEAD> (sampler SDF queries: register-resident trunk, 3-limb split on "
@@ -468,50 +482,81 @@ def main():
                                        "workgroups for the 256x256 layers, LDS tiles otherwise; 3-limb split on v_mfma_f32_32x32x16_bf16)"
                                        if x6 else "wgrad_lds_kernel (weight gradients, v_mfma_f32_32x32x2_f32)")}
             ent = {}
-            for name, (t_, fl_, n_) in agg.items():
+            hbm_step = 0.0
+            for name, (t_, fl_, n_, by_) in agg.items():
                 tf = fl_ / t_ / 1e12
                 is6 = name in split
                 # split-precision kernels are priced on the pipe they run on: 6 bf16 limb products issued per algorithmic
                 # product, against the dense bf16 MFMA peak; the algorithmic (fp32-equivalent) rate is a named extra
-                ent[name] = {"achieved": 6.0 * tf if is6 else tf, "peak": BF16_MFMA_PEAK_TFLOPS if is6 else FP32_MFMA_PEAK_TFLOPS,
-                             "frac": (6.0 * tf / BF16_MFMA_PEAK_TFLOPS) if is6 else tf / FP32_MFMA_PEAK_TFLOPS,
-                             "launches": n_, "avg_launch_ms": t_ / n_ * 1e3, "time_share": t_ / dt,
-                             "flop_per_launch_avg": fl_ / n_, "arithmetic": "f32x6" if is6 else "f32",
-                             "fp32_equivalent_tflops": tf}
+                issued, peak = (6.0 * tf, BF16_MFMA_PEAK_TFLOPS) if is6 else (tf, FP32_MFMA_PEAK_TFLOPS)
+                # BOTH floors of the family: matrix pipe = issued FLOP / peak; HBM = bytes / 8 TB/s, with the
+                # measured bytes (PMC FETCH_SIZE / WRITE_SIZE of separate passes, per launch) when the round's profile has this
+                # family and the ALGORITHMIC bytes (operands once, results once) otherwise.  bound = the larger floor.
+                pmc_b, pmc_src = pmc_traffic(name)
+                alg_b = by_ / n_
+                hbm_b = pmc_b if pmc_b else alg_b
+                t_launch = t_ / n_
+                floor_mfma = (fl_ / n_) * (6.0 if is6 else 1.0) / (peak * 1e12)
+                floor_hbm = hbm_b / (HBM_PEAK_GBPS * 1e9)
+                bound = "hbm" if floor_hbm > floor_mfma else "mfma"
+                hbm_step += hbm_b * n_ / args.steps
+                ent[name] = {"bound": bound, "mfma_achieved": issued, "mfma_peak": peak, "mfma_frac": issued / peak,
+                             "hbm_achieved_gbps": alg_b / t_launch / 1e9, "hbm_frac": alg_b / t_launch / 1e9 / HBM_PEAK_GBPS,
+                             "hbm_frac_measured_bytes": (pmc_b / t_launch / 1e9 / HBM_PEAK_GBPS) if pmc_b else None,
+                             "floor_ms": {"mfma": floor_mfma * 1e3, "hbm": floor_hbm * 1e3},
+                             "launches": n_, "avg_launch_ms": t_launch * 1e3, "time_share": t_ / dt,
+                             "flop_per_launch_avg": fl_ / n_, "algorithmic_bytes_per_launch_avg": alg_b,
+                             "traffic": pmc_b, "traffic_source": pmc_src,
+                             "arithmetic": "f32x6" if is6 else "f32", "fp32_equivalent_tflops": tf}
+                if bound == "hbm":
+                    ent[name].update(achieved=alg_b / t_launch / 1e9, peak=HBM_PEAK_GBPS, unit="GB/s",
+                                     frac=alg_b / t_launch / 1e9 / HBM_PEAK_GBPS)
+                else:
+                    ent[name].update(achieved=issued, peak=peak, unit="TFLOP/s", frac=issued / peak)
                 if is6:
-                    ent[name]["note"] = ("achieved = bf16 MFMA FLOP/s issued (6 limb products per algorithmic fp32 product), peak = "
-                                         "dense bf16 MFMA; fp32_equivalent_tflops = algorithmic FLOP / time")
+                    ent[name]["note"] = ("mfma_achieved = bf16 MFMA FLOP/s issued (6 limb products per algorithmic fp32 product), "
+                                         "mfma_peak = dense bf16 MFMA; fp32_equivalent_tflops = algorithmic FLOP / time; bound = the "
+                                         "larger of the two floors (issued FLOP / MFMA peak, HBM bytes / 8 TB/s); achieved / peak / "
+                                         "frac are those of the bound")
             # the sampler / compositor stages: scan and search work on <= 640-float per-ray windows held in LDS -- their HBM
             # traffic is the windows in and out; achieved GB/s (algorithmic bytes / live-timed launch) against the HBM roof
             # shows they are nowhere near it (they are latency / LDS-bound at < 2 % of the step), not that they are fast
-            for name, (t_, by_, n_) in hbm.items():
+            for name, (t_, by_, n_, _) in hbm.items():
                 ent[name[4:] + "_kernel"] = {"bound": "hbm", "achieved": by_ / t_ / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                              "frac": by_ / t_ / 1e9 / HBM_PEAK_GBPS, "launches": n_,
                                              "avg_launch_ms": t_ / n_ * 1e3, "time_share": t_ / dt,
                                              "algorithmic_bytes_per_launch_avg": by_ / n_}
-            dom = max((k for k in ent if ent[k].get("bound") != "hbm"), key=lambda k: ent[k]["time_share"])
-            traffic, tsrc = pmc_traffic(dom)
-            res["roofline"] = {"bound": "mfma", "achieved": ent[dom]["achieved"], "peak": ent[dom]["peak"],
-                               "unit": "TFLOP/s", "frac": ent[dom]["frac"], "traffic": traffic,
-                               "kernel": labels.get(dom, dom), "launches": ent[dom]["launches"],
-                               "avg_launch_ms": ent[dom]["avg_launch_ms"], "time_share": ent[dom]["time_share"],
-                               "flop_per_launch_avg": ent[dom]["flop_per_launch_avg"],
-                               "arithmetic": ent[dom]["arithmetic"],
-                               "fp32_equivalent_tflops": ent[dom]["fp32_equivalent_tflops"],
-                               "traffic_note": f"HBM bytes/launch of this kernel from separate --pmc passes (profiles/{tsrc})",
+            dom = max((k for k in agg), key=lambda k: ent[k]["time_share"])
+            d = ent[dom]
+            res["roofline"] = {"bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
+                               "frac": d["frac"], "traffic": d["traffic"],
+                               "mfma_frac": d["mfma_frac"], "hbm_frac": d["hbm_frac"],
+                               "hbm_frac_measured_bytes": d["hbm_frac_measured_bytes"], "floor_ms": d["floor_ms"],
+                               "kernel": labels.get(dom, dom), "launches": d["launches"],
+                               "avg_launch_ms": d["avg_launch_ms"], "time_share": d["time_share"],
+                               "flop_per_launch_avg": d["flop_per_launch_avg"],
+                               "algorithmic_bytes_per_launch_avg": d["algorithmic_bytes_per_launch_avg"],
+                               "arithmetic": d["arithmetic"],
+                               "fp32_equivalent_tflops": d["fp32_equivalent_tflops"],
+                               "traffic_note": (f"HBM bytes/launch of this kernel from separate --pmc passes (profiles/{d['traffic_source']})"
+                                                if d["traffic"] else "no PMC pass of this kernel family in profiles/ yet"),
                                "kernels": ent}
-            if "note" in ent[dom]:
-                res["roofline"]["note"] = ent[dom]["note"]
-            for k in ent:
-                ent[k].setdefault("bound", "mfma")
-                ent[k].setdefault("unit", "TFLOP/s")
+            if "note" in d:
+                res["roofline"]["note"] = d["note"]
             mf = sum(v[1] for v in agg.values())
             mf6 = sum((6.0 if k in split else 1.0) * v[1] for k, v in agg.items())
             res["roofline"]["end_to_end"] = {"mfma_tflops_fp32_equivalent": mf / dt / 1e12,
                                              "mfma_tflops_issued": mf6 / dt / 1e12,
                                              "frac_of_bf16_mfma_peak_issued": (mf6 / dt / 1e12 / BF16_MFMA_PEAK_TFLOPS) if x6 else None,
                                              "frac_of_fp32_mfma_peak": None if x6 else mf / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                                             "time_in_mfma_kernels": sum(v[0] for v in agg.values()) / dt}
+                                             "time_in_mfma_kernels": sum(v[0] for v in agg.values()) / dt,
+                                             # HBM side of the whole step: bytes of the MFMA families (PMC per launch where
+                                             # profiled, algorithmic otherwise) x launches; floors of the step on both roofs
+                                             "hbm_bytes_per_step": hbm_step,
+                                             "hbm_tb_s": hbm_step / (dt / args.steps) / 1e12,
+                                             "hbm_frac_of_8tbs": hbm_step / (dt / args.steps) / (HBM_PEAK_GBPS * 1e9),
+                                             "step_floor_s": {"hbm": hbm_step / (HBM_PEAK_GBPS * 1e9),
+                                                              "mfma": mf6 / args.steps / ((BF16_MFMA_PEAK_TFLOPS if x6 else FP32_MFMA_PEAK_TFLOPS) * 1e12)}}
         res["config"]["c_abi_calls_per_step"] = (_L.CALLS - calls0) / args.steps
         if args.mode == "c3" and not args.no_refine:
             try:

@@ -542,9 +542,9 @@ class NodeField:
             K.chain(K.CHAIN_DSP, P, r7, pk["chain_bwd"], 7, 32, skip_layer=3, aux1=[h[l - 1] for l in range(7, 0, -1)],
                     aux2=None if a2 is None else [a2[l - 1] for l in range(7, 0, -1)],
                     out=[r[l - 1] for l in range(7, 0, -1)], wpack_x6=pk.get("chain_bwd_x6"),
-                    # register-resident sweep only without the additive side input: with a2 it moves 3 KiB per point and
-                    # layer as 32-byte row fragments and measured slower than hold_chain_x6 (113 vs 124 TF-eq)
-                    wpack_r6=pk.get("chain_bwd_r6") if (USE_R6_BWD and a2 is None) else None)
+                    # register-resident sweep, with or without the additive side input: since round 4 its side traffic moves
+                    # as whole 128-byte lines through LDS (rtile_kernel: 140 vs 122 TF-eq for hold_chain_x6 with a2)
+                    wpack_r6=pk.get("chain_bwd_r6") if USE_R6_BWD else None)
             if ebar is not None:
                 K.copy_cols(r[3][:, sp.skip_out:], ebar, sp.E, P)
             for l in range(7, 0, -1):

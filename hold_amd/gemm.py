@@ -10,8 +10,9 @@ from ._lib import (EPI_DBWD, EPI_MUL_DRELU, EPI_MUL_DSIG, EPI_MUL_DSP, EPI_NONE,
                    EPI_SOFTPLUS, GemmDesc, check, ptr, stream_ptr)
 
 
-# when set to a list, every launch appends (start_event, end_event, algorithmic_flops, kernel_name); the events
-# are recorded on torch's current stream, which is the stream the kernel is launched on.
+# when set to a list, every launch appends (start_event, end_event, algorithmic_flops, kernel_name, algorithmic_bytes); the
+# events are recorded on torch's current stream, which is the stream the kernel is launched on.  algorithmic_bytes = the HBM
+# bytes the launch has to move (operands in once, results out once; weights stay in L2), DESIGN.md section 4.
 PROFILE = None
 
 
@@ -23,12 +24,12 @@ def _prof_begin():
     return e
 
 
-def _prof_end(e0, flops, name):
+def _prof_end(e0, flops, name, nbytes=0.0):
     if e0 is None:
         return
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
-    PROFILE.append((e0, e1, flops, name))
+    PROFILE.append((e0, e1, flops, name, float(nbytes)))
 
 
 def _ld(t):
@@ -52,7 +53,7 @@ def gemm_r6(A, wpack, out, *, K, bias=None, epi=R6_NONE, aux=None):
         n = min(P, r0 + rows) - r0
         check(L.hold_gemm_r6(ptr(A[r0:]), _ld(A), n, ptr(wpack), K, ptr(bias), int(epi), ptr(None if aux is None else aux[r0:]),
                              0 if aux is None else _ld(aux), ptr(out[r0:]), _ld(out), stream_ptr()), "hold_gemm_r6")
-    _prof_end(e0, 2.0 * P * 256 * K, "rgemm_kernel")
+    _prof_end(e0, 2.0 * P * 256 * K, "rgemm_kernel", 4.0 * P * (K + 256 + (256 if aux is not None else 0)))
     return out
 
 
@@ -91,7 +92,8 @@ def gemm_nt(A, W, out, *, bias=None, epi=EPI_NONE, alpha=1.0, N=None, K=None, n_
         check(_lib.lib().hold_gemm_nt_x6(C.byref(d), stream_ptr()), "hold_gemm_nt_x6")
     else:
         check(_lib.lib().hold_gemm_nt(C.byref(d), stream_ptr()), "hold_gemm_nt")
-    _prof_end(e0, 2.0 * P * N * K, "gemm_nt_kernel")
+    n_side = sum(x is not None for x in (aux1, aux2, out2)) + (1 if accumulate else 0)
+    _prof_end(e0, 2.0 * P * N * K, "gemm_nt_kernel", 4.0 * P * (K + N * (1 + n_side)))
     return out
 
 
@@ -121,7 +123,7 @@ def wgrad(R, X, dW, db=None, *, N=None, K=None, accumulate=False, splits=None):
     fn = L.hold_wgrad_x6 if config.x6() else L.hold_wgrad
     check(fn(ptr(R), _ld(R), ptr(X), _ld(X), P, N, K, ptr(dW), _ld(dW), ptr(db), 1 if accumulate else 0,
              splits, ptr(ws), stream_ptr()), "hold_wgrad")
-    _prof_end(e0, 2.0 * P * N * K, "wgrad_kernel")
+    _prof_end(e0, 2.0 * P * N * K, "wgrad_kernel", 4.0 * P * (N + K))
     return dW
 
 

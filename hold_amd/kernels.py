@@ -109,7 +109,7 @@ def fused_sdf(xc, P, wpack, bias8, w8, b8, barf_w, out_sdf):
     e0 = _g._prof_begin()
     call("hold_fused_sdf", ptr(xc), _ld(xc), P, ptr(wpack), ptr(bias8), ptr(w8), float(b8), ptr(barf_w), ptr(out_sdf),
          _ld(out_sdf))
-    _g._prof_end(e0, 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256), "fused_sdf_kernel")
+    _g._prof_end(e0, 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256), "fused_sdf_kernel", 20.0 * P)
 
 
 def fused_sdf_x6(xc, P, wpack_x6, bias8, w8, b8, barf_w, out_sdf):
@@ -119,7 +119,7 @@ def fused_sdf_x6(xc, P, wpack_x6, bias8, w8, b8, barf_w, out_sdf):
     e0 = _g._prof_begin()
     call("hold_fused_sdf_x6", ptr(xc), _ld(xc), P, ptr(wpack_x6), ptr(bias8), ptr(w8), float(b8), ptr(barf_w),
          ptr(out_sdf), _ld(out_sdf))
-    _g._prof_end(e0, 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256), "fused_sdf_kernel")
+    _g._prof_end(e0, 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256), "fused_sdf_kernel", 20.0 * P)
 
 
 def fused_sdf_r6(xc, P, wpack_r6, bias8, w8, b8, barf_w, out_sdf):
@@ -131,7 +131,7 @@ def fused_sdf_r6(xc, P, wpack_r6, bias8, w8, b8, barf_w, out_sdf):
     e0 = _g._prof_begin()
     call("hold_fused_sdf_r6", ptr(xc), _ld(xc), P, ptr(wpack_r6), ptr(bias8), ptr(w8), ptr(b8), ptr(barf_w),
          ptr(out_sdf), _ld(out_sdf))
-    _g._prof_end(e0, 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256), "fused_sdf_kernel")
+    _g._prof_end(e0, 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256), "fused_sdf_kernel", 20.0 * P)
 
 
 _TRUNK_MAX_ROWS = ((1 << 32) // 1024 - 1) // 128 * 128
@@ -149,7 +149,7 @@ def trunk_r6(xc, P, wpack_r6, bias8, barf_w, h):
         arr = (C.c_void_p * 8)(*[t[r0:].data_ptr() for t in h])
         e0 = _g._prof_begin()
         call("hold_trunk_r6", ptr(xc[r0:]), _ld(xc), n, ptr(wpack_r6), ptr(bias8), ptr(barf_w), arr, ld)
-        _g._prof_end(e0, 2.0 * n * (40 * 256 + 6 * 65536 + 217 * 256), "trunk_r6_kernel")
+        _g._prof_end(e0, 2.0 * n * (40 * 256 + 6 * 65536 + 217 * 256), "trunk_r6_kernel", n * (16.0 + 8 * 1024))
 
 
 CHAIN_SOFTPLUS, CHAIN_DSP, CHAIN_DBWD = 0, 1, 2
@@ -197,7 +197,11 @@ def chain(mode, P, x_in, wpack, n_layers, first_chunks, skip_layer=-1, side=None
         d.ld = ld if ld is not None else 256
         e0 = _g._prof_begin()
         call("hold_chain_r6" if r6 else ("hold_chain" if wpack_x6 is None else "hold_chain_x6"), C.byref(d))
-        _g._prof_end(e0, 2.0 * (r1 - r0) * 256 * (8 * first_chunks + 256 * (n_layers - 1)), "rchain_kernel" if r6 else "chain_kernel")
+        # algorithmic HBM bytes: the chain input row + per layer 1 KiB per side input and per stored result
+        n_mats = sum(sum(t is not None for t in lst) for lst in (aux1, aux2, out, out2) if lst is not None)
+        _g._prof_end(e0, 2.0 * (r1 - r0) * 256 * (8 * first_chunks + 256 * (n_layers - 1)),
+                     ("rchain_a2_kernel" if aux2 is not None else "rchain_kernel") if r6 else "chain_kernel",
+                     (r1 - r0) * (32.0 * first_chunks + 1024.0 * n_mats))
 
 
 def seed_dsp(h, w, N, P, t):
