@@ -460,19 +460,21 @@ def main():
             if args.shape_report:
                 json.dump(gemm_shapes(prof), open(args.shape_report, "w"), indent=1)
             split = {"fused_sdf_kernel", "wgrad_kernel", "chain_kernel", "gemm_nt_kernel", "trunk_r6_kernel", "rchain_kernel",
-                     "rchain_a2_kernel", "rgemm_kernel"} if x6 else set()
+                     "rchain_a2_kernel", "rchain_dbwd_kernel", "rgemm_kernel"} if x6 else set()
             labels = {"gemm_nt_kernel": ("gemm_nt_kernel<x6> (one layer per launch, 3-limb split on v_mfma_f32_32x32x16_bf16)"
                                          if x6 else "gemm_nt_kernel (one layer per launch, v_mfma_f32_32x32x2_f32)"),
                       "trunk_r6_kernel": "rmlp_kernel<STORE> (forward trunk, 8 layers per launch, register-resident, 3-limb split on "
                                          "v_mfma_f32_32x32x16_bf16)",
                       "rgemm_kernel": "rgemm_kernel (rendering-net layers, their input gradients, lin8 features: one 256-wide layer "
                                       "per launch, register-resident, 3-limb split on v_mfma_f32_32x32x16_bf16)",
-                      "rchain_kernel": "rtile_kernel<DSP> (descending sweep of the normal path, 7 layers per launch, register-resident, "
+                      "rchain_kernel": "rsweep_kernel<DSP> (descending sweep of the normal path, 7 layers per launch, register-resident, "
                                        "side I/O as whole 128-byte lines through LDS, 3-limb split on v_mfma_f32_32x32x16_bf16)",
-                      "rchain_a2_kernel": "rtile_kernel<DSP+a2> (first-order backward sweep, 7 layers per launch, register-resident, "
+                      "rchain_a2_kernel": "rsweep_kernel<DSP+a2> (first-order backward sweep, 7 layers per launch, register-resident, "
                                           "two side inputs as whole lines through LDS, 3-limb split on v_mfma_f32_32x32x16_bf16)",
-                      "chain_kernel": ("chain_x6_kernel (second-order ascending sweep DBWD [+ any sweep not routed to the "
-                                       "register-resident kernels]: 7-8 trunk layers per launch, "
+                      "rchain_dbwd_kernel": "rsweep_kernel<DBWD> (second-order ascending sweep, 8 layers per launch, register-resident, "
+                                            "two side inputs and two results as whole lines through LDS, 3-limb split on "
+                                            "v_mfma_f32_32x32x16_bf16)",
+                      "chain_kernel": ("chain_x6_kernel (any sweep not routed to the register-resident kernels: 7-8 trunk layers per launch, "
                                        "LDS-resident, 3-limb split on v_mfma_f32_32x32x16_bf16)" if x6 else
                                        "chain_kernel (7-8 trunk layers per launch, LDS-resident, v_mfma_f32_32x32x2_f32)"),
                       "fused_sdf_kernel": ("rmlp_kernel<HEAD> (sampler SDF queries: register-resident trunk, 3-limb split on "

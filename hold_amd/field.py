@@ -504,8 +504,14 @@ class NodeField:
         a2 = [pool.get(f"a2_{l}", P, 256) for l in range(8)]
         if USE_CHAIN:
             vb = [pool.get(f"vbc{l}", P, 256) for l in range(8)]
+            wr6 = pk.get("trunk_r6") if USE_R6_BWD else None
+            if wr6 is not None:
+                # register-resident sweep (csrc/rchain.hip): it takes the skip layer's side columns (the next input's columns
+                # 217.. = the embedding cotangent) from aux2[3][:, 217:] -- that part of t_3 held the raw d sdf / d embedding
+                # products, which the forward copied out to `ge` right after its reverse sweep and nobody reads again
+                K.copy_cols(gebar, t[3][:, sp.skip_out:], sp.E, P)
             K.chain(K.CHAIN_DBWD, P, gebar, pk["fused"][0], 8, 5, skip_layer=3, side=gebar, aux1=h, aux2=t, out=vb,
-                    out2=a2, wpack_x6=pk.get("chain_fwd_x6"))
+                    out2=a2, wpack_x6=pk.get("chain_fwd_x6"), wpack_r6=wr6)
             G.wgrad(t[0], gebar, dW[0], None, K=sp.K0, accumulate=True)
             for l in range(1, 8):
                 if l == 3:

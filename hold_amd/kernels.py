@@ -167,9 +167,13 @@ def chain(mode, P, x_in, wpack, n_layers, first_chunks, skip_layer=-1, side=None
     assert wpack.numel() == _lib.lib().hold_chain_pack_floats(first_chunks, n_layers)
     if wpack_x6 is not None:  # split-precision sweep (hold_chain_x6): same descriptor, the weights as bf16 limbs
         assert wpack_x6.numel() * wpack_x6.element_size() == _lib.lib().hold_chain_x6_pack_bytes(first_chunks, n_layers)
-    r6 = wpack_r6 is not None and mode == CHAIN_DSP  # register-resident descending sweep (hold_chain_r6): same descriptor
+    # register-resident sweeps (hold_chain_r6, csrc/rchain.hip): same descriptor.  DSP: wpack_r6 = field.pack_r6_stack of the
+    # seven matrices; DBWD: wpack_r6 = the stream of hold_trunk_r6 (field.pack_r6), and the CALLER has stored the skip
+    # layer's side columns in aux2[3][:, 217:256] (the kernel does not read `side`)
+    r6 = wpack_r6 is not None and mode in (CHAIN_DSP, CHAIN_DBWD)
     if r6:
-        assert wpack_r6.numel() * wpack_r6.element_size() == _lib.lib().hold_chain_r6_pack_bytes()
+        want = _lib.lib().hold_chain_r6_pack_bytes() if mode == CHAIN_DSP else _lib.lib().hold_trunk_r6_pack_bytes()
+        assert wpack_r6.numel() * wpack_r6.element_size() == want
         assert skip_layer == 3
     for r0 in range(0, P, _CHAIN_MAX_ROWS):
         r1 = min(P, r0 + _CHAIN_MAX_ROWS)
@@ -200,7 +204,8 @@ def chain(mode, P, x_in, wpack, n_layers, first_chunks, skip_layer=-1, side=None
         # algorithmic HBM bytes: the chain input row + per layer 1 KiB per side input and per stored result
         n_mats = sum(sum(t is not None for t in lst) for lst in (aux1, aux2, out, out2) if lst is not None)
         _g._prof_end(e0, 2.0 * (r1 - r0) * 256 * (8 * first_chunks + 256 * (n_layers - 1)),
-                     ("rchain_a2_kernel" if aux2 is not None else "rchain_kernel") if r6 else "chain_kernel",
+                     ("rchain_dbwd_kernel" if mode == CHAIN_DBWD else "rchain_a2_kernel" if aux2 is not None else "rchain_kernel")
+                     if r6 else "chain_kernel",
                      (r1 - r0) * (32.0 * first_chunks + 1024.0 * n_mats))
 
 

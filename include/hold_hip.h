@@ -373,11 +373,15 @@ int hold_chain(const hold_chain_desc* d, hold_stream_t stream);
 int64_t hold_chain_x6_pack_bytes(int32_t first_chunks, int32_t n_layers);
 int hold_chain_x6(const hold_chain_desc* d, hold_stream_t stream);
 
-/* Register-resident variant of the DESCENDING sweeps (hold_amd/csrc/rchain.hip; structure of hold_trunk_r6): the same
- * descriptor and semantics as hold_chain_x6 for mode DSP (n_layers 7, first_chunks 32, skip_layer 3; out[] entries may be
- * NULL, aux2 optional).  d->wpack = hold_chain_r6_pack_bytes() bytes: [7 x 16 k steps][8 nt][3 limbs][2 h][32 i][8 e],
- * every layer limb_t(M_j)[32 nt + i][32 (s / 2) + 16 (s % 2) + 8 (e / 4) + 4 h + e % 4] (the k order of hold_trunk_r6).
- * The ascending second-order sweep (mode DBWD) stays on hold_chain_x6: see the header of rchain.hip. */
+/* Register-resident variants of the backward sweeps (hold_amd/csrc/rchain.hip; structure of hold_trunk_r6, side inputs and
+ * results moved as whole 128-byte lines through swizzled LDS tiles): the descriptor and semantics of hold_chain_x6 for
+ *   mode DSP  (n_layers 7, first_chunks 32, skip_layer 3; out[] entries may be NULL, aux2 optional).  d->wpack =
+ *             hold_chain_r6_pack_bytes() bytes: [7 x 16 k steps][8 nt][3 limbs][2 h][32 i][8 e], every layer
+ *             limb_t(M_j)[32 nt + i][32 (s / 2) + 16 (s % 2) + 8 (e / 4) + 4 h + e % 4] (the k order of hold_trunk_r6);
+ *   mode DBWD (n_layers 8, first_chunks 5, skip_layer 3; aux1, aux2, out, out2 all given).  d->wpack = the weight stream of
+ *             hold_trunk_r6 (hold_trunk_r6_pack_bytes() bytes).  d->side is NOT read: the skip layer's side columns (the
+ *             39 columns of the chain input that become columns 217.. of out[3]) are taken from aux2[3][:, 217..255],
+ *             where the caller stores them before the launch (out2[3] is 0 in those columns, as with hold_chain_x6). */
 int64_t hold_chain_r6_pack_bytes(void);
 int hold_chain_r6(const hold_chain_desc* d, hold_stream_t stream);
 

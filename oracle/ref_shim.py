@@ -202,13 +202,16 @@ class chdir:
         os.chdir(self.old)
 
 
-def build_holdnet(scene: dict, seed: int = 1, perturb: float = 0.02):
-    """Construct the reference HOLDNet on CPU under seed (reset_all_seeds-style)."""
+def build_holdnet(scene: dict, seed: int = 1, perturb: float = 0.02, sampler: dict = None):
+    """Construct the reference HOLDNet on CPU under seed (reset_all_seeds-style).  sampler: overrides of
+    confs/general.yaml's model.ray_sampler block (BASELINE.json configs[0] / configs[4]: N_samples = 32 / 128)."""
     install()
     from src.hold.hold_net import HOLDNet
 
     opt = load_opt()
     opt.model.scene_bounding_sphere = scene["scene_bounding_sphere"]
+    if sampler:
+        opt.model.ray_sampler.update(sampler)
     args = make_args(n_images=scene["n_frames"])
     wd = prepare_workdir(scene)
     torch.manual_seed(seed)

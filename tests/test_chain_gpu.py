@@ -32,10 +32,11 @@ ARITH_BWD = ARITH + ["r6"]  # descending sweeps: + hold_chain_r6, the register-r
 
 
 def _r6_stream(mode, mats):
-    """weight stream of hold_chain_r6 (hold_amd/field.py:pack_r6_stack)"""
+    """weight stream of hold_chain_r6: DSP = field.pack_r6_stack of the 7 matrices, DBWD = field.pack_r6 (hold_trunk_r6's)"""
     from hold_amd import field as F
-    assert mode == "dsp"
-    return F.pack_r6_stack(torch.stack(mats))
+    if mode == "dsp":
+        return F.pack_r6_stack(torch.stack(mats))
+    return F.pack_r6(mats[0], torch.stack(mats[1:]))
 
 
 class _Guarded:
@@ -114,8 +115,8 @@ def test_chain_descending_dsp(P, with_a2, arith):
         cur = out[j].double()
 
 
-@pytest.mark.parametrize("arith", ARITH)
-@pytest.mark.parametrize("P", [200, 128 * 256 + 64])
+@pytest.mark.parametrize("arith", ARITH_BWD)
+@pytest.mark.parametrize("P", [200, 128 * 256 + 64, 128 * 513 + 1])
 def test_chain_second_order_dbwd(P, arith):
     from hold_amd import kernels as K
     dev = _dev()
@@ -130,8 +131,11 @@ def test_chain_second_order_dbwd(P, arith):
     x0, Ws = x0.to(dev), [w.to(dev) for w in Ws]
     g1, g2 = _Guarded(8, P, dev), _Guarded(8, P, dev)
     o1, o2 = g1.views, g2.views
+    if arith == "r6":  # contract of hold_chain_r6 (DBWD): the skip layer's side columns come from aux2[3][:, 217:256]
+        ts[3][:, SK:] = x0[:, :39]
     K.chain(K.CHAIN_DBWD, P, x0, _pack(Ws), 8, 5, skip_layer=3, side=x0, aux1=hs, aux2=ts, out=o1, out2=o2,
-            wpack_x6=_pack_x6(Ws, 48) if arith == "f32x6" else None)
+            wpack_x6=_pack_x6(Ws, 48) if arith == "f32x6" else None,
+            wpack_r6=_r6_stream("dbwd", Ws) if arith == "r6" else None)
     g1.check()
     g2.check()
     cur = x0.double()

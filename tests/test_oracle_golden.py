@@ -74,15 +74,29 @@ def test_train_forward_backward_matches_reference(gold_dir):
     assert abs(float(loss) - float(g["loss"])) < 2e-5
     assert np.abs(out["rgb"].detach().numpy() - g["out.rgb"]).max() < 1e-3
     loss.backward()
-    for name in ["nodes.right.params.pose.weight", "nodes.right.params.transl.weight", "nodes.object.params.transl.weight",
-                 "nodes.right.density.beta", "nodes.object.density.beta", "nodes.right.params.global_orient.weight"]:
+    # EVERY gradient tensor the reference recorded (dense layers, density betas, frame latents, pose / shape / translation
+    # tables): relative to the reference tensor's norm.  Measured worst 1.3e-4 (fp32 summation order of
+    # the two autograd graphs); the GPU suite holds the HIP path to 2e-4 of the oracle's fp64 autograd on the same tensors.
+    names = [k[5:] for k in g if k.startswith("grad.")]
+    assert len(names) >= 100, len(names)
+    worst = ("", 0.0)
+    for name in names:
+        ref = g["grad." + name]
+        assert sdg[name].grad is not None, name
         og = sdg[name].grad.numpy()
-        rel = np.linalg.norm(og - g["grad." + name]) / (np.linalg.norm(g["grad." + name]) + 1e-12)
-        assert rel < 5e-3, (name, rel)
-    for name in ["nodes.right.implicit_network.lin4.weight_v", "nodes.object.rendering_network.lin2.weight_v",
-                 "background.bg_implicit_network.lin5.weight"]:
+        if og.size > 4096:  # recorded as a strided sample of 1 024 elements (scripts/make_golden.py); gradnorm.* covers the whole
+            og = og.reshape(-1)[:: max(1, og.size // 1024)][:1024]
+        nr = np.linalg.norm(ref)
+        if nr == 0.0:
+            assert np.abs(og).max() == 0.0, name
+            continue
+        rel = np.linalg.norm(og - ref) / nr
+        worst = max(worst, (name, rel), key=lambda t: t[1])
+        assert rel < 3e-4, (name, rel)
+    for name in [k[9:] for k in g if k.startswith("gradnorm.")]:
         gn = float(sdg[name].grad.norm())
-        assert abs(gn - float(g["gradnorm." + name])) / float(g["gradnorm." + name]) < 5e-3, name
+        assert abs(gn - float(g["gradnorm." + name])) / float(g["gradnorm." + name]) < 3e-4, name
+    print("worst gradient tensor vs the reference:", worst)
 
 
 def test_fitting_losses_match_reference(gold_dir):
