@@ -162,11 +162,17 @@ class _WeightNormFn(torch.autograd.Function):
         L = ctx.L
         sv = ctx.saved_tensors
         vs, gs = sv[:L], sv[L:]
-        direct = [dW[i] is not None and getattr(vs[i], "_hold_bucket", False) and vs[i].grad is not None
-                  and getattr(gs[i], "_hold_bucket", False) and gs[i].grad is not None for i in range(L)]
+        # inputs: (L, v_0..v_{L-1}, g_0..g_{L-1}) -- a layer whose v AND g need no gradient (frozen after FlatAdam was built,
+        # or excluded by backward(inputs=...)) is skipped altogether: the in-place path must not write gradients autograd
+        # was told not to produce (round-3 advisor)
+        need = [ctx.needs_input_grad[1 + i] or ctx.needs_input_grad[1 + L + i] for i in range(L)]
+        direct = [dW[i] is not None and need[i] and getattr(vs[i], "_hold_bucket", False) and vs[i].grad is not None
+                  and getattr(gs[i], "_hold_bucket", False) and gs[i].grad is not None
+                  and ctx.needs_input_grad[1 + i] and ctx.needs_input_grad[1 + L + i] for i in range(L)]
         dv, dg = [None] * L, [None] * L
+        keep = []  # contiguous copies of incoming gradients stay alive until their launch has been issued
         for mode in (True, False):  # one launch for the layers accumulated in place, one for those returned to autograd
-            idx = [i for i in range(L) if dW[i] is not None and direct[i] == mode]
+            idx = [i for i in range(L) if dW[i] is not None and need[i] and direct[i] == mode]
             if not idx:
                 continue
             d = _lib.WnDesc()
@@ -177,6 +183,7 @@ class _WeightNormFn(torch.autograd.Function):
                 off = 0
             for j, i in enumerate(idx):
                 v, g, D = vs[i], gs[i], dW[i].contiguous()
+                keep.append(D)
                 l = d.layers[j]
                 if mode:
                     tv, tg = v.grad, g.grad

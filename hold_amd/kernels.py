@@ -134,7 +134,12 @@ def fused_sdf_r6(xc, P, wpack_r6, bias8, w8, b8, barf_w, out_sdf):
     _g._prof_end(e0, 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256), "fused_sdf_kernel", 20.0 * P)
 
 
-_TRUNK_MAX_ROWS = ((1 << 32) // 1024 - 1) // 128 * 128
+def _max_rows(ld):
+    """largest row count per launch of the kernels with 32-bit byte offsets: they reject (P + 128) * ld * 4 >= 2^32"""
+    return ((1 << 32) // (4 * ld) - 129) // 128 * 128
+
+
+_TRUNK_MAX_ROWS = _max_rows(256)
 
 
 def trunk_r6(xc, P, wpack_r6, bias8, barf_w, h):
@@ -144,8 +149,9 @@ def trunk_r6(xc, P, wpack_r6, bias8, barf_w, h):
     from . import gemm as _g
     ld = h[0].stride(0)
     assert all(t.stride(0) == ld and t.stride(1) == 1 for t in h)
-    for r0 in range(0, P, _TRUNK_MAX_ROWS):
-        n = min(_TRUNK_MAX_ROWS, P - r0)
+    step = min(_TRUNK_MAX_ROWS, _max_rows(ld))
+    for r0 in range(0, P, step):
+        n = min(step, P - r0)
         arr = (C.c_void_p * 8)(*[t[r0:].data_ptr() for t in h])
         e0 = _g._prof_begin()
         call("hold_trunk_r6", ptr(xc[r0:]), _ld(xc), n, ptr(wpack_r6), ptr(bias8), ptr(barf_w), arr, ld)
@@ -155,7 +161,7 @@ def trunk_r6(xc, P, wpack_r6, bias8, barf_w, h):
 CHAIN_SOFTPLUS, CHAIN_DSP, CHAIN_DBWD = 0, 1, 2
 
 
-_CHAIN_MAX_ROWS = ((1 << 32) // 1024 - 1) // 128 * 128  # 32-bit byte offsets inside the kernel (ld = 256)
+_CHAIN_MAX_ROWS = _max_rows(256)  # 32-bit byte offsets inside the kernel (ld = 256)
 
 
 def chain(mode, P, x_in, wpack, n_layers, first_chunks, skip_layer=-1, side=None, bias=None, aux1=None, aux2=None,

@@ -83,24 +83,51 @@ class Loss(nn.Module):
         # ray-chunked steps (hold_amd.train.train_step): off-surface ray counts per node, accumulated on the device over
         # the chunks of the running step / the completed previous step
         self._off_acc, self._off_prev = {}, {}
+        # ray tiles of ONE frame spread over ranks (bench.py --split rays): set to a process group (or True for the default
+        # group) and the previous step's off-surface counts are summed over the ranks -- one all-reduce of a scalar per node
+        # and step -- so that every rank normalises by the frame's exact count; `count_reduce` is the hook it goes through
+        self.sync_group = None
+        self.count_reduce = None
 
-    def _chunked_sparse_den(self, nid, cnt, first_chunk, scale):
+    def _chunked_sparse_den(self, nid, cnt, first_chunk, chunk_scale, own_scale, covers_all):
         """Denominator of a node's opacity-sparsity mean in a ray-chunked step.  The reference takes the mean over the
         off-surface rays of the WHOLE batch (loss_terms.get_opacity_sparse_loss); a chunk only knows its own count, and
         the later chunks' counts do not exist yet when this chunk is backpropagated.  Chunks are therefore normalised
-        by the previous step's whole-batch count (exact in steady state: the count moves by a few rays per step), in the
-        first step by the chunk's own count scaled to the batch -- so that the chunk terms ADD UP to one batch mean
-        instead of to `n_chunks` means.  Everything stays on the device (no host sync)."""
+        by the previous step's count of the rays THIS PROCESS owns, scaled to the whole batch by `own_scale` = batch rays /
+        owned rays (1 unless the batch is a frame whose ray tiles are spread over ranks, bench.py --split rays: then every
+        rank estimates the whole-frame count -- or, with `sync_group` / `count_reduce` set, knows it exactly from one scalar
+        all-reduce per node and step -- and the ranks' terms ADD UP to one frame mean (round-3 advisor), in the
+        first step by the chunk's own count scaled to the batch by `chunk_scale` -- so that the chunk terms add up to one
+        batch mean instead of to `n_chunks` means.  A chunk that IS the whole batch uses its exact count.  Everything stays
+        on the device (no host sync)."""
         cnt = cnt.detach()
         if first_chunk:
             if nid in self._off_acc:
-                self._off_prev[nid] = self._off_acc[nid]
+                prev = self._off_acc[nid]
+                red = self.count_reduce or (self._allreduce_count if self.sync_group is not None else None)
+                if red is not None and own_scale != 1.0:
+                    prev = red(prev)  # the frame's exact count of the previous step
+                    self._off_total = getattr(self, "_off_total", set()) | {nid}
+                self._off_prev[nid] = prev
             self._off_acc[nid] = cnt.clone()
         else:
             self._off_acc[nid] = self._off_acc.get(nid, torch.zeros_like(cnt)) + cnt
+        if covers_all:
+            return cnt
         prev = self._off_prev.get(nid)
-        est = cnt * scale
-        return est if prev is None else torch.where(prev > 0, prev, est)
+        est = cnt * chunk_scale
+        if prev is None:
+            return est
+        if nid in getattr(self, "_off_total", ()):
+            own_scale = 1.0
+        return torch.where(prev > 0, prev * own_scale, est)
+
+    def _allreduce_count(self, t):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            t = t.clone()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=None if self.sync_group is True else self.sync_group)
+        return t
 
     def forward(self, batch, model_outputs):
         rgb = model_outputs["rgb"]
@@ -120,10 +147,13 @@ class Loss(nn.Module):
         sem_loss = sums[1] / n_total
         opacity_sparse_loss = 0.0
         chunked = "hold_amd.n_total" in batch
+        # rays this process owns in the step (train_step): the whole batch, or its ray tile of a frame shared between ranks
+        rays_owned = float(batch.get("hold_amd.rays_owned", n_total))
         for i, nid in enumerate(node_ids):
             num, cnt = sums[3 + 2 * i], sums[4 + 2 * i]
             if chunked:
-                den = self._chunked_sparse_den(nid, cnt, bool(batch.get("hold_amd.frame_terms", True)), n_total / float(N))
+                den = self._chunked_sparse_den(nid, cnt, bool(batch.get("hold_amd.frame_terms", True)), n_total / float(N),
+                                               n_total / rays_owned, float(N) == n_total)
                 # a chunk without off-surface rays contributes 0 (0 / 0 would poison the accumulated gradient bucket)
                 opacity_sparse_loss = opacity_sparse_loss + torch.where(den > 0, num / den.clamp_min(1.0), torch.zeros_like(num))
             else:
@@ -138,14 +168,17 @@ class Loss(nn.Module):
                 nid = k.split(".")[0]
                 mano_cano_loss = mano_cano_loss + get_mano_cano_loss(model_outputs[f"{nid}.pred_sdf"],
                                                                      model_outputs[k].detach(), 0.01)
+        # per-frame terms (evaluated once per process, with its first chunk): with the frame's ray tiles spread over ranks
+        # whose gradients are SUMMED, each rank contributes its share of the frame -- not the whole term once per rank
+        share = rays_owned / n_total if chunked else 1.0
         progress = min(self.milestone, int(model_outputs["step"]))
         w_sem = 1.1 + (0.1 - 1.1) * progress / self.milestone  # torch.linspace(1.1, 0.1, milestone + 1)[progress]
         w_sparse = progress / self.milestone
         loss_dict = {"loss/rgb": rgb_loss * 1.0, "loss/sem": sem_loss * w_sem}
         eikonal_loss = eikonal_loss * 0.00001
-        if torch.is_tensor(eikonal_loss):  # loss.py:86-88 without the host sync
-            loss_dict["loss/eikonal"] = torch.where(eikonal_loss > 0.0008, eikonal_loss, torch.zeros_like(eikonal_loss))
-        loss_dict["loss/mano_cano"] = mano_cano_loss * 5.0
+        if torch.is_tensor(eikonal_loss):  # loss.py:86-88 without the host sync (the threshold acts on the whole term)
+            loss_dict["loss/eikonal"] = torch.where(eikonal_loss > 0.0008, eikonal_loss, torch.zeros_like(eikonal_loss)) * share
+        loss_dict["loss/mano_cano"] = mano_cano_loss * (5.0 * share)
         loss_dict["loss/opacity_sparse"] = opacity_sparse_loss * w_sparse
         loss_dict["loss"] = sum(loss_dict[k] for k in list(loss_dict.keys()))
         return loss_dict

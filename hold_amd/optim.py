@@ -100,18 +100,81 @@ class FlatAdam:
         return 1.0
 
     def rehome(self):
-        """re-attach parameters whose storage left the bucket (``net.to()`` / ``.float()`` / ``p.data = ...`` after
-        construction, e.g. GenericParams.init_parameters): their current values are copied in -- without this step()
-        would keep updating the bucket while the model reads the detached storage."""
+        """re-attach parameters whose storage left the bucket (``.float()`` / ``p.data = ...`` after construction, e.g.
+        GenericParams.init_parameters): their current values are copied in and their ``.grad`` views are re-attached --
+        without this step() would keep updating the bucket while the model reads the detached storage.  A parameter that
+        was moved to ANOTHER DEVICE (``net.to(other)`` after the optimiser was built) is an error: silently pulling it
+        back would leave the model split over two devices -- build the optimiser after placing the model."""
         moved = 0
         with torch.no_grad():
             for p, off in zip(self.params, self.offsets):
                 if p.data_ptr() != self.flat.data_ptr() + 4 * off:
+                    if p.device != self.flat.device:
+                        raise RuntimeError(f"FlatAdam: a parameter now lives on {p.device}, the bucket on {self.flat.device}: "
+                                           "construct FlatAdam after moving the model")
                     k = p.numel()
-                    self.flat[off:off + k].copy_(p.data.reshape(-1).to(self.flat.device, torch.float32))
+                    self.flat[off:off + k].copy_(p.data.reshape(-1).to(torch.float32))
                     p.data = self.flat[off:off + k].view(p.shape)
+                    stray = p.grad if (p.grad is not None and p.grad.data_ptr() != self.grad.data_ptr() + 4 * off) else None
+                    p.grad = self.grad[off:off + k].view(p.shape)
+                    if stray is not None and stray.device == self.grad.device:
+                        p.grad.add_(stray.reshape(p.shape))
+                    p._hold_bucket = True
                     moved += 1
         return moved
+
+    # ---- interchange with torch.optim.Adam (what the reference's Lightning checkpoints hold: per-parameter `step`,
+    # `exp_avg`, `exp_avg_sq`, code/src/hold/hold.py:79-101).  The reference builds its parameter groups from python sets,
+    # so a checkpoint's parameter INDICES carry no stable meaning; the exchange is therefore by parameter identity (a
+    # torch optimiser built over this model's parameters) or by parameter name.
+    def named_state(self):
+        """{parameter name: {"step", "exp_avg", "exp_avg_sq"}} -- Adam's per-parameter state as torch.optim.Adam keeps it"""
+        names = {id(p): n for n, p in self.net.named_parameters()}
+        out = {}
+        for p, off in zip(self.params, self.offsets):
+            k = p.numel()
+            out[names[id(p)]] = {"step": torch.tensor(float(self.step_count)),
+                                 "exp_avg": self.m[off:off + k].view(p.shape).clone(),
+                                 "exp_avg_sq": self.v[off:off + k].view(p.shape).clone()}
+        return out
+
+    def load_named_state(self, state):
+        """inverse of named_state(); every bucket parameter must be present, all with the same step count"""
+        names = {id(p): n for n, p in self.net.named_parameters()}
+        steps = set()
+        for p, off in zip(self.params, self.offsets):
+            st = state[names[id(p)]]
+            k = p.numel()
+            self.m[off:off + k].copy_(st["exp_avg"].reshape(-1).to(self.m.device))
+            self.v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1).to(self.v.device))
+            steps.add(int(st["step"]))
+        if len(steps) != 1:
+            raise ValueError(f"FlatAdam keeps ONE step count for all parameters; the given state has {sorted(steps)}")
+        self.step_count = steps.pop()
+
+    def torch_optimizer(self):
+        """a torch.optim.Adam over this model's parameters with the reference's groups (pose tables at 0.1 lr, everything
+        else at lr) carrying this optimiser's state: what `HOLD.configure_optimizers` would hold at this point"""
+        low = self.params[:sum(1 for o in self.offsets if o < self.n_low)]
+        main = self.params[len(low):]
+        groups = ([{"params": low, "lr": self.lr * self.pose_lr_scale}] if low else []) + \
+                 ([{"params": main, "lr": self.lr}] if main else [])
+        opt = torch.optim.Adam(groups, lr=self.lr, betas=tuple(self.betas), eps=self.eps)
+        self.export_to(opt)
+        return opt
+
+    def export_to(self, opt):
+        """write Adam's moments and step count into a torch optimiser built over the same parameter objects"""
+        for p, off in zip(self.params, self.offsets):
+            k = p.numel()
+            opt.state[p] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.m[off:off + k].view(p.shape).clone(),
+                            "exp_avg_sq": self.v[off:off + k].view(p.shape).clone()}
+
+    def import_from(self, opt):
+        """read them back from a torch optimiser (e.g. after `opt.load_state_dict(reference_checkpoint)`)"""
+        names = {id(p): n for n, p in self.net.named_parameters()}
+        self.load_named_state({names[id(p)]: opt.state[p] for p in self.params})
 
     def state_dict(self):
         """optimiser state for checkpoint / resume (the reference's Lightning checkpoints carry Adam's moments and step

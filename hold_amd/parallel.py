@@ -46,3 +46,9 @@ def shard_frames(frame_ids, rank, world):
     n = len(frame_ids)
     per = (n + world - 1) // world
     return frame_ids[rank * per:(rank + 1) * per]
+
+
+def ray_tile(n_rays, rank, world):
+    """[lo, hi) of the contiguous ray tile rank `rank` of `world` owns of one frame (bench.py --split rays): balanced -- sizes
+    differ by at most one ray, no rank is left without rays while n_rays >= world -- and exhaustive."""
+    return n_rays * rank // world, n_rays * (rank + 1) // world

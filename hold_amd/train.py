@@ -65,7 +65,8 @@ def train_step(net, inp, chunk_rays, step=0, epoch=0, loss_fn=None, n_total=None
     .grad.  Per-frame (not per-ray) loss terms -- eikonal, MANO-canonical -- are evaluated with the first chunk only;
     the BARF counter steps once per call (the reference steps it once per training_step).
     ``n_total``: the ray count the ray-wise loss terms are normalised by (default: the rays of ``inp``; a rank that owns a
-    ray tile of a frame passes the frame's total so that the ranks' gradients ADD UP to the whole-frame gradient).
+    ray tile of a frame passes the frame's total so that the ranks' gradients ADD UP to the whole-frame gradient -- the
+    opacity-sparsity denominator and the per-frame terms are scaled by the tile's share of the frame, hold_amd.loss.Loss).
     Returns (loss -- a device scalar, read it once per step at most --, rays processed)."""
     B, P = inp["uv"].shape[:2]
     n_total = B * P if n_total is None else int(n_total)
@@ -78,6 +79,7 @@ def train_step(net, inp, chunk_rays, step=0, epoch=0, loss_fn=None, n_total=None
             c = with_params(net, chunked_input(inp, lo, hi), epoch, step)  # pose-table lookups: one graph per chunk
             c["hold_amd.frame_terms"] = ci == 0
             c["hold_amd.n_total"] = n_total
+            c["hold_amd.rays_owned"] = B * P
             out = net(c)
             if loss_fn is None:
                 loss, _ = pixel_losses(out, c["gt.rgb"].reshape(-1, 3), c["gt.mask"].reshape(-1), n_total, step)

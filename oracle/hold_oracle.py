@@ -210,6 +210,44 @@ def sampler_round(z_vals, sdf, beta, beta0, eps=0.1, beta_iters=10):
     return beta, dists, d_star, weights, trans
 
 
+def round_cdf(z_vals, sdf, beta, more, add_tiny=1e-6):
+    """the CDF a round samples from (ray_sampler.py:247-293), given the round's final beta: the error-bound pdf while the
+    hierarchy grows (`more`), the rendering weights + 1e-5 in the last round.  Any float dtype (the parity tests evaluate
+    it in fp64 to bound the conditioning of the inverse-CDF stage)."""
+    dists, d_star = d_star_bound(z_vals, sdf)
+    density = laplace_density(sdf, beta.unsqueeze(-1))
+    dists_e = torch.cat([dists, torch.full((dists.shape[0], 1), 1e10, dtype=sdf.dtype)], -1)
+    fe = dists_e * density
+    sfe = torch.cat([torch.zeros(dists.shape[0], 1, dtype=sdf.dtype), fe[:, :-1]], -1)
+    trans = torch.exp(-torch.cumsum(sfe, -1))
+    if more:
+        eps_sec = torch.exp(-d_star / beta.unsqueeze(-1)) * (dists ** 2.0) / (4 * beta.unsqueeze(-1) ** 2)
+        bo = (torch.clamp(torch.exp(torch.cumsum(eps_sec, -1)), max=1.0e6) - 1.0) * trans[:, :-1]
+        pdf = bo + add_tiny
+    else:
+        pdf = ((1 - torch.exp(-fe)) * trans)[..., :-1] + 1e-5
+    pdf = pdf / pdf.sum(-1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    return torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+
+
+def inv_cdf_conditioning(z_vals, sdf, beta, more, u, eps_c, add_tiny=1e-6):
+    """fp64 inverse-CDF samples of a round and, per sample, how far it moves when its CDF argument moves by +- eps_c (the
+    size of fp32 rounding differences between two evaluations of the same CDF): (z64[N,n], spread[N,n]).  Where the CDF
+    is flat (no mass: empty space behind / in front of the surface) a sample is defined only up to the width of the flat
+    stretch -- that is the discontinuity of the stage, and `spread` measures it sample by sample."""
+    z, s, b, u = z_vals.double(), sdf.double(), beta.double(), u.double()
+    cdf = round_cdf(z, s, b, more, add_tiny)
+    z0 = inv_cdf(cdf, z, u.contiguous())
+    lo = inv_cdf(cdf, z, torch.clamp(u - eps_c, min=0.0).contiguous())
+    hi = inv_cdf(cdf, z, torch.clamp(u + eps_c, max=1.0).contiguous())
+    # u = 1 exactly sits on the end of the CDF: an evaluation whose last knot rounds above 1 finds it inside the last
+    # stretch of mass, one whose last knot is <= 1 returns the last bin edge
+    last = z[:, -1:].expand_as(z0)
+    hi = torch.where(u >= 1.0 - eps_c, torch.maximum(hi, last), hi)
+    return z0, torch.maximum(hi, z0) - torch.minimum(lo, z0)
+
+
 def error_bound_sample(z_vals, sdf_fn, cam_loc, ray_dirs, beta0, R, is_training=False, rng=None,
                        N_samples=64, N_eval=128, N_extra=32, eps=0.1, beta_iters=10, max_iters=5,
                        add_tiny=1e-6, near=0.0, trace=None, sync=None):
@@ -239,18 +277,8 @@ def error_bound_sample(z_vals, sdf_fn, cam_loc, ray_dirs, beta0, R, is_training=
             bmax = sync(bmax)
         not_converge = bool(bmax > float(beta0))
         more = not_converge and total_iters < max_iters
-        if more:
-            n_new = N_eval
-            eps_sec = torch.exp(-d_star / beta.unsqueeze(-1)) * (dists ** 2.0) / (4 * beta.unsqueeze(-1) ** 2)
-            e_int = torch.cumsum(eps_sec, -1)
-            bo = (torch.clamp(torch.exp(e_int), max=1.0e6) - 1.0) * trans[:, :-1]
-            pdf = bo + add_tiny
-        else:
-            n_new = N_samples
-            pdf = weights[..., :-1] + 1e-5
-        pdf = pdf / pdf.sum(-1, keepdim=True)
-        cdf = torch.cumsum(pdf, -1)
-        cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+        n_new = N_eval if more else N_samples
+        cdf = round_cdf(z_vals, sdf, beta, more, add_tiny)
         if more or not is_training:
             u = torch.linspace(0.0, 1.0, steps=n_new, dtype=dt).unsqueeze(0).repeat(N, 1)
         else:

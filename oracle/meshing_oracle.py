@@ -3,7 +3,9 @@
 
 The reference extracts the zero level set of the canonical SDF with MISE (code/src/libmise/mise.pyx) + skimage's
 Lewiner marching cubes (scikit-image is not installed here and not vendored in /root/reference: **parity with
-skimage's triangulation is unpinned**).  Both the reference and hold_amd/meshing.py triangulate the same object -- the
+skimage's triangulation is unpinned**).  The MISE refinement itself IS pinned: `MISE` below restates it and
+tests/test_meshing_cpu.py compares it, query by query and in the final dense grid, with the reference's own module
+compiled by oracle/build_ref.py (oracle/_ref/mise.so).  Both the reference and hold_amd/meshing.py triangulate the same object -- the
 piecewise-linear interpolant of the grid samples -- so this oracle is pinned against closed-form level sets instead
 (tests/test_oracle_golden.py: sphere area / volume / vertex residuals) and restates the product's method (marching
 tetrahedra on the Kuhn decomposition) *without its case tables*: every tetrahedron is cut from its actual values and
@@ -234,3 +236,97 @@ def point_to_tris(pts, tris, chunk=256):
         q = sel((d1 <= 0) & (d2 <= 0), np.broadcast_to(a, q.shape), q)
         out[i0:i0 + chunk] = np.sqrt(((p - q) ** 2).sum(-1)).min(1)
     return out
+
+
+# ------------------------------------------------------------------------------------------ MISE (round 4)
+class MISE:
+    """code/src/libmise/mise.pyx:37-370 restated on dense numpy arrays: an octree over [0, R]^3 (R = resolution_0 << depth)
+    whose leaves are refined wherever their 8 corners straddle `threshold`.  Same interface as the reference's extension
+    type (query / update / to_dense, .resolution); the order of the points `query()` returns is NOT part of the contract
+    (the reference's is the insertion order of a std::vector; callers only pair it with `update`).
+
+      __cinit__ (:46-87)       resolution_0^3 leaf voxels of size 1 << depth, the (resolution_0 + 1)^3 lattice points unknown
+      query (:105-127)         the lattice points without a value
+      update (:89-103)         store values, then subdivide_voxels (:186-233): every KNOWN point marks the up to 8 LEAF voxels
+                               around it (offsets -1 / 0 per axis, :200-216) `next_to_positive` if value >= threshold and
+                               `next_to_negative` if value <= threshold; a leaf above the finest level with both marks is
+                               split into 8 (:235-283) and the 27 points of its 3 x 3 x 3 lattice are created if missing
+      to_dense (:129-163)      values at the known points; the rest forward-filled along x, then y, then z
+    """
+
+    def __init__(self, resolution_0, depth, threshold):
+        self.resolution_0, self.depth, self.threshold = int(resolution_0), int(depth), float(threshold)
+        self.voxel_size_0 = 1 << self.depth
+        self.resolution = R = self.resolution_0 * self.voxel_size_0
+        self.leaf_level = np.zeros((R, R, R), dtype=np.int8)  # level of the leaf voxel that covers each finest cell
+        self.value = np.full((R + 1,) * 3, np.nan)
+        self.known = np.zeros((R + 1,) * 3, dtype=bool)
+        self.exists = np.zeros((R + 1,) * 3, dtype=bool)
+        lat = np.arange(0, R + 1, self.voxel_size_0)
+        self.exists[np.ix_(lat, lat, lat)] = True
+
+    def query(self):
+        return np.argwhere(self.exists & ~self.known).astype(np.int64)
+
+    def update(self, points, values):
+        points = np.asarray(points)
+        assert points.shape[0] == np.asarray(values).shape[0] and points.shape[1] == 3
+        idx = tuple(points.T)
+        if not np.all(self.exists[idx]):
+            raise ValueError("Point not in grid!")
+        self.value[idx] = values
+        self.known[idx] = True
+        self._subdivide_voxels()
+
+    def _subdivide_voxels(self):
+        R, D = self.resolution, self.depth
+        pos = [np.zeros((self.resolution_0 << l,) * 3, dtype=bool) for l in range(D + 1)]
+        neg = [np.zeros((self.resolution_0 << l,) * 3, dtype=bool) for l in range(D + 1)]
+        pts = np.argwhere(self.known)
+        val = self.value[self.known]
+        for off in itertools.product((-1, 0), repeat=3):
+            adj = pts + np.array(off)
+            ok = np.all((adj >= 0) & (adj < R), axis=1)
+            a, v = adj[ok], val[ok]
+            lev = self.leaf_level[tuple(a.T)]
+            for l in range(D + 1):
+                m = lev == l
+                c = a[m] >> (D - l)
+                pos[l][tuple(c[v[m] >= self.threshold].T)] = True
+                neg[l][tuple(c[v[m] <= self.threshold].T)] = True
+        for l in range(D):  # leaves of the finest level are never split
+            size = self.voxel_size_0 >> l
+            half = size >> 1
+            for c in np.argwhere(pos[l] & neg[l]):
+                lo = c * size
+                if self.leaf_level[tuple(lo)] != l:  # (marks only ever land on leaves; kept as the reference's is_leaf test)
+                    continue
+                self.leaf_level[lo[0]:lo[0] + size, lo[1]:lo[1] + size, lo[2]:lo[2] + size] = l + 1
+                g = [lo[k] + half * np.arange(3) for k in range(3)]
+                self.exists[np.ix_(*g)] = True
+
+    def to_dense(self):
+        out = np.where(self.known, self.value, np.nan)
+        for axis in range(3):
+            for i in range(1, self.resolution + 1):
+                cur = out.take(i, axis=axis)
+                prev = out.take(i - 1, axis=axis)
+                fill = np.where(np.isnan(cur), prev, cur)
+                sl = [slice(None)] * 3
+                sl[axis] = i
+                out[tuple(sl)] = fill
+        assert not np.isnan(out).any()
+        return out
+
+
+def mise_dense_grid(func, resolution_0, depth, threshold=0.0):
+    """the query loop of generate_mesh (code/src/utils/meshing.py:20-49) around an extractor: func(points [n,3] int64 grid
+    coordinates) -> values [n]; returns (dense grid [R+1]^3, number of points evaluated, the extractor)"""
+    ext = MISE(resolution_0, depth, threshold)
+    n = 0
+    pts = ext.query()
+    while pts.shape[0] != 0:
+        ext.update(pts, np.asarray(func(pts), dtype=np.float64))
+        n += pts.shape[0]
+        pts = ext.query()
+    return ext.to_dense(), n, ext

@@ -75,7 +75,7 @@ def main():
         gold = {f"out.{k}": np_(v) for k, v in out.items()
                 if torch.is_tensor(v) and (full or "fg_weights" not in k) and (full or k == "bg_weights" or "bg_weights" not in k)}
         for nid, rec in cap.items():
-            for k in (("z_vals", "x_c", "sdf", "color", "normal", "density", "verts", "tfs") if full else ("z_vals",)):
+            for k in (("z_vals", "x_c", "sdf", "color", "normal", "density", "verts", "tfs") if full else ("z_vals", "verts")):
                 if k in rec:
                     gold[f"{nid}.{k}"] = np_(rec[k])
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), **gold)

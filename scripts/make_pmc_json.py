@@ -3,15 +3,17 @@ Unit / correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both
 reports half of wide coalesced reads, so read bytes = 2 * FETCH_SIZE * 1024."""
 import json, os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "prof_r03")
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "prof_r04")
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
 F = json.load(open(os.path.join(src, "FETCH_SIZE.json")))
 W = json.load(open(os.path.join(src, "WRITE_SIZE.json")))
 # bench.py's kernel families -> rocprof kernel names (rmlp_kernel is both the sampler query <HEAD> and the forward trunk
 # <STORE>: the counter CSV keys carry no template arguments, so its traffic is reported under its own entry too)
 groups = {"fused_sdf_kernel": ["rmlp_kernel<true,false,0>", "fused_sdf_x6p_kernel", "fused_sdf_pipe_kernel", "fused_sdf_kernel"],
           "trunk_r6_kernel": ["rmlp_kernel<false,true,0>"],
-          "rchain_kernel": ["rchain_kernel<false,0>", "rchain_kernel<true,0>", "rchain_kernel<false>", "rchain_kernel<true>"],
+          "rchain_kernel": ["rsweep_kernel<1,false,1>", "rchain_kernel<false,0>", "rchain_kernel<false>"],
+          "rchain_a2_kernel": ["rsweep_kernel<1,true,1>"],
+          "rchain_dbwd_kernel": ["rsweep_kernel<2,true,1>"],
           "rgemm_kernel": ["rgemm_kernel<0>", "rgemm_kernel<1>", "rgemm_kernel<2>"],
           "chain_kernel": ["chain_x6_kernel<1,true,16>", "chain_x6_kernel<2,true,3>", "chain_x6_kernel<1,false,16>",
                            "chain_x6_kernel<0,false,3>", "chain_kernel"],
@@ -25,13 +27,15 @@ notes = {
                     "the second-order sweep (DBWD: reads 2 + writes 2 KiB, 8 layers) of one node-chunk (P = 1.61 M points)",
     "trunk_r6_kernel": "forward trunk: 16 B in per point, 8 x 1 KiB of h stores out",
     "rchain_kernel": "descending sweep of the normal path: 1 KiB in (chain input) + per layer 1 KiB side in, 1 KiB out, 7 layers",
+    "rchain_a2_kernel": "first-order backward sweep: 1 KiB in (chain input) + per layer 2 KiB side in (h, a2), 1 KiB out, 7 layers",
+    "rchain_dbwd_kernel": "second-order ascending sweep: 160 B in + per layer 2 KiB side in (h, t), 2 KiB out (vbar, a2), 8 layers",
     "rgemm_kernel": "rendering-net layers / dgrad / lin8 features: 4 (K + 256) B per point (+ 1 KiB mask operand)",
     "gemm_nt_kernel": "per-layer GEMMs (rendering net fwd+bwd, lin8 features, d/d embedding, background): (K + N) * 4 B per "
                       "point (+ N * 4 B per aux operand of the MUL_DSP / DRELU epilogues)",
     "wgrad_kernel": "dW[N,K] = R^T X over P = 1.61 M points: (N + K) * 4 B per point = 2 KiB (3.3 GB) for the 256x256 layers; "
                     "split-K partials (<= 256 x 256 KiB) are written here and reduced by wgrad_reduce4_kernel"}
 out = {"command": "rocprofv3 --kernel-trace --pmc <C> -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile "
-                  "(one pass per counter; scripts/prof_r03.sh), chunk 16384 rays, default precision (f32x6)",
+                  "(one pass per counter; scripts/prof_r04.sh), chunk 16384 rays, default precision (f32x6)",
        "correction": "gfx950 FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md HBM section): read bytes = "
                      "2*FETCH_SIZE*1024; WRITE_SIZE taken as KiB", "kernels": {}}
 for g, names in groups.items():

@@ -304,3 +304,74 @@ def test_barf_counter_is_mirrored_on_the_host():
     assert emb._iter_host == 1234 and int(emb.alpha_iter) == 1234
     w = emb.weights("cpu")
     assert w is None or (w.shape[0] == 39 and bool(torch.isfinite(w).all()))
+
+
+def test_row_split_size_passes_the_kernels_32_bit_offset_check():
+    """hold_trunk_r6 / hold_chain_* reject (P + 128) * ld * 4 >= 2^32; the host splits larger batches by rows.  The split size
+    must itself pass that check (round-3 advisor: 4 194 176 rows at ld = 256 gave exactly 2^32) and be the largest that does."""
+    from hold_amd import kernels as K
+    for ld in (256, 260, 272, 304, 320):
+        rows = K._max_rows(ld)
+        assert rows % 128 == 0 and (rows + 128) * ld * 4 < 2 ** 32
+        assert (rows + 128 + 128) * ld * 4 >= 2 ** 32
+    assert K._TRUNK_MAX_ROWS == K._max_rows(256) == K._CHAIN_MAX_ROWS
+
+
+def test_flat_adam_state_interchange_with_torch_adam_and_rehome_errors():
+    """round-3 advisor: FlatAdam's moments must be exportable to / importable from torch.optim.Adam's per-parameter state
+    (what the reference's Lightning checkpoints carry, hold.py:79-101), and rehome() must refuse a parameter that moved to
+    another device instead of silently pulling it back.  (The bucket layout needs no GPU; step() does.)"""
+    import torch
+    from torch import nn
+    from hold_amd.optim import FlatAdam
+
+    class _Node(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.params = nn.Embedding(4, 6)
+            self.net = nn.Linear(5, 3)
+
+    class _Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.nodes = nn.ModuleDict({"right": _Node(), "object": _Node()})
+            self.bg = nn.Linear(7, 2)
+
+    torch.manual_seed(0)
+    net = _Net()
+    opt = FlatAdam(net, lr=5e-4)
+    opt.m.copy_(torch.rand(opt.n))
+    opt.v.copy_(torch.rand(opt.n))
+    opt.step_count = 17
+    t = opt.torch_optimizer()
+    assert len(t.param_groups) == 2 and t.param_groups[0]["lr"] == 5e-5 and t.param_groups[1]["lr"] == 5e-4
+    assert {id(p) for p in t.param_groups[0]["params"]} == {id(net.nodes[n].params.weight) for n in net.nodes}
+    for p, off in zip(opt.params, opt.offsets):
+        st = t.state[p]
+        assert float(st["step"]) == 17 and torch.equal(st["exp_avg"].reshape(-1), opt.m[off:off + p.numel()])
+        assert torch.equal(st["exp_avg_sq"].reshape(-1), opt.v[off:off + p.numel()])
+    sd = t.state_dict()  # torch's own (index-keyed) checkpoint format round-trips through a second torch optimiser
+    t2 = torch.optim.Adam(t.param_groups)
+    t2.load_state_dict(sd)
+    m0, v0 = opt.m.clone(), opt.v.clone()
+    opt.m.zero_(); opt.v.zero_(); opt.step_count = 0
+    opt.import_from(t2)
+    # padding elements between the 256-byte aligned pieces are not parameters: compare the parameter ranges
+    for p, off in zip(opt.params, opt.offsets):
+        assert torch.equal(opt.m[off:off + p.numel()], m0[off:off + p.numel()])
+        assert torch.equal(opt.v[off:off + p.numel()], v0[off:off + p.numel()])
+    assert opt.step_count == 17
+    named = opt.named_state()
+    assert set(named) == {n for n, p in net.named_parameters()}
+    # a parameter detached from the bucket on the same device is re-attached together with its gradient view ...
+    p = net.bg.weight
+    p.data = p.data.clone() + 1.0
+    p.grad = torch.ones_like(p)
+    assert opt.rehome() == 1
+    off = opt.offsets[[id(q) for q in opt.params].index(id(p))]
+    assert p.data_ptr() == opt.flat.data_ptr() + 4 * off and p.grad.data_ptr() == opt.grad.data_ptr() + 4 * off
+    assert float(opt.grad[off]) == 1.0
+    # ... one that moved to another device is an error
+    opt.flat = torch.empty(opt.n, device="meta")  # (no second real device here: the bucket "lives elsewhere")
+    with pytest.raises(RuntimeError):
+        opt.rehome()

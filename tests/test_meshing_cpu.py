@@ -157,3 +157,79 @@ def test_marching_tetrahedra_stays_within_half_a_voxel_of_marching_cubes():
         d1 = mo.point_to_tris(np.unique(mt.reshape(-1, 3).round(9), axis=0)[::2], mc)
         d2 = mo.point_to_tris(np.unique(mc.reshape(-1, 3).round(9), axis=0)[::2], mt)
         assert d1.max() < 0.5 * h and d2.max() < 0.5 * h, (name, d1.max() / h, d2.max() / h)
+
+
+# ------------------------------------------------------------------------------------------ MISE
+def _mise_sdfs():
+    """canonical-SDF stand-ins on the [0, 128]^3 extraction grid of generate_mesh (meshing.py:20-35): a hand-like union of
+    blobs, an object-like box with rounded edges, a torus (genus 1)"""
+    def grid_to_unit(p):
+        return (np.asarray(p, dtype=np.float64) / 128.0 - 0.5) * 1.1
+
+    def blobs(p):
+        x = grid_to_unit(p)
+        c = np.array([[0.0, 0.0, 0.0], [0.22, 0.05, 0.0], [-0.2, 0.1, 0.05], [0.05, -0.25, 0.1], [0.1, 0.2, -0.15]])
+        r = np.array([0.22, 0.1, 0.09, 0.08, 0.11])
+        return (np.linalg.norm(x[:, None, :] - c[None], axis=-1) - r[None]).min(1)
+
+    def box(p):
+        q = np.abs(grid_to_unit(p)) - np.array([0.25, 0.15, 0.3])
+        return np.linalg.norm(np.maximum(q, 0.0), axis=-1) + np.minimum(q.max(-1), 0.0) - 0.04
+
+    def torus(p):
+        x = grid_to_unit(p)
+        return np.sqrt((np.sqrt(x[:, 0] ** 2 + x[:, 1] ** 2) - 0.3) ** 2 + x[:, 2] ** 2) - 0.09
+
+    return {"blobs": blobs, "box": box, "torus": torus}
+
+
+def test_mise_restatement_equals_the_compiled_reference_module():
+    """oracle/meshing_oracle.py:MISE against the REFERENCE's own code/src/libmise/mise.pyx, compiled where it lies by
+    oracle/build_ref.py into oracle/_ref/mise.so: for the two (res_init, res_up) pairs the reference uses (mano_node.py:144-150:
+    64 / 1; object_node.py:114-119: 32 / 2), every refinement round queries the same set of grid points and the final dense
+    grids are identical."""
+    import pytest
+    from oracle import build_ref
+    from oracle import meshing_oracle as mo
+    build_ref.build()
+    ref = build_ref.load_mise()
+    if ref is None:
+        pytest.skip("oracle/_ref/mise.so not built (needs /root/reference + Cython: this container only)")
+    for name, f in _mise_sdfs().items():
+        for r0, up in ((64, 1), (32, 2)):
+            a, b = ref.MISE(r0, up, 0.0), mo.MISE(r0, up, 0.0)
+            assert a.resolution == b.resolution == 128
+            rounds = 0
+            pa, pb = a.query(), b.query()
+            while pa.shape[0] != 0 or pb.shape[0] != 0:
+                sa = {tuple(p) for p in pa.tolist()}
+                assert sa == {tuple(p) for p in pb.tolist()}, (name, r0, up, rounds, len(pa), len(pb))
+                a.update(pa, f(pa).astype(np.float64))
+                b.update(pb, f(pb).astype(np.float64))
+                pa, pb = a.query(), b.query()
+                rounds += 1
+            assert rounds >= up + 1  # (fine points on a shared face can mark a coarse neighbour in a later round)
+            assert np.array_equal(a.to_dense(), b.to_dense()), (name, r0, up)
+
+
+def test_dense_grid_has_the_level_set_of_the_mise_grid():
+    """What hold_amd/meshing.py does instead of MISE: ONE dense 129^3 query.  On SDFs whose
+    features are resolved by the coarse lattice the two grids agree at every point MISE evaluated and have the same sign at
+    every other point -- every grid cell is cut (or not) identically, so any iso-surface extractor run on either grid returns
+    the same surface; MISE only saves evaluations (here 6-9x).  A feature thinner than a coarse voxel that no coarse lattice
+    point sees is MISSED by MISE and found by the dense grid: the dense evaluation is the superset."""
+    from oracle import meshing_oracle as mo
+    ax = np.arange(129)
+    full = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    for name, f in _mise_sdfs().items():
+        dense = f(full).reshape(129, 129, 129)
+        for r0, up in ((64, 1), (32, 2)):
+            grid, n_eval, ext = mo.mise_dense_grid(f, r0, up)
+            assert np.array_equal(grid[ext.known], dense[ext.known])
+            assert np.array_equal(grid < 0, dense < 0), (name, r0, up)
+            assert n_eval < dense.size / 3
+    # a 2.5-cell ball centred in a coarse voxel of the 32 / 2 octree (coarse spacing 4 cells): no coarse corner is inside
+    def speck(p):
+        return np.linalg.norm(np.asarray(p, dtype=np.float64) - np.array([66.0, 66.0, 66.0]), axis=-1) - 1.25
+    grid, _, _ = mo.mise_dense_grid(speck, 32, 2)
+    assert not (grid < 0).any() and (speck(full) < 0).any()

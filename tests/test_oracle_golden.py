@@ -5,7 +5,7 @@ import os
 import numpy as np
 import torch
 
-from parity_common import ho, oracle_input, setup, syn
+from parity_common import ho, oracle_input, setup, syn  # noqa: F401
 
 CFG = dict(W=8, H=8, frames_eval=[1, 3], frames_train=[0, 2])
 
@@ -97,6 +97,101 @@ def test_train_forward_backward_matches_reference(gold_dir):
         gn = float(sdg[name].grad.norm())
         assert abs(gn - float(g["gradnorm." + name])) / float(g["gradnorm." + name]) < 3e-4, name
     print("worst gradient tensor vs the reference:", worst)
+
+
+def _params_input(sc, sd, frames, W):
+    b, inp = oracle_input(sc, sd, frames, W, W)
+    return b, inp
+
+
+def test_two_hand_eval_matches_reference(gold_dir):
+    """configs[3]-like scene (right + left + object) against the reference's own run: pins the oracle's 3-node merge /
+    trim (hold_utils.py:76-121) and the left-hand MANO server (mano/server.py:116-133)."""
+    g = _load(gold_dir, "twohand_eval.npz")
+    sc, sd_np, sd, osc = setup(n_frames=2, two_hands=True)
+    b, inp = _params_input(sc, sd, [0, 1], 6)
+    zo = {n: torch.from_numpy(g[f"{n}.z_vals"]) for n in sc["entities"]}
+    ex = {}
+    out = ho.holdnet_forward(osc, sd, inp, False, z_override=zo, extras=ex)
+    assert out["fg_weights"].shape[1] == 3 * 98 - 2 * 3 + 1
+    for k in [k[4:] for k in g if k.startswith("out.")]:
+        if k in out and torch.is_tensor(out[k]) and out[k].dtype.is_floating_point:
+            assert np.abs(out[k].detach().numpy() - g["out." + k]).max() < 2e-5, k
+    for n in sc["entities"]:
+        assert np.abs(ex[n]["x_c"].detach().numpy() - g[f"{n}.x_c"].reshape(-1, 3)).max() < 1e-5
+        assert np.abs(ex[n]["sdf"].detach().numpy() - g[f"{n}.sdf"].reshape(-1, 1)).max() < 2e-5
+    # ... and its own sampler lands on the reference's samples
+    o2 = ho.holdnet_forward(osc, sd, inp, False)
+    for n in sc["entities"]:
+        dz = np.abs(o2[f"{n}.z_vals"].numpy() - g[f"{n}.z_vals"])
+        assert (dz > 1e-4).mean() < 0.02 and dz.max() < 0.1, (n, dz.max())
+
+
+def test_two_hand_train_matches_reference(gold_dir):
+    """two-hand training step with the reference's recorded draws: loss and EVERY recorded gradient tensor (167)."""
+    g = _load(gold_dir, "twohand_train.npz")
+    sc, sd_np, sd, osc = setup(n_frames=2, two_hands=True)
+    sdg = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    b, inp = oracle_input(sc, sdg, [0, 1], 6, 6)
+    nodes = ["right", "left", "object"]  # the reference's node order (hold_net.py: right, left, object)
+    assert list(sc["entities"].keys()) == nodes
+    rng = {"bg_t": torch.from_numpy(g[f"rand.{2 * len(nodes)}"])}
+    for i, n in enumerate(nodes):
+        rng[n] = {"t_uniform": torch.from_numpy(g[f"rand.{2 * i}"]), "u_final": torch.from_numpy(g[f"rand.{2 * i + 1}"]),
+                  "perm": torch.from_numpy(g[f"perm.{i}"])}
+    out = ho.holdnet_forward(osc, sdg, inp, True, rng=rng, current_epoch=25, barf_alpha_iter=4000)
+    gt = torch.from_numpy(b["gt.rgb"]).view(-1, 3)
+    loss = (out["rgb"] - gt).abs().mean() + 0.1 * (out["semantics"] ** 2).mean() + 0.05 * out["normal"].sum(-1).mean()
+    assert abs(float(loss) - float(g["loss"])) < 2e-5
+    loss.backward()
+    names = [k[5:] for k in g if k.startswith("grad.")]
+    assert len(names) >= 150, len(names)
+    for name in names:
+        ref = g["grad." + name]
+        og = sdg[name].grad.numpy()
+        if og.size > 4096:
+            og = og.reshape(-1)[:: max(1, og.size // 1024)][:1024]
+        nr = np.linalg.norm(ref)
+        if nr == 0.0:
+            assert np.abs(og).max() == 0.0, name
+            continue
+        assert np.linalg.norm(og - ref) / nr < 3e-4, (name, np.linalg.norm(og - ref) / nr)
+
+
+def test_c1_c5_configs_match_reference(gold_dir):
+    """BASELINE.json configs[0] (N_samples = 32, 64 x 64 rays) and configs[4] (N_samples = 128) of the reference itself:
+    the oracle's own sampler against the reference's z_vals and, given those z, every recorded per-ray output."""
+    from hold_amd import synthetic as syn
+    mano = {"right": syn.make_mano_model(True), "left": syn.make_mano_model(False)}
+    for name, ns, W, frames in [("c1_eval", 32, 64, [0]), ("c5_eval", 128, 16, [0, 1])]:
+        g = _load(gold_dir, name + ".npz")
+        sc, sd_np, sd, _ = setup()
+        osc = ho.OracleScene(sc, mano, N_samples=ns)
+        b, inp = _params_input(sc, sd, frames, W)
+        zo = {n: torch.from_numpy(g[f"{n}.z_vals"]) for n in sc["entities"]}
+        assert zo["right"].shape[1] == ns + 2 + 32
+        if name == "c5_eval":  # C1 is 4 096 rays: its end-to-end oracle run (a minute on 8 cores) stays in make_golden_configs.py
+            o2 = ho.holdnet_forward(osc, sd, inp, False)
+            for n in sc["entities"]:
+                dz = np.abs(o2[f"{n}.z_vals"].numpy() - g[f"{n}.z_vals"])
+                assert (dz > 1e-4).mean() < 0.02 and dz.max() < 0.1, (name, n, dz.max())
+            zo_run = zo
+        else:  # a 256-ray subset of the 4 096 (rays are independent given the weights)
+            sel = torch.arange(0, 4096, 16)
+            inp = {k: (v[:, sel] if (torch.is_tensor(v) and v.dim() >= 2 and v.shape[1] == 4096) else v) for k, v in inp.items()}
+            zo_run = {n: z[sel] for n, z in zo.items()}
+        out = ho.holdnet_forward(osc, sd, inp, False, z_override=zo_run)
+        n_cmp = 0
+        for k in [k[4:] for k in g if k.startswith("out.")]:
+            if k in out and torch.is_tensor(out[k]) and out[k].dtype.is_floating_point and k not in ("ray_dirs", "cam_loc"):
+                ref = g["out." + k]
+                if name == "c1_eval":
+                    ref = ref[sel.numpy()] if ref.shape[0] == 4096 else ref
+                if ref.shape != tuple(out[k].shape):
+                    continue
+                assert np.abs(out[k].detach().numpy() - ref).max() < 2e-5, (name, k)
+                n_cmp += 1
+        assert n_cmp >= 15, (name, n_cmp)
 
 
 def test_fitting_losses_match_reference(gold_dir):

@@ -159,3 +159,116 @@ def test_ray_tiles_with_synchronised_rounds_equal_the_unsharded_call(tmp_path):
     assert all(p["it_sync"] == it_full for p in parts)
     assert torch.equal(torch.cat([p["z_sync"] for p in parts]), z_full)
     assert min(p["it_solo"] for p in parts) < it_full  # the test distinguishes the two behaviours
+
+
+# ------------------------------------------------------------------------------------------ world 4 and 8 (first contact of an 8-GPU run)
+def test_ray_tiles_partition_every_frame_size():
+    from hold_amd.parallel import ray_tile
+    for n in (8, 67, 1000, 512 * 512, 512 * 512 + 5):
+        for world in (1, 2, 3, 4, 8):
+            tiles = [ray_tile(n, r, world) for r in range(world)]
+            assert tiles[0][0] == 0 and tiles[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(tiles, tiles[1:]))
+            sizes = [hi - lo for lo, hi in tiles]
+            assert max(sizes) - min(sizes) <= 1 and min(sizes) >= 1
+
+
+class _ToyNode(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.params = torch.nn.Embedding(1, 3)  # one frame's pose row: EVERY tile's rays depend on it
+
+
+class _ToyNet(torch.nn.Module):
+    """what FlatAdam needs of HOLDNet: .nodes[*].params (pose tables, 0.1 lr) + dense parameters"""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(3)
+        self.nodes = torch.nn.ModuleDict({"right": _ToyNode()})
+        self.mlp = torch.nn.Sequential(torch.nn.Linear(3, 16), torch.nn.Softplus(beta=100), torch.nn.Linear(16, 3))
+
+    def loss_sum(self, rays, gt):
+        """ray-wise L1 term, SUM over the given rays (the caller divides by the frame's ray count)"""
+        x = rays + self.nodes["right"].params.weight[0]
+        return (self.mlp(x) - gt).abs().sum()
+
+
+def _frame(n):
+    g = torch.Generator().manual_seed(9)
+    return torch.randn(n, 3, generator=g), torch.rand(n, 3, generator=g)
+
+
+def _split_rays_worker(rank, world, port, n, out):
+    """one optimiser-step's gradient exchange of bench.py --split rays: rank r owns ray_tile(n, r, world) of ONE frame, the
+    loss is normalised by the frame's ray count, FlatAdam.allreduce averages over the ranks and grad_mul = world undoes
+    it -- the bucket must then hold the un-sharded frame gradient on every rank, whatever the tile sizes"""
+    from hold_amd.optim import FlatAdam
+    from hold_amd.parallel import ray_tile
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = _ToyNet()
+    opt = FlatAdam(net, lr=5e-4, clip_norm=0.5)
+    opt.zero_grad()
+    rays, gt = _frame(n)
+    lo, hi = ray_tile(n, rank, world)
+    (net.loss_sum(rays[lo:hi], gt[lo:hi]) / n).backward()
+    opt.gather_stray_grads()
+    grad_mul = float(world) * opt.allreduce(average=True)
+    assert dist.get_world_size() == world
+    torch.save(dict(grad=opt.grad * grad_mul, tile=(lo, hi)), out + str(rank))
+    dist.destroy_process_group()
+
+
+def _check_split_rays(tmp_path, world, n):
+    from hold_amd.optim import FlatAdam
+
+    out = str(tmp_path / f"s{world}_")
+    mp.spawn(_split_rays_worker, args=(world, _free_port(), n, out), nprocs=world, join=True)
+    net = _ToyNet()
+    opt = FlatAdam(net, lr=5e-4, clip_norm=0.5)
+    opt.zero_grad()
+    rays, gt = _frame(n)
+    (net.loss_sum(rays, gt) / n).backward()
+    opt.gather_stray_grads()
+    parts = [torch.load(out + str(r)) for r in range(world)]
+    assert parts[0]["tile"][0] == 0 and parts[-1]["tile"][1] == n
+    for p in parts:  # every rank ends with the same, complete gradient (incl. the shared pose row)
+        assert torch.allclose(p["grad"], opt.grad, atol=2e-6, rtol=1e-5), float((p["grad"] - opt.grad).abs().max())
+    assert float(opt.grad[:3].abs().sum()) > 0  # the pose row is inside the bucket and received gradient from every tile
+
+
+def test_split_rays_world4_non_divisible_tiles(tmp_path):
+    _check_split_rays(tmp_path, 4, 1003)  # tiles of 250 / 251 rays
+
+
+def test_split_rays_world8_last_tiles_short(tmp_path):
+    _check_split_rays(tmp_path, 8, 67)   # 8 or 9 rays per rank
+
+
+def _tile_worker_n(rank, world, port, n, out):
+    from hold_amd.parallel import ray_tile
+    from hold_amd.sampler import ErrorBoundSampler
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dirs, cam = _rays(n)
+    lo, hi = ray_tile(n, rank, world)
+    smp = ErrorBoundSampler(3.0)
+    smp.sync_group = True
+    z, it = _sample(dirs[lo:hi], cam[lo:hi], sync=lambda b: smp.sync_round(b, False)[0])
+    torch.save(dict(z=z, it=it), out + str(rank))
+    dist.destroy_process_group()
+
+
+def test_ray_tiles_world4_uneven_tiles_run_the_unsharded_rounds(tmp_path):
+    """the sampler's per-round MAX exchange with 4 ranks and tiles of unequal size (70 rays: 17 / 18): every tile runs the
+    round count of the un-sharded call and the concatenated z_vals are bit-identical to it"""
+    out = str(tmp_path / "u")
+    mp.spawn(_tile_worker_n, args=(4, _free_port(), 70, out), nprocs=4, join=True)
+    dirs, cam = _rays(70)
+    z_full, it_full = _sample(dirs, cam)
+    parts = [torch.load(out + str(r)) for r in range(4)]
+    assert all(p["it"] == it_full for p in parts)
+    assert torch.equal(torch.cat([p["z"] for p in parts]), z_full)

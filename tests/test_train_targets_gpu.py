@@ -457,3 +457,74 @@ def test_chunked_loss_terms_add_up_to_the_unchunked_loss():
     for k in g_full:
         assert torch.isfinite(g_part[k]).all(), k
         assert float((g_part[k] - g_full[k]).abs().max()) <= 2e-5 * float(g_full[k].abs().max()), k
+
+
+def test_ray_tile_losses_of_two_ranks_add_up_to_the_unsharded_loss():
+    """bench.py --split rays / train_step(n_total = frame rays): two ranks own the two ray tiles of ONE frame and their
+    gradients are SUMMED (FlatAdam averages, grad_mul = world undoes it).  For the FULL Loss -- ray-wise terms, the
+    opacity-sparsity mean over the frame's off-surface rays, and the per-frame terms (eikonal, MANO-canonical SDF) that
+    every rank evaluates -- the two ranks' losses and gradients must add up to the un-sharded step's, from the first step
+    on for the per-frame terms and in steady state for the sparsity term (round-3 advisor: rank-local previous counts made
+    it world x too large from step 2 on, the per-frame terms were counted once per rank)."""
+    from hold_amd.loss import Loss
+    dev = "cuda:0"
+    N, W = 2048, 2
+    g = torch.Generator().manual_seed(12)
+    r = lambda *s: torch.rand(*s, generator=g)
+    leaves = {"rgb": r(N, 3), "semantics": r(N, 4), "right.mask_prob": r(N), "object.mask_prob": r(N)}
+    # per-frame terms: the same tensors on every rank (replicated weights, same eikonal / canonical samples)
+    # (gradient norms around 12: the eikonal term passes the reference's `> 0.0008` gate, loss.py:86-88)
+    frame_leaves = {"right.grad_theta": r(1, 307, 3) * 14, "object.grad_theta": r(1, 307, 3) * 14, "right.pred_sdf": r(1, 307) * 0.02 - 0.01}
+    frame_const = {"right.pts2mano_sdf_cano": (r(1, 307) * 0.02 - 0.01).to(dev)}
+    off = {"right": r(N) > 0.5, "object": r(N) > 0.8}  # uneven over the tiles: rank-local counts differ from the frame's
+    off["object"][:N // 2] &= r(N // 2) > 0.5
+    batch = {"gt.rgb": r(N, 3).to(dev), "gt.mask": torch.tensor([0, 50, 150, 250])[torch.randint(0, 4, (N,), generator=g)].to(dev)}
+
+    def run(rank_slices, loss_fns):
+        lv = {k: v.clone().to(dev).requires_grad_(True) for k, v in {**leaves, **frame_leaves}.items()}
+        tot = {}
+        for sl, loss_fn in zip(rank_slices, loss_fns):
+            out = {k: lv[k][sl] for k in leaves}
+            out.update({k: lv[k] for k in frame_leaves})
+            out.update(frame_const)
+            out.update({f"{n}.index_off_surface": o[sl].to(dev) for n, o in off.items()}, step=15000)
+            b = {k: v[sl] for k, v in batch.items()}
+            if len(rank_slices) > 1:  # what train_step puts into the batch of a rank that owns one ray tile (one chunk)
+                b["hold_amd.n_total"], b["hold_amd.frame_terms"], b["hold_amd.rays_owned"] = N, True, sl.stop - sl.start
+            ld = loss_fn(b, out)
+            ld["loss"].backward()
+            for k, v in ld.items():
+                tot[k] = tot.get(k, 0.0) + float(v.detach() if torch.is_tensor(v) else v)
+        return tot, {k: v.grad.clone() for k, v in lv.items()}
+
+    full, g_full = run([slice(0, N)], [Loss()])
+    assert full["loss/eikonal"] > 0 and full["loss/mano_cano"] > 0 and full["loss/opacity_sparse"] > 0
+    tiles = [slice(0, N // W), slice(N // W, N)]
+    ranks = [Loss(), Loss()]
+    first, g_first = run(tiles, ranks)   # first step: the sparsity denominator is each tile's count scaled to the frame
+    for k in ("loss/rgb", "loss/sem", "loss/eikonal", "loss/mano_cano"):
+        assert first[k] == pytest.approx(full[k], rel=2e-5), (k, first[k], full[k])
+    part, g_part = run(tiles, ranks)     # steady state
+    for k in ("loss/rgb", "loss/sem", "loss/eikonal", "loss/mano_cano", "loss"):
+        assert part[k] == pytest.approx(full[k], rel=2e-5 if k != "loss" else 2e-2), (k, part[k], full[k])
+    # the sparsity term: every rank estimates the frame's count from its own tile (prev * world): the estimate differs from
+    # the true count by the tiles' imbalance, the SUM over ranks stays within it (it was `world` x off before)
+    cnt = {n: float(o.sum()) for n, o in off.items()}
+    imb = max(abs(float(o[t].sum()) * W - cnt[n]) / cnt[n] for n, o in off.items() for t in tiles)
+    assert part["loss/opacity_sparse"] == pytest.approx(full["loss/opacity_sparse"], rel=imb / (1 - imb) + 1e-4), (part, full, imb)
+    for k in g_full:
+        tol = (imb / (1 - imb) + 1e-3) if "mask_prob" in k else 2e-5  # 1 / (estimated count) against 1 / (true count)
+        assert float((g_part[k] - g_full[k]).abs().max()) <= tol * float(g_full[k].abs().max()), k
+    # with the counts summed over the ranks (Loss.sync_group: one scalar all-reduce per node and step; here the hook it goes
+    # through returns the two tiles' sum) the steady-state step is EXACT
+    ranks = [Loss(), Loss()]
+    run(tiles, ranks)
+    totals = {n: torch.tensor(float(o.sum()), device=dev) for n, o in off.items()}
+    for lf in ranks:
+        acc = dict(lf._off_acc)
+        lf.count_reduce = (lambda t, _acc=acc: next(totals[n] for n, v in _acc.items() if v is t))
+    part, g_part = run(tiles, ranks)
+    for k in ("loss/rgb", "loss/sem", "loss/eikonal", "loss/mano_cano", "loss/opacity_sparse", "loss"):
+        assert part[k] == pytest.approx(full[k], rel=2e-5), (k, part[k], full[k])
+    for k in g_full:
+        assert float((g_part[k] - g_full[k]).abs().max()) <= 2e-5 * float(g_full[k].abs().max()), k
