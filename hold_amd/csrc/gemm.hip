@@ -599,7 +599,9 @@ template <int KT, int X6 = 0, int NBUF = 2>  // X6: 0 fp32 MFMA, 1 bf16 x 6 limb
 __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restrict__ R, int ldr,
                                                            const float* __restrict__ X, int ldx, int P, int N, int K,
                                                            int splits, float* __restrict__ part,
-                                                           float* __restrict__ part_b, int remap) {
+                                                           float* __restrict__ part_b, int remap, int xcols) {
+  // xcols = floats of a row of X that exist from the X pointer on (ldx, or less when X points INTO a row: the K - 256 tail
+  // of the rendering net's first layer) -- the bound the staged columns are clamped to
   constexpr int BKW = 64 * KT;              // block width along k
   constexpr int PC = (KT == 4) ? 16 : 32;   // rows (reduction index) per stage
   constexpr int STEPS = PC / 2;
@@ -653,7 +655,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restri
         const int ins = wave * (XI / 4) + j;
         const int row = (BKW == 256) ? ins : ins * 2 + (lane >> 5);
         int col = k0 + ((BKW == 256) ? lane : (lane & 31)) * 4;
-        col = col <= ldx - 4 ? col : ldx - 4;
+        col = col <= xcols - 4 ? col : xcols - 4;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (p0 + row) * (long)ldx + col),
                                          (__attribute__((address_space(3))) void*)(sX + buf * PC * BKW + ins * 256), 16, 0, 0);
       }
@@ -672,7 +674,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restri
           *reinterpret_cast<f32x4*>(sR + buf * PC * 128 + row * 128 + c4) = z;
         } else {
           int col = k0 + c4;
-          col = col <= ldx - 4 ? col : ldx - 4;
+          col = col <= xcols - 4 ? col : xcols - 4;
           if (p < P) z = *reinterpret_cast<const f32x4*>(X + p * (long)ldx + col);
           *reinterpret_cast<f32x4*>(sX + buf * PC * BKW + row * BKW + c4) = z;
         }
@@ -816,11 +818,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restri
 }
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, long NK, int K, float* __restrict__ dW,
-                                    int lddw, int accumulate) {
+                                    int lddw, int accumulate, long pstride) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= NK) return;
   float s = 0.f;
-  for (int sp = 0; sp < splits; ++sp) s += part[(long)sp * NK + i];
+  for (int sp = 0; sp < splits; ++sp) s += part[(long)sp * pstride + i];
   const long n = i / K, k = i % K;
   float* o = dW + n * lddw + k;
   *o = accumulate ? *o + s : s;
@@ -830,14 +832,15 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, 
 // owns 64 consecutive elements (16 lanes x float4 = one 256-byte segment per partial tile), thread group g sums the
 // tiles g, g + 16, ... (independent loads in flight instead of one dependent chain of `splits` loads per thread),
 // then the 16 group sums are added in a fixed order -- deterministic, ~5x faster than the scalar version at 256 splits.
+// pstride = floats between the partial tiles (>= NK: the whole-dW kernel writes 256-row tiles of which the first N count)
 __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ part, int splits, long NK, int K,
-                                                            float* __restrict__ dW, int lddw, int accumulate) {
+                                                            float* __restrict__ dW, int lddw, int accumulate, long pstride) {
   __shared__ f32x4 red[16][16];
   const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
   const long i = ((long)blockIdx.x * 16 + e) * 4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (i < NK)
-    for (int sp = g; sp < splits; sp += 16) s += *reinterpret_cast<const f32x4*>(part + (long)sp * NK + i);
+    for (int sp = g; sp < splits; sp += 16) s += *reinterpret_cast<const f32x4*>(part + (long)sp * pstride + i);
   red[g][e] = s;
   __syncthreads();
   if (g != 0 || i >= NK) return;
@@ -994,7 +997,7 @@ extern "C" int hold_wcolsum(const float* X, int32_t ldx, int32_t N, int64_t P, c
   blocks = (P + rpb - 1) / rpb;
   hipLaunchKernelGGL(wcolsum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, ldx, N, (long)P, w, rpb, workspace);
   hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((N / 4 + 15) / 16)), dim3(256), 0, s, workspace, (int)blocks,
-                     (long)N, N, out, N, accumulate);
+                     (long)N, N, out, N, accumulate, (long)N);
   return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
 }
 
@@ -1075,7 +1078,9 @@ extern "C" int hold_gemm_nt(const hold_gemm_desc* dp, hold_stream_t stream) { re
 extern "C" int hold_gemm_nt_x6(const hold_gemm_desc* dp, hold_stream_t stream) { return gemm_nt_impl(dp, stream, 1); }
 
 extern "C" int64_t hold_wgrad_workspace_floats(int32_t N, int32_t K, int32_t splits) {
-  return (int64_t)splits * ((int64_t)N * K + N);
+  // the whole-dW kernel (K in 256..320, N in 129..256) writes partial tiles of 256 rows whatever N is
+  const int64_t Np = (N > 128 && N < 256 && K >= 256 && K <= 320) ? 256 : N;
+  return (int64_t)splits * (Np * (int64_t)K + Np);
 }
 
 // register-resident 256 x 256 variant (csrc/wgrad_r6.hip): fills <= max_splits partial tiles, returns their number
@@ -1086,14 +1091,15 @@ int hold_wgrad_r6_partials(const float* R, int ldr, const float* X, int ldx, lon
 // truncating limb split (both decompose the 24-bit significand exactly)
 static int wgrad_impl(const float* R, int32_t ldr, const float* X, int32_t ldx, int32_t P, int32_t N, int32_t K,
                       float* dW, int32_t lddw, float* db, int32_t accumulate, int32_t splits, float* workspace,
-                      hold_stream_t stream, int mode) {
+                      hold_stream_t stream, int mode, int xcols = -1) {
   if (!R || !X || !dW || !workspace || N <= 0 || K <= 0 || P < 0 || splits <= 0) return HOLD_E_ARG;
+  if (xcols < 0) xcols = ldx;  // columns of a row of X that exist from the X pointer on
   hipStream_t s = (hipStream_t)stream;
   const long chunks = ((long)P + 31) / 32;
   if (splits > chunks) splits = (int)(chunks > 0 ? chunks : 1);
   float* part = workspace;
   float* part_b = db ? workspace + (long)splits * N * K : nullptr;
-  bool lds_ok = !(ldr & 3) && !(ldx & 3) && !((uintptr_t)R & 15) && !((uintptr_t)X & 15) && ldr >= 4 && ldx >= 4;
+  bool lds_ok = !(ldr & 3) && !(ldx & 3) && !((uintptr_t)R & 15) && !((uintptr_t)X & 15) && ldr >= 4 && ldx >= 4 && xcols >= 4;
 #ifdef HOLD_DEV
   if (getenv("HOLD_WGRAD_DIRECT")) lds_ok = false;
 #endif
@@ -1105,14 +1111,30 @@ static int wgrad_impl(const float* R, int32_t ldr, const float* X, int32_t ldx, 
 #ifdef HOLD_DEV
   if (const char* w = getenv("HOLD_WGRAD_X6_TILE")) x6_wide = atoi(w) == 256;
 #endif
-  bool r6 = lds_ok && mode == 2 && N == 256 && K == 256 && (P % 16) == 0 && P >= 4096;
+  // whole-dW workgroups (csrc/wgrad_r6.hip), one wave per SIMD: each operand row read once, 3 VALU of limb split per MFMA.
+  // Taken for 256 columns of X and N in 129..256 columns of R that is at least 256 wide in memory (the kernel reads 256
+  // columns of both; rows >= N of its partial tiles are never reduced); K in 257..320: the first 256 columns of X this way,
+  // the rest by the tile kernel below through a second call (R is read twice: 1 KiB per point more than the one-kernel form).
+  bool r6 = lds_ok && mode == 2 && N > 128 && N <= 256 && ldr >= 256 && K >= 256 && K <= 320 && ldx >= K &&
+            (P % 16) == 0 && P >= 4096;
 #ifdef HOLD_DEV
   if (const char* w = getenv("HOLD_WGRAD_R6")) r6 = r6 && atoi(w) != 0;
 #endif
-  if (r6) {  // whole-dW workgroups, one wave per SIMD: each operand row read once, 3 VALU of limb split per MFMA
-    const int g = hold_wgrad_r6_partials(R, ldr, X, ldx, (long)P, splits, part, part_b, s);
+  long pstride = (long)N * K;  // floats between partial tiles
+  int Kred = K;                // columns the reduction below covers
+  if (r6) {
+    const int g = hold_wgrad_r6_partials(R, ldr, X, ldx, (long)P, splits, part, db ? part + (long)splits * 65536 : nullptr, s);
     if (g < 0) return g;
+    if (K > 256) {  // the remaining K - 256 columns of dW: tile kernel on (R, X + 256), its partials behind the first part's
+      float* ws2 = part + (long)splits * (65536 + 256);
+      const int rc = wgrad_impl(R, ldr, X + 256, ldx, P, N, K - 256, dW + 256, lddw, nullptr, accumulate, splits, ws2, stream, mode,
+                                ldx - 256);
+      if (rc != HOLD_OK) return rc;
+    }
+    part_b = db ? part + (long)splits * 65536 : nullptr;
     splits = g;
+    pstride = 65536;
+    Kred = 256;
   } else if (lds_ok && mode == 2 && x6_wide) {
     const int tiles = ((N + 127) / 128) * ((K + 255) / 256);
     const long ch = ((long)P + 15) / 16;
@@ -1122,48 +1144,49 @@ static int wgrad_impl(const float* R, int32_t ldr, const float* X, int32_t ldx, 
     if (const char* nb = getenv("HOLD_WGRAD_NBUF")) deep = atoi(nb) == 3;
     if (deep)
       hipLaunchKernelGGL((wgrad_lds_kernel<4, 2, 3>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K,
-                         splits, part, part_b, remap);
+                         splits, part, part_b, remap, xcols);
 #endif
     if (!deep)
       hipLaunchKernelGGL((wgrad_lds_kernel<4, 2>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits,
-                         part, part_b, remap);
+                         part, part_b, remap, xcols);
   } else if (lds_ok && mode != 0) {  // split-precision path (128 x 128 tiles)
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
     if (mode == 2)
       hipLaunchKernelGGL((wgrad_lds_kernel<2, 2>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits,
-                         part, part_b, remap);
+                         part, part_b, remap, xcols);
     else
       hipLaunchKernelGGL((wgrad_lds_kernel<2, 1>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits,
-                         part, part_b, remap);
+                         part, part_b, remap, xcols);
   } else if (lds_ok && K > 128) {
     const int tiles = ((N + 127) / 128) * ((K + 255) / 256);
     const long ch = ((long)P + 15) / 16;
     if (splits > ch) splits = (int)(ch > 0 ? ch : 1);
     hipLaunchKernelGGL((wgrad_lds_kernel<4>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits,
-                       part, part_b, remap);
+                       part, part_b, remap, xcols);
   } else if (lds_ok) {
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
     hipLaunchKernelGGL((wgrad_lds_kernel<2>), dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits,
-                       part, part_b, remap);
+                       part, part_b, remap, xcols);
   } else {
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
     hipLaunchKernelGGL(wgrad_kernel, dim3(tiles * splits), dim3(256), 0, s, R, ldr, X, ldx, P, N, K, splits, part,
                        part_b);
   }
-  const long NK = (long)N * K;
-  if (!(K & 3) && !(lddw & 3) && !((uintptr_t)dW & 15) && !((uintptr_t)part & 15))
-    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((NK / 4 + 15) / 16)), dim3(256), 0, s, part, splits, NK, K,
-                       dW, lddw, accumulate);
+  const long NK = (long)N * Kred;
+  if (!(Kred & 3) && !(lddw & 3) && !((uintptr_t)dW & 15) && !((uintptr_t)part & 15))
+    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((NK / 4 + 15) / 16)), dim3(256), 0, s, part, splits, NK, Kred,
+                       dW, lddw, accumulate, pstride);
   else
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((NK + 255) / 256)), dim3(256), 0, s, part, splits, NK, K, dW,
-                       lddw, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((NK + 255) / 256)), dim3(256), 0, s, part, splits, NK, Kred, dW,
+                       lddw, accumulate, pstride);
   if (db) {
+    const long bstride = r6 ? 256 : N;
     if (!(N & 3) && !((uintptr_t)db & 15) && !((uintptr_t)part_b & 15))
       hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((N / 4 + 15) / 16)), dim3(256), 0, s, part_b, splits,
-                         (long)N, N, db, N, accumulate);
+                         (long)N, N, db, N, accumulate, bstride);
     else
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, part_b, splits,
-                         (long)N, N, db, N, accumulate);
+                         (long)N, N, db, N, accumulate, bstride);
   }
   return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
 }
@@ -1225,7 +1248,7 @@ extern "C" int hold_head3_bwd(const float* dy, int32_t ldy, const float* R, int3
                      rr, ldrr, part, part_b);
   const long NK = 3L * K;
   hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((NK / 4 + 15) / 16)), dim3(256), 0, s, part, (int)blocks, NK, K,
-                     dW, lddw, accumulate);
-  hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(1), dim3(256), 0, s, part_b, (int)blocks, 4L, 4, db4, 4, accumulate);
+                     dW, lddw, accumulate, NK);
+  hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(1), dim3(256), 0, s, part_b, (int)blocks, 4L, 4, db4, 4, accumulate, 4L);
   return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
 }

@@ -144,14 +144,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     Limbs8 L0, L1;
     Frag fs[2];
     // column sums of R for the bias gradient: wave (wn, wk) keeps those of the fragments 2 wk, 2 wk + 1 -- branch-free (a
-    // wave-uniform 0 / 1 factor): a branch here would end the scheduling region and make the LDS wait counts pessimistic
-    // (and 0 for the rows prepared during the LAST step: they are the re-read of that step, not new points)
-    float sel[2] = {wk == 0 ? 1.f : 0.f, wk == 1 ? 1.f : 0.f};
+    // wave-uniform SELECT: a branch here would end the scheduling region and make the LDS wait counts pessimistic; a 0 / 1
+    // FACTOR, as in round 3, let a NaN / Inf of a column the wave does not own -- with N < 256 the columns N..255 of R are
+    // whatever the caller left there -- into the sums of the columns it owns: 0 x NaN).  Nothing is kept for the rows
+    // prepared during the LAST step: they are the re-read of that step, not new points.
+    bool sel[2] = {wk == 0, wk == 1};
     auto bias_add = [&](int f, const Frag& s) {
       if (BIAS && f < 4) {
         const f32x2 p0 = {s.x[0], s.x[1]}, p1 = {s.x[2], s.x[3]}, p2 = {s.x[4], s.x[5]}, p3 = {s.x[6], s.x[7]};
         const f32x2 q = (p0 + p1) + (p2 + p3);
-        bsum[f & 1] = fmaf(sel[f >> 1], q[0] + q[1], bsum[f & 1]);
+        const float add = sel[f >> 1] ? q[0] + q[1] : 0.f;
+        bsum[f & 1] += add;
       }
     };
     {  // limbs of the first step (not overlapped)
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const uint32_t db = (uint32_t)((int)((t + 3) % NST) * STAGE) + dst0;
       const char* p = dptr;
       dptr = (t + 4 < s1) ? dptr + 16 * rowb : dptr;
-      if (BIAS && t + 1 >= s1) sel[0] = sel[1] = 0.f;
+      if (BIAS && t + 1 >= s1) sel[0] = sel[1] = false;
 #pragma unroll
       for (int m = 0; m < 96; ++m) {
         const int aa = m / 24, pr = (m % 24) / 4, bb = m % 4;  // four accumulators in rotation
@@ -242,8 +245,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 }  // namespace
 
-// Called by hold_wgrad_x6 (gemm.hip) for N == K == 256, P a multiple of 16: fills part[G][256][256] (and part_b[G][256])
-// with G <= max_splits workgroup partials and returns G (< 0: error); the caller reduces them.
+// Called by hold_wgrad_x6 (gemm.hip) for 256 columns of R and of X, P a multiple of 16: fills part[G][256][256] (and
+// part_b[G][256]) with G <= max_splits workgroup partials and returns G (< 0: error); the caller reduces them -- all 256
+// rows, or the first N when R has fewer meaningful columns (rows are independent: what columns N..255 of R hold, NaN
+// included, only reaches the rows >= N of a partial tile).
 int hold_wgrad_r6_partials(const float* R, int ldr, const float* X, int ldx, long P, int max_splits, float* part,
                            float* part_b, hipStream_t s) {
   static int n_cu = 0;

@@ -226,11 +226,11 @@ _RPLANS = {}
 
 def render_plan(Kr, need_bwd, device):
     """gather indices of the hold_gemm_r6 packs of the rendering net from the flat source
-    [R0 zero-padded to [256, 320] | R1 | R2 | R3 (| R1^T | R2^T | R3^T)] (see pack_plan)"""
+    [R0 zero-padded to [256, 320] | R1 | R2 | R3 (| R1^T | R2^T | R3^T | (R0[:, :256])^T)] (see pack_plan)"""
     key = (Kr, bool(need_bwd), str(device))
     if key not in _RPLANS:
         n0 = 256 * 320
-        nm = 6 if need_bwd else 3
+        nm = 7 if need_bwd else 3
         N = n0 + nm * 65536
         l3 = lambda I: torch.stack([I + t * N for t in range(3)])
         I0 = torch.arange(n0, device=device).view(256, 320)
@@ -345,11 +345,14 @@ def _pack_render(pk, spec, rw, rb, need_bwd, dev):
         mats = [torch.nn.functional.pad(r0, (0, 320 - spec.Kr)).reshape(-1), R[1].reshape(-1), R[2].reshape(-1), R[3].reshape(-1)]
         if need_bwd:
             mats.append(RT123.reshape(-1))
+            # lin0's input gradient, the 256 feature columns of d_rin (rin's columns 0..255 are the feature block): the
+            # remaining 16 / 48 columns (xc, normal, pose(, time)) stay a narrow hold_gemm_nt
+            mats.append(r0[:, :256].t().contiguous().reshape(-1))
         limbs = torch.stack(split_limbs(torch.cat(mats))).reshape(-1)
         packs = limbs.index_select(0, plan["idx"]).split(plan["sizes"])
         pk["R_r6"] = list(packs[:4])
         if need_bwd:
-            pk["RT_r6"] = [None] + list(packs[4:7])
+            pk["RT_r6"] = [packs[7]] + list(packs[4:7])
     return pk
 
 
@@ -691,7 +694,11 @@ class NodeField:
             cur = nxt
         G.wgrad(cur, rin, dR[0], dRb[0], K=sp.Kr)
         d_rin = pool.get("d_rin", P, sp.Kr)
-        G.gemm_nt(cur, RT[0], d_rin, N=sp.Kr)
+        if USE_R6_GEMM and "RT_r6" in pk:  # the 256 feature columns register-resident, the 16 / 48 others a narrow GEMM
+            G.gemm_r6(cur, pk["RT_r6"][0], d_rin[:, :FEAT], K=256)
+            G.gemm_nt(cur, RT[0][FEAT:], d_rin[:, FEAT:], N=sp.Kr - FEAT)
+        else:
+            G.gemm_nt(cur, RT[0], d_rin, N=sp.Kr)
         B = n_frames
         d_pose = torch.zeros(B, 8, device=dev)
         K.frame_colsum(d_rin, RIN_POSE, 8, P, ppf, d_pose)

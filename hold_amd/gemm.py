@@ -117,6 +117,8 @@ def wgrad(R, X, dW, db=None, *, N=None, K=None, accumulate=False, splits=None):
     if splits is None:
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
         splits = max(1, min(1024 // tiles, (P + 255) // 256))
+        if config.x6() and 128 < N <= 256 and 256 <= K <= 320:  # whole-dW workgroups (csrc/wgrad_r6.hip): one per CU
+            splits = max(1, min(256, (P + 255) // 256))
     L = _lib.lib()
     ws = _workspace(L.hold_wgrad_workspace_floats(N, K, splits), R.device)
     e0 = _prof_begin()

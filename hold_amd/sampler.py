@@ -61,6 +61,14 @@ class ErrorBoundSampler:
         # run the number of rounds the un-sharded call would (set to a process group, or True for the default group)
         self.sync_group = None
         self.pool = None
+        # speculative rounds (round 4): the host reads the convergence flag ONCE per call instead of once per round -- it
+        # launches as many rounds as the previous call of this sampler took (the SDF moves slowly between optimiser steps),
+        # every round recording its max beta in its own slot, and validates all decisions afterwards: a call that needed more
+        # rounds continues from where it stands, one that converged EARLIER than predicted is redone round by round (the
+        # extra rounds changed the window).  Results are those of the round-by-round loop either way.  Off with sync_group
+        # (the data-parallel exchange is per round by definition).
+        self.speculate = True
+        self._pred_rounds = 0
         self.last_iters = 0
         self.sum_iters = 0  # rounds summed over all calls / number of calls (bench.py: FLOP per ray of a timed region)
         self.n_calls = 0
@@ -132,49 +140,86 @@ class ErrorBoundSampler:
         sdf = pool.get("sdf", N, ld)
         beta = pool.get("beta", N, 1)
         far = pool.get("far", N, 1)
-        flags = pool.get("flags", 1, 4, torch.int32)
-        flags.zero_()
+        # [0] error flag, [1 + r] max beta of round r (float bits, atomic max over the rays)
+        flags = pool.get("flags", 1, 2 + self.max_total_iters, torch.int32)
         t_rand = None
         if is_training:
             t_rand = (rng["t_uniform"] if rng is not None else self._rand((N, n0), dev)).contiguous()
-        K.sampler_init(cam_loc, ray_dirs, self.R, self.near, n0, self.eps, t_rand, z, beta, far, flags[:, 0:1])
         pts = pool.get("pts", N * n0, 4)
         sdf_new = pool.get("sdf_new", N * n0, 1)
-        samples = z  # first round: the first n0 columns of the window
         slot = pool.get("slot", N, n0, torch.int32)
         samp = pool.get("samples", N, n0)
-        S, iters = n0, 0
         beta0 = float(beta0)
         u_more = torch.linspace(0.0, 1.0, steps=n0, device=dev)
-        while True:
-            K.ray_points(cam_loc, ray_dirs, samples, n0, pts)
+        st = {}
+
+        def start():
+            flags.zero_()
+            K.sampler_init(cam_loc, ray_dirs, self.R, self.near, n0, self.eps, t_rand, z, beta, far, flags[:, 0:1])
+            st.update(S=n0, iters=0, samples=z)  # first round: the first n0 columns of the window
+
+        def run_round():
+            """SDF at the newest samples + the beta search of the round; its max beta goes to flags[1 + round]"""
+            r = st["iters"]
+            K.ray_points(cam_loc, ray_dirs, st["samples"], n0, pts)
             sdf_query(pts, N * n0, sdf_new)
-            flags[:, 1:2].zero_()
-            if iters == 0:
+            fl = flags[:, 1 + r:2 + r]
+            if r == 0:
                 K.copy_cols(sdf_new.view(N, n0), sdf, n0, N)
-                K.sampler_beta(z, sdf, S, N, None, None, 0, beta, beta0, self.eps, self.beta_iters, flags[:, 1:2])
+                K.sampler_beta(z, sdf, st["S"], N, None, None, 0, beta, beta0, self.eps, self.beta_iters, fl)
             else:
-                K.sampler_beta(z, sdf, S, N, sdf_new, slot, n0, beta, beta0, self.eps, self.beta_iters,
-                               flags[:, 1:2])
-            iters += 1
-            fl = flags.cpu()
-            max_beta, err = self.sync_round(float(fl[0, 1:2].view(torch.float32)), int(fl[0, 0]) != 0, dev)
+                K.sampler_beta(z, sdf, st["S"], N, sdf_new, slot, n0, beta, beta0, self.eps, self.beta_iters, fl)
+            st["iters"] = r + 1
+
+        def grow():
+            """the hierarchy grows: n0 new samples from the error-bound pdf, merged into the window"""
+            K.sampler_sample(z, sdf, st["S"], N, beta, True, self.add_tiny, u_more, n0, samp, slot)
+            st["S"] += n0
+            st["samples"] = samp
+
+        def read_flags():
+            return flags.cpu()  # the one host <-> device synchronisation of a converged, correctly predicted call
+
+        def decide(fl, r):
+            """the reference's test after round r (ray_sampler.py:244): continue?"""
+            max_beta, err = self.sync_round(float(fl[0, 1 + r:2 + r].view(torch.float32)), int(fl[0, 0]) != 0, dev)
             if err:  # every rank of a sync group raises together (the flag is reduced with the convergence test)
                 raise RuntimeError("BOUNDING SPHERE PROBLEM!")  # ray_sampler.py:16-18
-            not_converge = max_beta > beta0
-            if not_converge and iters < self.max_total_iters:
-                K.sampler_sample(z, sdf, S, N, beta, True, self.add_tiny, u_more, n0, samp, slot)
-                S += n0
-                samples = samp
-                continue
-            ns = self.N_samples
-            zs = pool.get("z_samples", N, ns)
-            if is_training:
-                u = (rng["u_final"] if rng is not None else self._rand((N, ns), dev)).contiguous()
-            else:
-                u = torch.linspace(0.0, 1.0, steps=ns, device=dev)
-            K.sampler_sample(z, sdf, S, N, beta, False, self.add_tiny, u, ns, zs, None)
-            break
+            return max_beta > beta0 and r + 1 < self.max_total_iters
+
+        def round_by_round():
+            while True:
+                run_round()
+                if not decide(read_flags(), st["iters"] - 1):
+                    return
+                grow()
+
+        start()
+        pred = self._pred_rounds if (self.speculate and self.sync_group is None) else 0
+        if pred >= 2:
+            for r in range(pred):  # no host read inside
+                run_round()
+                if r + 1 < pred:
+                    grow()
+            fl = read_flags()
+            first_stop = next((r for r in range(pred) if not decide(fl, r)), None)
+            if first_stop is None:  # every predicted round wanted another one: carry on from here
+                grow()
+                round_by_round()
+            elif first_stop < pred - 1:  # converged earlier than predicted: the later rounds must not have happened
+                start()
+                round_by_round()
+        else:
+            round_by_round()
+        S, iters = st["S"], st["iters"]
+        self._pred_rounds = iters
+        ns = self.N_samples
+        zs = pool.get("z_samples", N, ns)
+        if is_training:
+            u = (rng["u_final"] if rng is not None else self._rand((N, ns), dev)).contiguous()
+        else:
+            u = torch.linspace(0.0, 1.0, steps=ns, device=dev)
+        K.sampler_sample(z, sdf, S, N, beta, False, self.add_tiny, u, ns, zs, None)
         self.last_iters = iters
         self.sum_iters += iters
         self.n_calls += 1

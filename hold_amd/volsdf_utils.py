@@ -1,7 +1,10 @@
 """Free functions of the reference's engine layer that sit on the drop-in boundary, kernel-backed:
-``sdf_func_with_deformer`` (code/src/engine/volsdf_utils.py:150-169), ``density2weight`` (:220-251),
-``compute_gradient_samples`` (:19-48).  The fused node path in hold_net.py does not go through these (it launches the
-same kernels without materialising [P,257] outputs); they exist so that reference-side callers keep working."""
+``sdf_func_with_deformer`` (code/src/engine/volsdf_utils.py:150-169) and ``compute_gradient_samples`` (:19-48).  The fused
+node path in hold_net.py does not go through these (it launches the same kernels without materialising [P,257] outputs);
+they exist so that reference-side callers keep working.  ``density2weight`` (:220-251) has NO standalone equivalent here:
+its only caller in the reference is the volumetric renderer (hold_utils.py:245), which HOLDNet's compositor kernel
+(hold_composite_fwd / _bwd: density, weights, transmittance and all renders of a ray in one launch) replaces as a whole --
+an eager-torch restatement would be a CPU/eager path inside the product package (round 3 had one; removed)."""
 from __future__ import annotations
 
 import torch
@@ -19,18 +22,6 @@ def sdf_func_with_deformer(deformer, sdf_fn, training, x, deform_info):
         x_c, _ = deformer.forward(x, tfs, return_weights=False, inverse=True, verts=verts)
     out = sdf_fn(x_c, cond)
     return out[:, :, 0:1], x_c, out[:, :, 1:]
-
-
-def density2weight(density_flat, z_vals, z_max):
-    """volsdf_utils.py:220-251 on [N,S] tensors: alpha compositing weights and the background transmittance.  Elementwise
-    + one scan over <= 294 samples per ray; the fused renderer (hold_composite_fwd) never materialises these."""
-    density = density_flat.reshape(-1, z_vals.shape[1])
-    dists = torch.cat([z_vals[:, 1:] - z_vals[:, :-1], z_max.unsqueeze(-1) - z_vals[:, -1:]], -1)
-    free_energy = dists * density
-    alpha = 1 - torch.exp(-free_energy)
-    shifted = torch.cat([torch.zeros(dists.shape[0], 1, device=dists.device), free_energy], dim=-1)
-    transmittance = torch.exp(-torch.cumsum(shifted, dim=-1))
-    return alpha * transmittance[:, :-1], transmittance[:, -1]
 
 
 def compute_gradient_samples(pt_in_space_sampler, implicit_network, cond, num_pixels, verts_c, local_sigma=0.008,

@@ -135,6 +135,44 @@ def test_wgrad_256x256_whole_layer_workgroups(P, ldr, ldx, bias):
     assert float((dW2.double().cpu() - ref2).abs().max()) < 1e-6 * ref2[37, 201]
 
 
+@pytest.mark.parametrize("P,N,K,ldr,ldx", [(4096 * 3 + 16, 217, 256, 256, 256), (65536, 217, 256, 256, 256), (8192, 256, 272, 256, 272),
+                                           (20000 * 16, 256, 304, 256, 304), (4096, 130, 256, 260, 256), (4096, 256, 320, 256, 320)])
+def test_wgrad_whole_layer_workgroups_other_shapes(P, N, K, ldr, ldx):
+    """the whole-dW weight gradient for the trunk's 217-row layer (N < 256: the kernel reads 256 columns of R and the rows
+    >= N of its partial tiles are never reduced) and the rendering net's first layer (K = 272 / 304: 256 columns this way, the
+    tail by the tile kernel) against fp64 -- with the columns N..255 of R POISONED (NaN / Inf: round 3's 0 x NaN in the
+    branch-free bias sums), sentinels around dW / db, accumulate on and off"""
+    import hold_amd
+    from hold_amd import gemm
+    if hold_amd.precision() != "f32x6":
+        pytest.skip("split-precision path")
+    dev = _dev()
+    torch.manual_seed(P + N + K)
+    Rb = torch.randn(P, ldr, device=dev)
+    Xb = torch.randn(P, ldx, device=dev)
+    if N < 256:
+        Rb[:, N:256] = float("nan")
+        Rb[::3, N:256] = float("inf")
+    R, X = Rb[:, :N], Xb[:, :K]
+    big = torch.full((N + 2, K + 4), 7.0, device=dev)  # dW as an interior view: rows / columns beyond stay untouched
+    dW = big[1:N + 1, :K]
+    dbb = torch.full((N + 8,), 7.0, device=dev)
+    db = dbb[4:4 + N]
+    dW.fill_(1.0)
+    db.fill_(1.0)
+    gemm.wgrad(R, X, dW, db, accumulate=True)
+    ref = R.double().t() @ X.double() + 1
+    refb = R.double().sum(0) + 1
+    assert torch.isfinite(dW).all() and torch.isfinite(db).all()
+    assert ((dW.double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
+    assert ((db.double() - refb).abs().max() / refb.abs().max()).item() < 1e-5
+    assert torch.all(big[0] == 7.0) and torch.all(big[N + 1] == 7.0) and torch.all(big[:, K:] == 7.0)
+    assert torch.all(dbb[:4] == 7.0) and torch.all(dbb[4 + N:] == 7.0)
+    dW2 = torch.empty(N, K, device=dev)
+    gemm.wgrad(R, X, dW2, None)
+    assert ((dW2.double() - (ref - 1)).abs().max() / ref.abs().max()).item() < 1e-5
+
+
 def test_fused_sdf_matches_layered_path():
     """hold_fused_sdf (LDS-resident 8-layer trunk) against the layer-by-layer GEMM path on the same weights."""
     import numpy as np

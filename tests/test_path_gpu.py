@@ -109,6 +109,30 @@ def test_sampler_end_to_end(ctx):
     assert 10 * np.log10(1.0 / max(mse, 1e-20)) > 60.0
 
 
+def test_speculative_sampler_rounds_equal_the_round_by_round_loop(ctx):
+    """hold_amd.sampler: launching the predicted number of rounds with ONE flag read per call must return exactly what the
+    reference's round-by-round loop (ray_sampler.py:150-310) returns -- for a correct prediction, for one that is too low
+    (the call continues) and for one that is too high (the call is redone: the extra rounds changed the window)."""
+    sc, sd = ctx["sc"], ctx["sd"]
+    b, _ = oracle_input(sc, sd, [0, 1], 10, 10)
+    net = hip_net(sc, ctx["sd_np"])
+    for node in net.nodes.values():
+        node.ray_sampler.speculate = False
+    ref = net(hip_input(b, net))
+    zr = {n: ref[n + ".z_vals"].clone() for n in sc["entities"]}
+    it = {n: net.nodes[n].ray_sampler.last_iters for n in sc["entities"]}
+    assert all(2 <= v <= 5 for v in it.values()), it
+    for pred in (2, 3, 4, 5):
+        for node in net.nodes.values():
+            node.ray_sampler.speculate = True
+            node.ray_sampler._pred_rounds = pred
+        out = net(hip_input(b, net))
+        for n in sc["entities"]:
+            assert net.nodes[n].ray_sampler.last_iters == it[n], (pred, n)
+            assert torch.equal(out[n + ".z_vals"], zr[n]), (pred, n)
+            assert net.nodes[n].ray_sampler._pred_rounds == it[n]  # the next call predicts what this one took
+
+
 def test_sampler_rounds_match_trace(ctx, gold_dir):
     """per-round kernels on the oracle's recorded (z, sdf) windows: beta line search and new samples."""
     from hold_amd import kernels as K
