@@ -47,6 +47,7 @@ class ChainDesc(C.Structure):
         ("wpack", C.c_void_p), ("ld", C.c_int32),
         ("bias", C.c_void_p * 8), ("aux1", C.c_void_p * 8), ("aux2", C.c_void_p * 8),
         ("out", C.c_void_p * 8), ("out2", C.c_void_p * 8),
+        ("skip_out", C.c_int32),
     ]
 
 

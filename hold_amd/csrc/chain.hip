@@ -543,6 +543,7 @@ static int chain_impl(const hold_chain_desc* dp, hold_stream_t st, bool x6) {
   if (!al16(d.in) || !al16(d.wpack) || (d.side && (!al16(d.side) || d.ld_side < 40 || (d.ld_side & 3))))
     return HOLD_E_ARG;
   if (d.skip_layer >= d.n_layers - 1) return HOLD_E_ARG;  // the side matrix must not be re-filled under a reader
+  if (d.skip_out != 0 && d.skip_out != SKIP_OUT) return HOLD_E_ARG;  // only hold_chain_r6 knows another skip width
   // 32-bit byte offsets inside the kernels (incl. the rows of a partial last block): split larger batches by rows
   if (((uint64_t)d.P + 128) * (uint64_t)d.ld * 4 >= (1ull << 32)) return HOLD_E_ARG;
   const bool has2 = d.aux2[0] != nullptr;

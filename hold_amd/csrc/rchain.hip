@@ -42,6 +42,7 @@
 // Roofline: bf16 MFMA pipe; HBM bytes per point and layer: DSP 2 KiB (1 side + 1 out), DSP + a2 3 KiB, DBWD 4 KiB.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/hold_hip.h"
 
@@ -54,7 +55,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int NW = 4, BPTS = 32 * NW, PIECE = 1024, UNIT = 6 * PIECE, SLOT = 4 * UNIT, TILE = 4 * PIECE;
-constexpr int SKIP_OUT = 217;
 enum { RC_DSP = 1, RC_DBWD = 2 };
 
 struct RCArgs {
@@ -144,7 +144,10 @@ struct RCfg {
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
-template <int MODE, bool A2, int DIST_>
+// ABL (developer build, results garbage): 1 = the side tiles of every block are read from block 0's rows (they stay in L2): what the
+// HBM latency of the side requests costs; 2 = additionally no result stores
+// SKIP_OUT: first special output column of the skip layer (217: the foreground nets; 172: the background net)
+template <int MODE, bool A2, int DIST_, int ABL = 0, int SKIP_OUT = 217>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rsweep_kernel(RCArgs a) {
   using C = RCfg<MODE, A2, DIST_>;
   constexpr bool DB = C::DB;
@@ -221,8 +224,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const long r = blk * BPTS + wave * 32 + 8 * i + r8;
       const long cr = r < a.P ? r : a.P - 1;
       const int cs = p8 ^ f0 ^ ((i & 1) << 2);
-      dvoff[i] = (uint32_t)((cr * a.ld + 4 * cs) * 4);
-      svoff[i] = (uint32_t)((r * a.ld + 4 * cs) * 4);
+      dvoff[i] = (uint32_t)(((ABL >= 1 ? (long)(wave * 32 + 8 * i + r8) : cr) * a.ld + 4 * cs) * 4);
+      svoff[i] = ABL >= 2 ? 0xfffffff0u : (uint32_t)((r * a.ld + 4 * cs) * 4);
     }
     const char* rdX = ring_lane + ubx;  // fragment reads: slots 0..3 / 4..7 of this block's phase (DBWD)
     const char* rdY = ring_lane + uby;
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           else if (A2 && rd == 3) st.r[i] = st.r[i] + st.x2[i];
           else {
             float r = raw ? st.y[i] : st.r[i];
-            if (j >= 13) r = (skip && f >= SKIP_OUT) ? st.y[i] : r;  // the raw products (d / d skip input) are stored
+            if (j >= SKIP_OUT / 16) r = (skip && f >= SKIP_OUT) ? st.y[i] : r;  // the raw products (d / d skip input) are stored
             st.r[i] = r;
           }
         } else {
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           else if (rd == 2) st.r2[i] = 100.0f * st.y[i];
           else if (rd == 3) st.r2[i] = st.r2[i] * st.x2[i];
           else if (rd == 4) st.r2[i] = st.r2[i] * st.e[i];
-          else if (j >= 13) {  // skip layer: the next input's columns 217.. are the side columns (in aux2, see the header)
+          else if (j >= SKIP_OUT / 16) {  // skip layer: the next input's columns 217.. are the side columns (in aux2, see the header)
             const bool sp_ = skip && f >= SKIP_OUT;
             st.r[i] = sp_ ? st.x2[i] : st.r[i];
             st.r2[i] = sp_ ? 0.f : st.r2[i];
@@ -548,8 +551,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 extern "C" int64_t hold_chain_r6_pack_bytes(void) { return (int64_t)(7 * 16) * SLOT; }
 
-template <int MODE, bool A2, int DIST>
+template <int MODE, bool A2, int DIST, int SKIP = 217>
 static int rsweep_launch(const RCArgs& a, hipStream_t s) {
+#ifdef HOLD_DEV
+  if (const char* v = getenv("HOLD_R6_ABL")) {
+    constexpr int lds_ = RCfg<MODE, A2, DIST>::LDS;
+    const long blocks_ = (a.P + BPTS - 1) / BPTS;
+    int dev_ = 0;
+    hipDeviceProp_t prop_;
+    if (hipGetDevice(&dev_) != hipSuccess || hipGetDeviceProperties(&prop_, dev_) != hipSuccess) return HOLD_E_LAUNCH;
+    const dim3 grid_((unsigned)(blocks_ < prop_.multiProcessorCount ? blocks_ : prop_.multiProcessorCount));
+    if (v[0] == '1') {
+      if (hipFuncSetAttribute((const void*)rsweep_kernel<MODE, A2, DIST, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) return HOLD_E_LAUNCH;
+      hipLaunchKernelGGL((rsweep_kernel<MODE, A2, DIST, 1>), grid_, dim3(256), lds_, s, a);
+      return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+    }
+    if (v[0] == '2') {
+      if (hipFuncSetAttribute((const void*)rsweep_kernel<MODE, A2, DIST, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) return HOLD_E_LAUNCH;
+      hipLaunchKernelGGL((rsweep_kernel<MODE, A2, DIST, 2>), grid_, dim3(256), lds_, s, a);
+      return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+    }
+  }
+#endif
   constexpr int lds = RCfg<MODE, A2, DIST>::LDS;
   static int n_cu = 0;
   static bool attr_set = false;
@@ -560,12 +583,12 @@ static int rsweep_launch(const RCArgs& a, hipStream_t s) {
     n_cu = prop.multiProcessorCount;
   }
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)rsweep_kernel<MODE, A2, DIST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)rsweep_kernel<MODE, A2, DIST, 0, SKIP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return HOLD_E_LAUNCH;
     attr_set = true;
   }
   const long blocks = (a.P + BPTS - 1) / BPTS;
-  hipLaunchKernelGGL((rsweep_kernel<MODE, A2, DIST>), dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((rsweep_kernel<MODE, A2, DIST, 0, SKIP>), dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(256), lds, s, a);
   return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
 }
 
@@ -579,6 +602,8 @@ extern "C" int hold_chain_r6(const hold_chain_desc* dp, hold_stream_t st) {
   if (!dp) return HOLD_E_ARG;
   const hold_chain_desc& d = *dp;
   if (d.P < 0 || !d.in || !d.wpack || d.skip_layer != 3) return HOLD_E_ARG;
+  const int so = d.skip_out ? d.skip_out : 217;
+  if (so != 217 && so != 172) return HOLD_E_ARG;
   const bool db = d.mode == HOLD_CHAIN_DBWD;
   if (d.mode != HOLD_CHAIN_DSP && !db) return HOLD_E_ARG;
   const int nl = db ? 8 : 7;
@@ -601,10 +626,11 @@ extern "C" int hold_chain_r6(const hold_chain_desc* dp, hold_stream_t st) {
   }
   if (d.P == 0) return HOLD_OK;
   hipStream_t s = (hipStream_t)st;
-  if (db) return rsweep_launch<RC_DBWD, true, 1>(a, s);
+  if (db) return so == 217 ? rsweep_launch<RC_DBWD, true, 1>(a, s) : HOLD_E_ARG;
   // DIST 1 (8-unit ring) everywhere.  A 16-unit ring (DIST 3) fits beside one side matrix, but its slots 8..15 lie beyond the
   // 64 KiB reach of a ds_read immediate: the extra address registers spill and the sweep measured 150 against 158 TF-eq
   // (GPU call 3 of round 4)
+  if (so == 172) return has2 ? HOLD_E_ARG : rsweep_launch<RC_DSP, false, 1, 172>(a, s);
   if (has2) return rsweep_launch<RC_DSP, true, 1>(a, s);
   return rsweep_launch<RC_DSP, false, 1>(a, s);
 }

@@ -21,6 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import config
+from . import field as _field
 from . import gemm as G
 from . import kernels as K
 from .field import FEAT, FieldSpec, NodeField, Pool, pack_weights, pad4, zeros_like_many
@@ -912,18 +913,33 @@ class Background(nn.Module):
         G.gemm_nt(ob, WT[8], rb_[0], epi=G.EPI_MUL_DSP, aux1=h[7], K=260)
         cur = rb_[0]
         so = self.skip_out
-        for l in range(7, 0, -1):
-            nxt = rb_[1] if cur is rb_[0] else rb_[0]
-            if l == 4:
-                G.wgrad(cur, h[3], dW[4], dWb[4])
-                G.gemm_nt(cur, WT[4], nxt[:, :so], epi=G.EPI_MUL_DSP, aux1=h[3], N=so)
-            elif l == 3:
-                G.wgrad(cur, h[2], dW[3], dWb[3], N=so)
-                G.gemm_nt(cur, WT[3], nxt, epi=G.EPI_MUL_DSP, aux1=h[2], K=so)
-            else:
-                G.wgrad(cur, h[l - 1], dW[l], dWb[l])
-                G.gemm_nt(cur, WT[l], nxt, epi=G.EPI_MUL_DSP, aux1=h[l - 1])
-            cur = nxt
+        if config.x6() and _field.USE_R6_BWD:
+            # the seven 256-wide layers as ONE register-resident descending sweep (csrc/rchain.hip, skip width 172) instead
+            # of seven hold_gemm_nt launches with the MUL_DSP epilogue; every r_l stays for the weight gradients
+            S = torch.stack([F.pad(W[l], (0, 0, 0, 256 - W[l].shape[0])) for l in range(1, 8)])
+            wr6 = _field.pack_r6_stack(S.transpose(1, 2).flip(0).contiguous())  # layer j of the sweep = W_{7-j}^T
+            r = [pool.get(f"rs{l}", P, 256) for l in range(7)] + [cur]
+            K.chain(K.CHAIN_DSP, P, cur, None, 7, 32, skip_layer=3, aux1=[h[l - 1] for l in range(7, 0, -1)],
+                    out=[r[l - 1] for l in range(7, 0, -1)], wpack_r6=wr6, skip_out=so)
+            for l in range(7, 0, -1):
+                if l == 3:
+                    G.wgrad(r[3], h[2], dW[3], dWb[3], N=so)
+                else:
+                    G.wgrad(r[l], h[l - 1], dW[l], dWb[l])
+            cur = r[0]
+        else:
+            for l in range(7, 0, -1):
+                nxt = rb_[1] if cur is rb_[0] else rb_[0]
+                if l == 4:
+                    G.wgrad(cur, h[3], dW[4], dWb[4])
+                    G.gemm_nt(cur, WT[4], nxt[:, :so], epi=G.EPI_MUL_DSP, aux1=h[3], N=so)
+                elif l == 3:
+                    G.wgrad(cur, h[2], dW[3], dWb[3], N=so)
+                    G.gemm_nt(cur, WT[3], nxt, epi=G.EPI_MUL_DSP, aux1=h[2], K=so)
+                else:
+                    G.wgrad(cur, h[l - 1], dW[l], dWb[l])
+                    G.gemm_nt(cur, WT[l], nxt, epi=G.EPI_MUL_DSP, aux1=h[l - 1])
+                cur = nxt
         G.wgrad(cur, sv["in0"], dW[0], dWb[0], K=self.K0)
         d_in0 = pool.get("d_in0", P, self.K0)
         G.gemm_nt(cur, WT[0], d_in0, N=self.K0)

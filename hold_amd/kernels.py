@@ -165,12 +165,12 @@ _CHAIN_MAX_ROWS = _max_rows(256)  # 32-bit byte offsets inside the kernel (ld = 
 
 
 def chain(mode, P, x_in, wpack, n_layers, first_chunks, skip_layer=-1, side=None, bias=None, aux1=None, aux2=None,
-          out=None, out2=None, wpack_x6=None, wpack_r6=None):
+          out=None, out2=None, wpack_x6=None, wpack_r6=None, skip_out=0):
     """hold_chain: n_layers consecutive 256-wide layers of one sweep with the activation resident in LDS.
     bias: per-layer [256] tensors; aux1 / aux2 / out / out2: per-layer [P,256] tensors (one common row stride) or None
     entries.  Batches beyond the kernel's 32-bit offset range are split by rows."""
     from . import gemm as _g
-    assert wpack.numel() == _lib.lib().hold_chain_pack_floats(first_chunks, n_layers)
+    assert wpack is None or wpack.numel() == _lib.lib().hold_chain_pack_floats(first_chunks, n_layers)
     if wpack_x6 is not None:  # split-precision sweep (hold_chain_x6): same descriptor, the weights as bf16 limbs
         assert wpack_x6.numel() * wpack_x6.element_size() == _lib.lib().hold_chain_x6_pack_bytes(first_chunks, n_layers)
     # register-resident sweeps (hold_chain_r6, csrc/rchain.hip): same descriptor.  DSP: wpack_r6 = field.pack_r6_stack of the
@@ -185,9 +185,11 @@ def chain(mode, P, x_in, wpack, n_layers, first_chunks, skip_layer=-1, side=None
         r1 = min(P, r0 + _CHAIN_MAX_ROWS)
         d = _lib.ChainDesc()
         d.P, d.mode, d.n_layers, d.first_chunks, d.skip_layer = r1 - r0, mode, n_layers, first_chunks, skip_layer
+        d.skip_out = int(skip_out)  # 0 = 217; 172 = the background net (hold_chain_r6, DSP only)
         d.in_, d.ld_in = x_in[r0:r1].data_ptr(), _ld(x_in)
         if side is not None:
             d.side, d.ld_side = side[r0:r1].data_ptr(), _ld(side)
+        assert r6 or wpack is not None
         d.wpack = wpack_r6.data_ptr() if r6 else (wpack if wpack_x6 is None else wpack_x6).data_ptr()
         ld = None
         for name, lst in (("bias", bias), ("aux1", aux1), ("aux2", aux2), ("out", out), ("out2", out2)):

@@ -3,6 +3,8 @@ code/src/engine/ray_sampler.py:88-352 (VolSDF Algorithm 1), with the SDF query i
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import kernels as K
@@ -67,7 +69,7 @@ class ErrorBoundSampler:
         # rounds continues from where it stands, one that converged EARLIER than predicted is redone round by round (the
         # extra rounds changed the window).  Results are those of the round-by-round loop either way.  Off with sync_group
         # (the data-parallel exchange is per round by definition).
-        self.speculate = True
+        self.speculate = os.environ.get("HOLD_SAMPLER_SPECULATE", "1") != "0"
         self._pred_rounds = 0
         self.last_iters = 0
         self.sum_iters = 0  # rounds summed over all calls / number of calls (bench.py: FLOP per ray of a timed region)

@@ -361,6 +361,8 @@ typedef struct {
   const float* aux2[8];
   float* out[8];
   float* out2[8];
+  int32_t skip_out; /* first special output column of skip_layer: 0 = 217 (the foreground nets); hold_chain_r6 (DSP) also
+                       takes 172, the background net's (256 - 84 embedding columns, background.py:44-58); others reject it */
 } hold_chain_desc;
 int64_t hold_chain_pack_floats(int32_t first_chunks, int32_t n_layers);
 int hold_chain(const hold_chain_desc* d, hold_stream_t stream);

@@ -115,6 +115,32 @@ def test_chain_descending_dsp(P, with_a2, arith):
         cur = out[j].double()
 
 
+@pytest.mark.parametrize("P", [130, 128 * 257 + 3])
+def test_chain_descending_dsp_background_skip_width(P):
+    """hold_chain_r6 (DSP) with skip_out = 172, the background net's skip width (256 - 84 embedding columns,
+    code/src/model/renderables/background.py): columns 172.. of the skip layer's output are the raw products"""
+    from hold_amd import kernels as K
+    dev = _dev()
+    SKB = 172
+    g = torch.Generator().manual_seed(P + 11)
+    v7 = torch.randn(P, 256, generator=g).to(dev)
+    Ms = [(torch.randn(256, 256, generator=g) / 16).to(dev) for _ in range(7)]
+    Ms[4][:, SKB:] = 0  # the layer after the skip contracts over 172 inputs only
+    hs = [_sp(torch.randn(P, 256, generator=g) * 0.03).to(dev) for _ in range(7)]
+    guard = _Guarded(7, P, dev)
+    out = guard.views
+    K.chain(K.CHAIN_DSP, P, v7, None, 7, 32, skip_layer=3, aux1=hs, out=out, wpack_r6=_r6_stream("dsp", Ms), skip_out=SKB)
+    guard.check()
+    cur = v7.double()
+    for j in range(7):
+        y = cur @ Ms[j].double().t()
+        r = y * (-torch.expm1(-100 * hs[j].double()))
+        if j == 3:
+            r[:, SKB:] = y[:, SKB:]
+        assert (out[j].double() - r).abs().max().item() < 3e-5 * max(1.0, r.abs().max().item()), j
+        cur = out[j].double()
+
+
 @pytest.mark.parametrize("arith", ARITH_BWD)
 @pytest.mark.parametrize("P", [200, 128 * 256 + 64, 128 * 513 + 1])
 def test_chain_second_order_dbwd(P, arith):
