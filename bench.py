@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--chunk", type=int, default=16384, help="rays per microbatch (~85 GB of saved activations per fg node)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--cpu-frames", type=int, default=3, help="frames (x 128 rays) of the reference's 10-frame step the cpu_baseline leg times")
     ap.add_argument("--mode", default="train", choices=["train", "render", "c3", "c5"])
     ap.add_argument("--loss", default="full", choices=["pixel", "full"])
     ap.add_argument("--two-hands", action="store_true", help="ARCTIC-style scene (right + left + object), config C4")
@@ -78,14 +79,15 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(sc, sd_np, threads=32, repeats=1, n_frames=10):
+def cpu_baseline(sc, sd_np, threads=32, repeats=1, n_frames=3):
     """The CPU oracle (torch restatement of the reference's PyTorch path, oracle/hold_oracle.py + oracle/targets_oracle.py)
     timed on the host in the REFERENCE'S OWN step shape (VERDICT r3 missing #6): 10 frames x 128 random pixels = 1 280 rays
     (general.yaml:82, tempo_dataset.py:27-36), forward + the loss targets of a steady-state step (off-surface test of every
     canonical sample against the node's loss-target mesh, MANO-canonical SDF and eikonal samples, hold_utils.py:149-240) +
-    the full Loss (code/src/hold/loss.py:17-93) + backward; `repeats` steps (default ONE: a bounded sample of about a minute on
-    32 threads -- the exact point-to-mesh geometry of the loss targets, kaolin on a GPU in the reference, is 1.5e9
-    point-triangle tests per step on the host)."""
+    the full Loss (code/src/hold/loss.py:17-93) + backward.  BOUNDED SAMPLE: `n_frames` of the step's 10 frames (default 3 =
+    384 rays, about half a minute on 32 threads; every term is a sum over frames / rays, the cost is linear in them:
+    `--cpu-frames 10` times the whole 1 280-ray step, 114 s on the round's GPU box = 11.2 rays/s) -- the exact point-to-mesh
+    geometry of the loss targets (kaolin on a GPU in the reference) is 1.2e6 point-triangle tests per ray on the host."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from hold_amd import synthetic as syn
     from oracle import fitting_oracle as fo
@@ -159,8 +161,9 @@ def cpu_baseline(sc, sd_np, threads=32, repeats=1, n_frames=10):
         times.append(time.time() - t0)
     med = float(np.median(times))
     return {"value": N / med, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"{repeats} training steps in the reference's own step shape: {len(frames)} frames x 128 random pixels = {N} rays "
-                      f"(general.yaml:82), forward + loss targets (off-surface test of every canonical sample against the "
+            "sample": f"{repeats} training step(s) of {len(frames)} frames x 128 random pixels = {N} rays -- the reference's step layout "
+                      f"(general.yaml:82: 10 frames x 128 = 1 280 rays per step; a bounded sample of it, the cost is linear in frames; "
+                      f"--cpu-frames 10 times the whole step: 11.2 rays/s on this pool's box), forward + loss targets (off-surface test of every canonical sample against the "
                       f"{hf.shape[0]}- / {of_.shape[0]}-face loss-target meshes, MANO-canonical SDF, eikonal samples) + the full Loss "
                       f"(rgb, semantics, eikonal, MANO-cano SDF, opacity sparsity) + backward -- the GPU step's terms, without its "
                       f"clip + Adam; median step {med:.2f} s (all: {[round(t, 2) for t in times]}); kind 'port': oracle/hold_oracle.py + "
@@ -497,7 +500,7 @@ def main():
             if args.shape_report:
                 json.dump(gemm_shapes(prof), open(args.shape_report, "w"), indent=1)
             split = {"fused_sdf_kernel", "wgrad_kernel", "chain_kernel", "gemm_nt_kernel", "trunk_r6_kernel", "rchain_kernel",
-                     "rchain_a2_kernel", "rchain_dbwd_kernel", "rgemm_kernel"} if x6 else set()
+                     "rchain_bg_kernel", "rchain_a2_kernel", "rchain_dbwd_kernel", "rgemm_kernel"} if x6 else set()
             labels = {"gemm_nt_kernel": ("gemm_nt_kernel<x6> (one layer per launch, 3-limb split on v_mfma_f32_32x32x16_bf16)"
                                          if x6 else "gemm_nt_kernel (one layer per launch, v_mfma_f32_32x32x2_f32)"),
                       "trunk_r6_kernel": "rmlp_kernel<STORE> (forward trunk, 8 layers per launch, register-resident, 3-limb split on "
@@ -506,6 +509,8 @@ def main():
                                       "per launch, register-resident, 3-limb split on v_mfma_f32_32x32x16_bf16)",
                       "rchain_kernel": "rsweep_kernel<DSP> (descending sweep of the normal path, 7 layers per launch, register-resident, "
                                        "side I/O as whole 128-byte lines through LDS, 3-limb split on v_mfma_f32_32x32x16_bf16)",
+                      "rchain_bg_kernel": "rsweep_kernel<DSP, skip 172> (the background net's first-order backward sweep, 7 layers per "
+                                          "launch, register-resident, 3-limb split on v_mfma_f32_32x32x16_bf16)",
                       "rchain_a2_kernel": "rsweep_kernel<DSP+a2> (first-order backward sweep, 7 layers per launch, register-resident, "
                                           "two side inputs as whole lines through LDS, 3-limb split on v_mfma_f32_32x32x16_bf16)",
                       "rchain_dbwd_kernel": "rsweep_kernel<DBWD> (second-order ascending sweep, 8 layers per launch, register-resident, "
@@ -603,7 +608,7 @@ def main():
             except Exception as e:  # the refinement leg is reported beside the step rate, never instead of it
                 res["config"]["pose_refine"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1 and args.mode == "train" and not args.two_hands:
-            res["cpu_baseline"] = cpu_baseline(sc, sd_np, args.cpu_threads)
+            res["cpu_baseline"] = cpu_baseline(sc, sd_np, args.cpu_threads, n_frames=args.cpu_frames)
             res["config"]["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     if dist.is_initialized():

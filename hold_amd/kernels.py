@@ -212,8 +212,8 @@ def chain(mode, P, x_in, wpack, n_layers, first_chunks, skip_layer=-1, side=None
         # algorithmic HBM bytes: the chain input row + per layer 1 KiB per side input and per stored result
         n_mats = sum(sum(t is not None for t in lst) for lst in (aux1, aux2, out, out2) if lst is not None)
         _g._prof_end(e0, 2.0 * (r1 - r0) * 256 * (8 * first_chunks + 256 * (n_layers - 1)),
-                     ("rchain_dbwd_kernel" if mode == CHAIN_DBWD else "rchain_a2_kernel" if aux2 is not None else "rchain_kernel")
-                     if r6 else "chain_kernel",
+                     ("rchain_dbwd_kernel" if mode == CHAIN_DBWD else "rchain_a2_kernel" if aux2 is not None else
+                      "rchain_bg_kernel" if skip_out == 172 else "rchain_kernel") if r6 else "chain_kernel",
                      (r1 - r0) * (32.0 * first_chunks + 1024.0 * n_mats))
 
 
