@@ -60,6 +60,12 @@ class WnDesc(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("accumulate", C.c_int32), ("layers", WnLayer * 16)]
 
 
+class WgradItem(C.Structure):  # hold_wgrad_item
+    _fields_ = [("R", C.c_void_p), ("X", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p),
+                ("ldr", C.c_int32), ("ldx", C.c_int32), ("lddw", C.c_int32), ("N", C.c_int32),
+                ("accumulate", C.c_int32), ("reserved", C.c_int32)]
+
+
 _lib = None
 
 
@@ -110,6 +116,7 @@ SIGNATURES = {
     "hold_gemm_nt_x6": [C.POINTER(GemmDesc), _P],
     "hold_wgrad": [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _P],
     "hold_wgrad_x6": [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _P],
+    "hold_wgrad_group_x6": [C.POINTER(WgradItem), _I, _L, _P, _P],
     "hold_ray_points": [_P, _P, _P, _I, _I, _L, _P, _I, _P],
     "hold_embed_fwd": [_P, _I, _I, _I, _P, _L, _P, _I, _P, _I, _P, _I, _L, _P],
     "hold_embed_bwd": [_P, _I, _I, _P, _L, _P, _I, _P, _I, _I, _P],
@@ -172,6 +179,8 @@ def _declare(L):
     L.hold_abi_version.restype = C.c_int
     L.hold_wgrad_workspace_floats.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     L.hold_wgrad_workspace_floats.restype = C.c_int64
+    L.hold_wgrad_group_workspace_floats.argtypes = []
+    L.hold_wgrad_group_workspace_floats.restype = C.c_int64
     L.hold_reduce_workspace_floats.restype = C.c_int64
     L.hold_fused_sdf_pack_floats.restype = C.c_int64
     L.hold_fused_sdf_x6_pack_bytes.restype = C.c_int64

@@ -20,6 +20,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -94,19 +95,19 @@ __device__ __forceinline__ void split_mop(Frag& s, u32x4 (&out)[3], int k) {
 constexpr int rs(int f) { return 85 * f / 8; }
 constexpr int ws(int f) { return 11 + 85 * f / 8; }
 
+// the steps [s0, s1) of one (R, X) pair by one workgroup -> its partial tile out[256][256] (and out_b[256])
 template <bool BIAS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wgrad_r6_kernel(WArgs a) {
+__device__ __forceinline__ void wgrad_r6_body(const float* R, int ldr, const float* X, int ldx, long s0, long s1,
+                                              float* out, float* out_b) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, li = lane & 31;
   const int wn = wave >> 1, wk = wave & 1;  // this wave's quadrant: rows n = 128 wn .., columns k = 128 wk ..
-  const long s0 = (long)blockIdx.x * a.spw;
-  const long s1 = s0 + a.spw < a.nsteps ? s0 + a.spw : a.nsteps;
 
   // ---- LDS-DMA of this wave's eight rows of a step: waves 0, 1 -> R rows 0..7 / 8..15, waves 2, 3 -> X rows
-  const float* M = (wave >> 1) ? a.X : a.R;
-  const long ldm = (wave >> 1) ? a.ldx : a.ldr;
+  const float* M = (wave >> 1) ? X : R;
+  const long ldm = (wave >> 1) ? ldx : ldr;
   const uint32_t dvoff = (uint32_t)((lane ^ (8 * (wave & 1))) * 16);  // chunk swizzle: rows 8..15 swap 32-column halves
   const long rowb = ldm * 4;                                            // bytes between rows
   const char* mrow0 = reinterpret_cast<const char*>(M) + (wave & 1) * 8 * rowb;  // this wave's first row of step 0
@@ -224,7 +225,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 
   // ---- partial sums of this workgroup: lane (hh, li) holds column k = 128 wk + 32 b + li, rows 8 g + 4 hh + r ----
-  float* out = a.part + (long)blockIdx.x * 65536;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -238,9 +238,86 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const float s = bsum[q] + __shfl_xor(bsum[q], 32);
-      if (hh == 0) a.part_b[(long)blockIdx.x * 256 + 128 * wn + 32 * (2 * wk + q) + li] = s;
+      if (hh == 0) out_b[128 * wn + 32 * (2 * wk + q) + li] = s;
     }
   }
+}
+
+template <bool BIAS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wgrad_r6_kernel(WArgs a) {
+  const long s0 = (long)blockIdx.x * a.spw;
+  const long s1 = s0 + a.spw < a.nsteps ? s0 + a.spw : a.nsteps;
+  wgrad_r6_body<BIAS>(a.R, a.ldr, a.X, a.ldx, s0, s1, a.part + (long)blockIdx.x * 65536,
+                      BIAS ? a.part_b + (long)blockIdx.x * 256 : nullptr);
+}
+
+// ---- several (R, X) pairs over the same points in ONE launch (hold_wgrad_group_x6): workgroup b works on pair
+// b / gper, its share b % gper of the steps.  With n pairs a pair's points are split over gper = CUs / n workgroups
+// instead of over all of them, so a launch writes CUs partial tiles for ALL pairs together (64 MiB) where n single
+// launches write n x 64 MiB -- at 125k points (the two-hand configuration's chunks) the partial tiles of a single launch
+// are half the operand bytes -- and one reduction pass replaces 2 n.
+constexpr int WG_MAX_ITEMS = 24;
+struct WPair { const float* R; const float* X; int ldr; int ldx; };
+struct WGroupArgs {
+  WPair it[WG_MAX_ITEMS];
+  long nsteps;
+  int gper, spw;
+  float* part;    // [n x gper][256][256]
+  float* part_b;  // [n x gper][256]
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wgrad_r6_group_kernel(WGroupArgs a) {
+  const int item = blockIdx.x / a.gper, share = blockIdx.x % a.gper;
+  // a select chain, not a[item]: a dynamic index into the by-value argument would send the table through scratch
+  const float* R = a.it[0].R;
+  const float* X = a.it[0].X;
+  int ldr = a.it[0].ldr, ldx = a.it[0].ldx;
+#pragma unroll
+  for (int i = 1; i < WG_MAX_ITEMS; ++i)
+    if (item == i) { R = a.it[i].R; X = a.it[i].X; ldr = a.it[i].ldr; ldx = a.it[i].ldx; }
+  const long s0 = (long)share * a.spw;
+  const long s1 = s0 + a.spw < a.nsteps ? s0 + a.spw : a.nsteps;
+  wgrad_r6_body<true>(R, ldr, X, ldx, s0, s1, a.part + (long)blockIdx.x * 65536, a.part_b + (long)blockIdx.x * 256);
+}
+
+// destination d of the group = the pairs [first, first + count) (consecutive in the list): dW[:N][:256] (+)= the sum of
+// their count x gper partial tiles in a fixed order (16 strided chains, then the 16 chain sums in order: deterministic);
+// block x = 1024 reduces the bias sums of the pairs whose bit is set in bias_items.
+struct WDst { float* dW; float* db; int lddw, N, first, count, accumulate; unsigned bias_items; };
+struct WReduceArgs { WDst d[WG_MAX_ITEMS]; int gper; const float* part; const float* part_b; };
+
+__global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(WReduceArgs a) {
+  __shared__ f32x4 red[16][16];
+  const int di = blockIdx.y;
+  WDst d = a.d[0];
+#pragma unroll
+  for (int i = 1; i < WG_MAX_ITEMS; ++i)
+    if (di == i) d = a.d[i];
+  if (blockIdx.x == 1024) {
+    const int n = threadIdx.x;
+    if (!d.db || n >= d.N) return;
+    float s = 0.f;
+    for (int it = 0; it < d.count; ++it)
+      if ((d.bias_items >> it) & 1u)
+        for (int sp = 0; sp < a.gper; ++sp) s += a.part_b[((long)(d.first + it) * a.gper + sp) * 256 + n];
+    d.db[n] = d.accumulate ? d.db[n] + s : s;
+    return;
+  }
+  const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int i = (blockIdx.x * 16 + e) * 4, n = i >> 8, k = i & 255;
+  if (n >= d.N) return;  // block-uniform: a block's 64 elements lie in one row
+  const float* p = a.part + (long)d.first * a.gper * 65536 + i;
+  const int np = d.count * a.gper;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int sp = g; sp < np; sp += 16) s += *reinterpret_cast<const f32x4*>(p + (long)sp * 65536);
+  red[g][e] = s;
+  __syncthreads();
+  if (g != 0) return;
+#pragma unroll
+  for (int j = 1; j < 16; ++j) s += red[j][e];
+  float* o = d.dW + (long)n * d.lddw + k;
+  if (d.accumulate) s += *reinterpret_cast<const f32x4*>(o);
+  *reinterpret_cast<f32x4*>(o) = s;
 }
 
 }  // namespace
@@ -249,24 +326,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // part_b[G][256]) with G <= max_splits workgroup partials and returns G (< 0: error); the caller reduces them -- all 256
 // rows, or the first N when R has fewer meaningful columns (rows are independent: what columns N..255 of R hold, NaN
 // included, only reaches the rows >= N of a partial tile).
-int hold_wgrad_r6_partials(const float* R, int ldr, const float* X, int ldx, long P, int max_splits, float* part,
-                           float* part_b, hipStream_t s) {
+// compute units of the current device (0: query failed); the kernels' LDS size attribute is set on the first call
+static int wgrad_r6_setup() {
   static int n_cu = 0;
   static bool attr_set = false;
   if (n_cu == 0) {
     int dev = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return HOLD_E_LAUNCH;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
     n_cu = prop.multiProcessorCount;
   }
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)wgrad_r6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
             hipSuccess ||
         hipFuncSetAttribute((const void*)wgrad_r6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+            hipSuccess ||
+        hipFuncSetAttribute((const void*)wgrad_r6_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
             hipSuccess)
-      return HOLD_E_LAUNCH;
+      return 0;
     attr_set = true;
   }
+  return n_cu;
+}
+
+int hold_wgrad_r6_partials(const float* R, int ldr, const float* X, int ldx, long P, int max_splits, float* part,
+                           float* part_b, hipStream_t s) {
+  const int n_cu = wgrad_r6_setup();
+  if (n_cu <= 0) return HOLD_E_LAUNCH;
   WArgs a;
   a.R = R; a.ldr = ldr; a.X = X; a.ldx = ldx; a.nsteps = P / 16; a.part = part; a.part_b = part_b;
   long G = n_cu < max_splits ? n_cu : max_splits;
@@ -278,4 +364,52 @@ int hold_wgrad_r6_partials(const float* R, int ldr, const float* X, int ldx, lon
   else
     hipLaunchKernelGGL((wgrad_r6_kernel<false>), dim3((unsigned)G), dim3(256), LDS_BYTES, s, a);
   return hipGetLastError() == hipSuccess ? (int)G : HOLD_E_LAUNCH;
+}
+
+extern "C" int64_t hold_wgrad_group_workspace_floats(void) {
+  const int n_cu = wgrad_r6_setup();
+  return n_cu > 0 ? (int64_t)(n_cu > WG_MAX_ITEMS ? n_cu : WG_MAX_ITEMS) * (65536 + 256) : -1;
+}
+
+extern "C" int hold_wgrad_group_x6(const hold_wgrad_item* items, int32_t n_items, int64_t P, float* workspace,
+                                   hold_stream_t stream) {
+  if (!items || n_items <= 0 || n_items > WG_MAX_ITEMS || !workspace || P < 16 || (P % 16)) return HOLD_E_ARG;
+  const int n_cu = wgrad_r6_setup();
+  if (n_cu <= 0) return HOLD_E_LAUNCH;
+  WGroupArgs a;
+  WReduceArgs r;
+  int nd = 0;
+  for (int i = 0; i < n_items; ++i) {
+    const hold_wgrad_item& it = items[i];
+    if (!it.R || !it.X || !it.dW || it.N <= 0 || it.N > 256 || it.ldr < 256 || it.ldx < 256 || it.lddw < 256 ||
+        (it.ldr & 3) || (it.ldx & 3) || (it.lddw & 3) || ((uintptr_t)it.R & 15) || ((uintptr_t)it.X & 15) ||
+        ((uintptr_t)it.dW & 15))
+      return HOLD_E_ARG;
+    a.it[i] = WPair{it.R, it.X, it.ldr, it.ldx};
+    if (nd > 0 && r.d[nd - 1].dW == it.dW) {  // same destination as the previous pair: one reduction over both
+      WDst& d = r.d[nd - 1];
+      if (d.N != it.N || d.lddw != it.lddw || (it.db && d.db && it.db != d.db)) return HOLD_E_ARG;
+      if (it.db) { d.db = it.db; d.bias_items |= 1u << d.count; }
+      ++d.count;
+    } else {
+      for (int j = 0; j < nd; ++j)
+        if (r.d[j].dW == it.dW) return HOLD_E_ARG;  // pairs of one destination must be adjacent
+      r.d[nd++] = WDst{it.dW, it.db, it.lddw, it.N, i, 1, it.accumulate, it.db ? 1u : 0u};
+    }
+  }
+  for (int i = n_items; i < WG_MAX_ITEMS; ++i) a.it[i] = a.it[0];
+  for (int i = nd; i < WG_MAX_ITEMS; ++i) r.d[i] = r.d[0];
+  a.nsteps = P / 16;
+  long gper = n_cu / n_items > 0 ? n_cu / n_items : 1;
+  if (gper > a.nsteps) gper = a.nsteps;
+  a.spw = (int)((a.nsteps + gper - 1) / gper);
+  gper = (a.nsteps + a.spw - 1) / a.spw;
+  a.gper = (int)gper;
+  a.part = workspace;
+  a.part_b = workspace + (long)n_items * gper * 65536;
+  r.gper = a.gper; r.part = a.part; r.part_b = a.part_b;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(wgrad_r6_group_kernel, dim3((unsigned)(n_items * gper)), dim3(256), LDS_BYTES, s, a);
+  hipLaunchKernelGGL(wgrad_group_reduce_kernel, dim3(1025, nd), dim3(256), 0, s, r);
+  return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
 }

@@ -31,6 +31,8 @@ USE_CHAIN = os.environ.get("HOLD_CHAIN", "1") != "0"
 # register-resident trunk (csrc/rmlp.hip) for the sampler queries and the training forward trunk (f32x6 arithmetic only)
 USE_R6 = os.environ.get("HOLD_R6", "1") != "0"
 USE_R6_BWD = os.environ.get("HOLD_R6_BWD", "1") != "0"  # ... and for the descending sweeps (csrc/rchain.hip)
+# the 256 x 256 weight gradients of a backward as one grouped launch (gemm.WgradGroup / hold_wgrad_group_x6)
+USE_WGRAD_GROUP = os.environ.get("HOLD_WGRAD_GROUP", "1") != "0"
 USE_R6_GEMM = os.environ.get("HOLD_R6_GEMM", "1") != "0"  # ... and for the rendering net's layers / lin8 (csrc/rgemm.hip)
 RIN_FEAT, RIN_X, RIN_N, RIN_POSE, RIN_TIME = 0, 256, 259, 262, 270
 
@@ -500,7 +502,7 @@ class NodeField:
                     grad=g)
 
     # ------------------------------------------------------------------ shared backward sweeps
-    def _second_order_sweep(self, pk, h, t, gebar, dW, P):
+    def _second_order_sweep(self, pk, h, t, gebar, dW, P, grp=None):
         """ascending sweep of the double backward: tbar_l = W_l vbar_l, ubar_l = tbar_l * s_l,
         a2_l = 100 * tbar_l * t_l * (1 - s_l); dW_l += t_l^T vbar_l.  Returns (a2[8], ubar_7)."""
         sp, pool, W = self.spec, self.bpool, pk["W"]
@@ -516,11 +518,14 @@ class NodeField:
             K.chain(K.CHAIN_DBWD, P, gebar, pk["fused"][0], 8, 5, skip_layer=3, side=gebar, aux1=h, aux2=t, out=vb,
                     out2=a2, wpack_x6=pk.get("chain_fwd_x6"), wpack_r6=wr6)
             G.wgrad(t[0], gebar, dW[0], None, K=sp.K0, accumulate=True)
+            # t_l, vbar_l live in buffers of their own until the next backward: their weight gradients may wait for the
+            # grouped launch at the end of the caller (G.WgradGroup)
+            wg = G.wgrad if grp is None else grp.add
             for l in range(1, 8):
                 if l == 3:
-                    G.wgrad(t[3], vb[2], dW[3], None, N=sp.skip_out, accumulate=True)
+                    wg(t[3], vb[2], dW[3], None, N=sp.skip_out, accumulate=True)
                 else:
-                    G.wgrad(t[l], vb[l - 1], dW[l], None, accumulate=True)
+                    wg(t[l], vb[l - 1], dW[l], None, accumulate=True)
             return a2, vb[7]
         vb = [pool.get(f"vb{i}", P, 256) for i in range(2)]
         # l = 0: tbar_0 = W0 vbar_0 ; ubar_0 = tbar*s ; a2_0 = 100*tbar*t*(1-s)
@@ -541,7 +546,7 @@ class NodeField:
             cur = nxt
         return a2, cur
 
-    def _first_order_sweep(self, pk, h, a2, r7, in0, dW, dWb, ebar, P):
+    def _first_order_sweep(self, pk, h, a2, r7, in0, dW, dWb, ebar, P, grp=None):
         """descending sweep r_{l-1} = (W_l^T r_l) * s_{l-1} + a2_{l-1} from r_7 down to r_0 with
         dW_l += r_l^T in_l, db_l += sum r_l; the skip columns of W_4^T r_4 go to ebar[:, :39] (if given).
         Returns r_0."""
@@ -556,11 +561,12 @@ class NodeField:
                     wpack_r6=pk.get("chain_bwd_r6") if USE_R6_BWD else None)
             if ebar is not None:
                 K.copy_cols(r[3][:, sp.skip_out:], ebar, sp.E, P)
+            wg = G.wgrad if grp is None else grp.add
             for l in range(7, 0, -1):
                 if l == 3:
-                    G.wgrad(r[3], h[2], dW[3], dWb[3], N=sp.skip_out, accumulate=True)
+                    wg(r[3], h[2], dW[3], dWb[3], N=sp.skip_out, accumulate=True)
                 else:
-                    G.wgrad(r[l], h[l - 1], dW[l], dWb[l], accumulate=True)
+                    wg(r[l], h[l - 1], dW[l], dWb[l], accumulate=True)
             return r[0]
         rb_ = [pool.get(f"rb{i}", P, 256) for i in range(2)]
         cur = r7
@@ -608,8 +614,11 @@ class NodeField:
         r7 = pool.get("r7", P, 256)
         G.gemm_nt(ob, WT[8], r7, epi=G.EPI_MUL_DSP, aux1=h[7], K=260)
         ebar = pool.get("ebar", P, sp.K0)
-        cur = self._first_order_sweep(pk, h, None, r7, sv["in0"], dW, dWb, ebar, P)
+        grp = G.WgradGroup() if (USE_CHAIN and USE_WGRAD_GROUP) else None
+        cur = self._first_order_sweep(pk, h, None, r7, sv["in0"], dW, dWb, ebar, P, grp)
         G.wgrad(cur, sv["in0"], dW[0], dWb[0], K=sp.K0, accumulate=True)
+        if grp is not None:
+            grp.flush()
         G.gemm_nt(cur, WT[0], ebar, N=sp.K0, accumulate=True)
         xbar = pool.get("xbar", P, 4)
         K.embed_bwd(xc, sp.L, P, ebar, xbar, barf_w=sv["barf_w"])
@@ -648,12 +657,15 @@ class NodeField:
         K.copy_cols(gbar.contiguous(), gb, 3, P)
         gebar = pool.get("gebar", P, sp.K0)
         K.embed_bwd2(xc, sp.L, P, sv["ge"], gb, gebar, xbar=None, barf_w=sv["barf_w"])
-        a2, u7 = self._second_order_sweep(pk, h, t, gebar, dW, P)
+        grp = G.WgradGroup() if (USE_CHAIN and USE_WGRAD_GROUP) else None
+        a2, u7 = self._second_order_sweep(pk, h, t, gebar, dW, P, grp)
         d_w8sdf = torch.zeros(256, device=dev)
         G.wcolsum(u7, d_w8sdf, N=256)
         # first-order sweep driven only by the second-order terms a2_l (out_bar = 0  =>  r_7 = a2_7)
-        cur = self._first_order_sweep(pk, h, a2, a2[7], sv["in0"], dW, dWb, None, P)
+        cur = self._first_order_sweep(pk, h, a2, a2[7], sv["in0"], dW, dWb, None, P, grp)
         G.wgrad(cur, sv["in0"], dW[0], dWb[0], K=sp.K0, accumulate=True)
+        if grp is not None:
+            grp.flush()
         d0 = torch.zeros(256, pk["iw0_cols"], device=dev)
         d0[:, :sp.E] = dW[0][:, :sp.E]
         g_iw = [d0, dW[1], dW[2], dW[3], dW[4] / math.sqrt(2), dW[5], dW[6], dW[7]]
@@ -679,14 +691,22 @@ class NodeField:
         dy = pool.get("dy4", P, 4)
         sg = rgb[:, :3]
         dy[:, :3] = d_rgb * sg * (1.0 - sg)  # sigmoid'  (3 columns, elementwise)
-        rr = [pool.get(f"rr{i}", P, 256) for i in range(2)]
+        # one grouped launch for the 256 x 256 weight gradients of the whole backward (3 of the colour net, 14 + 1 of the
+        # implicit net): their operands must then survive to the end, so the colour net's cotangents get four buffers
+        # instead of two in rotation
+        grp = G.WgradGroup() if (USE_CHAIN and USE_WGRAD_GROUP) else None
+        rr = [pool.get(f"rr{i}", P, 256) for i in range(2 if grp is None else 4)]
         db4 = torch.zeros(4, device=dev)
         G.head3_bwd(dy, r[3], R[4], rr[1], dR[4], db4)  # input gradient + weight / bias gradients in one pass over r3
         dRb[4] = db4[:3]
-        cur = rr[1]
+        cur, ci = rr[1], 1
         for l in (3, 2, 1):
-            G.wgrad(cur, r[l - 1], dR[l], dRb[l])
-            nxt = rr[0] if cur is rr[1] else rr[1]
+            if grp is None:
+                G.wgrad(cur, r[l - 1], dR[l], dRb[l])
+            else:
+                grp.add(cur, r[l - 1], dR[l], dRb[l])
+            ci = (ci + 1) % len(rr)
+            nxt = rr[ci]
             if USE_R6_GEMM and "RT_r6" in pk:
                 G.gemm_r6(cur, pk["RT_r6"][l], nxt, K=256, epi=G.R6_MASK, aux=r[l - 1])
             else:
@@ -719,7 +739,7 @@ class NodeField:
         K.copy_cols(d_rin[:, RIN_X:RIN_X + 3], xbar, 3, P)
         gebar = pool.get("gebar", P, sp.K0)
         K.embed_bwd2(xc, sp.L, P, sv["ge"], gbar, gebar, xbar=xbar, barf_w=sv["barf_w"])
-        a2, u7 = self._second_order_sweep(pk, h, t, gebar, dW, P)
+        a2, u7 = self._second_order_sweep(pk, h, t, gebar, dW, P, grp)
         # gradient of the sdf row of W8: ubar_7 (second-order path) + the first-order term d_sdf^T h7, both as
         # deterministic (weighted) column sums -- a 257th wgrad row would cost a whole 128-row tile
         d_sdf = d_sdf.reshape(P)
@@ -730,15 +750,17 @@ class NodeField:
         # cotangent of lin8's output = [d_rin's feature block | d_sdf]: the feature block is used in place (no copy),
         # the sdf column enters the input-gradient GEMM as a rank-1 term d_sdf[p] * w8_sdf[n]
         d_feat = d_rin[:, RIN_FEAT:RIN_FEAT + FEAT]
-        G.wgrad(d_feat, h[7], dW[8], dWb[8], N=256, accumulate=True)
+        (G.wgrad if grp is None else grp.add)(d_feat, h[7], dW[8], dWb[8], N=256, accumulate=True)
         r7 = pool.get("r7", P, 256)
         G.gemm_nt(d_feat, pk["WT8_feat"], r7, epi=G.EPI_MUL_DSP, aux1=h[7], aux2=a2[7], K=256, r1_row=d_sdf,
                   r1_col=pk["w8_sdf"])
         ebar = pool.get("ebar", P, sp.K0)
-        cur = self._first_order_sweep(pk, h, a2, r7, sv["in0"], dW, dWb, ebar, P)
+        cur = self._first_order_sweep(pk, h, a2, r7, sv["in0"], dW, dWb, ebar, P, grp)
         G.wgrad(cur, sv["in0"], dW[0], dWb[0], K=sp.K0, accumulate=True)
         G.gemm_nt(cur, WT[0], ebar, N=sp.K0, accumulate=True)
         K.embed_bwd(xc, sp.L, P, ebar, xbar, barf_w=sv["barf_w"], accumulate=True)
+        if grp is not None:
+            grp.flush()
         # ---------- deformation ----------
         K.invskin_bwd(xc, sv["w_def"], sv["dfm"]["tfs"], sp.n_bones, P, ppf, xbar, dtfs)
         # ---------- map back to the layouts of the effective nn.Linear weights ----------

@@ -921,11 +921,15 @@ class Background(nn.Module):
             r = [pool.get(f"rs{l}", P, 256) for l in range(7)] + [cur]
             K.chain(K.CHAIN_DSP, P, cur, None, 7, 32, skip_layer=3, aux1=[h[l - 1] for l in range(7, 0, -1)],
                     out=[r[l - 1] for l in range(7, 0, -1)], wpack_r6=wr6, skip_out=so)
+            grp = G.WgradGroup() if _field.USE_WGRAD_GROUP else None  # every r_l has a buffer of its own: one launch for the 7
+            wg = G.wgrad if grp is None else grp.add
             for l in range(7, 0, -1):
                 if l == 3:
-                    G.wgrad(r[3], h[2], dW[3], dWb[3], N=so)
+                    wg(r[3], h[2], dW[3], dWb[3], N=so)
                 else:
-                    G.wgrad(r[l], h[l - 1], dW[l], dWb[l])
+                    wg(r[l], h[l - 1], dW[l], dWb[l])
+            if grp is not None:
+                grp.flush()
             cur = r[0]
         else:
             for l in range(7, 0, -1):

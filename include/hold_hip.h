@@ -91,6 +91,26 @@ int hold_wgrad_x6(const float* R, int32_t ldr, const float* X, int32_t ldx, int3
                   float* dW, int32_t lddw, float* db, int32_t accumulate, int32_t splits, float* workspace,
                   hold_stream_t stream);
 
+/* Several weight gradients over the SAME P points in one launch (the 15 of a node's implicit-net backward -- torch
+ * autograd's per-Linear `grad_output.T @ input`, reference code/src/networks/shape_net.py:84-130 -- plus the colour
+ * net's): item i contributes  R_i[:, :N]^T X_i[:, :256]  (and the column sums of R_i[:, :N] when db is given) to its
+ * dW / db.  Items with the same dW must be adjacent in the list and are summed into it in ONE deterministic reduction;
+ * `accumulate` of the first item of such a run decides whether dW / db's previous content is kept.  A compute unit
+ * works on one (item, share of the points): the launch writes one partial tile per compute unit for all items together
+ * instead of one per compute unit and item.  Split-precision arithmetic of hold_wgrad_x6.  Requirements: n_items <= 24,
+ * P a multiple of 16, R and X at least 256 floats wide in memory (256 columns of both are read; what the columns >= N
+ * of R hold is never used), 16-byte aligned, leading dimensions multiples of 4; HOLD_E_ARG otherwise.
+ * workspace >= hold_wgrad_group_workspace_floats() floats. */
+typedef struct hold_wgrad_item {
+  const float* R; const float* X;   /* [P, ldr], [P, ldx] */
+  float* dW; float* db;             /* [N, lddw] (256 columns written), [N] or NULL */
+  int32_t ldr, ldx, lddw, N;
+  int32_t accumulate, reserved;
+} hold_wgrad_item;
+int64_t hold_wgrad_group_workspace_floats(void);
+int hold_wgrad_group_x6(const hold_wgrad_item* items, int32_t n_items, int64_t P, float* workspace,
+                        hold_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Per-point kernels (hold_amd/csrc/points.hip)
  * ---------------------------------------------------------------------------------------- */

@@ -173,6 +173,95 @@ def test_wgrad_whole_layer_workgroups_other_shapes(P, N, K, ldr, ldx):
     assert ((dW2.double() - (ref - 1)).abs().max() / ref.abs().max()).item() < 1e-5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [4096, 20000, 131072 + 48])
+def test_wgrad_group_matches_fp64_and_single_launches(P):
+    """hold_wgrad_group_x6: several (R, X) pairs over the same points in one launch -- two pairs sharing a destination (one
+    with a bias, one without; the 217-row layer with its columns 217..255 poisoned), single pairs with and without bias,
+    accumulate on and off -- against fp64 (the grouped kernel splits the points differently from hold_wgrad_x6, so the
+    comparison with a single launch is at 1e-5 too, not bit for bit), with sentinels around every destination."""
+    import hold_amd
+    from hold_amd import gemm
+    if hold_amd.precision() != "f32x6":
+        pytest.skip("split-precision path")
+    dev = _dev()
+    torch.manual_seed(P)
+    mk = lambda ld=256: torch.randn(P, ld, device=dev)
+    R = [mk(), mk(), mk(), mk(260), mk(), mk()]
+    X = [mk(), mk(), mk(), mk(), mk(272), mk()]
+    R[2][:, 217:] = float("nan")
+    R[3][:, 217:256] = float("inf")
+    big = torch.full((5, 258, 260), 7.0, device=dev)
+    dW = [big[i, 1:257, :256] for i in range(4)]
+    dW[1] = big[1, 1:218, :256]
+    for d in dW:
+        d.fill_(1.0)
+    db = [torch.full((256,), 1.0, device=dev) for _ in range(4)]
+    grp = gemm.WgradGroup()
+    grp.add(R[0], X[0], dW[0], db[0], accumulate=True)            # destination 0: two pairs, bias from the first only
+    grp.add(R[2], X[2], dW[1], None, N=217, accumulate=True)      # destination 1 (217 rows): two pairs, bias from the second
+    grp.add(R[1], X[1], dW[0], None, accumulate=True)
+    grp.add(R[3], X[3], dW[1], db[1][:217], N=217, accumulate=True)
+    grp.add(R[4], X[4][:, :256], dW[2], db[2])                    # single pair, overwrite, X wider in memory
+    grp.add(R[5], X[5], dW[3], None, accumulate=True)             # single pair, no bias
+    grp.flush()
+    dd = lambda a, b: a.double().t() @ b.double()
+    ref = [dd(R[0], X[0]) + dd(R[1], X[1]) + 1, dd(R[2][:, :217], X[2]) + dd(R[3][:, :217], X[3]) + 1,
+           dd(R[4], X[4][:, :256]), dd(R[5], X[5]) + 1]
+    refb = [R[0].double().sum(0) + 1, R[3][:, :217].double().sum(0) + 1, R[4].double().sum(0)]
+    for i in range(4):
+        assert torch.isfinite(dW[i]).all(), i
+        assert ((dW[i].double() - ref[i]).abs().max() / ref[i].abs().max()).item() < 1e-5, i
+    assert ((db[0].double() - refb[0]).abs().max() / refb[0].abs().max()).item() < 1e-5
+    assert ((db[1][:217].double() - refb[1]).abs().max() / refb[1].abs().max()).item() < 1e-5
+    assert torch.all(db[1][217:] == 1.0)
+    assert ((db[2].double() - refb[2]).abs().max() / refb[2].abs().max()).item() < 1e-5
+    assert torch.all(db[3] == 1.0)
+    # nothing outside the destinations was touched
+    assert torch.all(big[4] == 7.0) and torch.all(big[:, 0] == 7.0) and torch.all(big[:, 257] == 7.0)
+    assert torch.all(big[:, :, 256:] == 7.0) and torch.all(big[1, 218:257] == 7.0)
+    # the same pairs one launch each
+    one = torch.zeros(256, 256, device=dev)
+    gemm.wgrad(R[5], X[5], one, None)
+    assert ((one.double() + 1 - dW[3].double()).abs().max() / ref[3].abs().max()).item() < 1e-5
+    # run-to-run determinism of the grouped reduction
+    again = [torch.ones(256, 256, device=dev), torch.ones(256, device=dev)]
+    g2 = gemm.WgradGroup()
+    g2.add(R[0], X[0], again[0], again[1], accumulate=True)
+    g2.add(R[1], X[1], again[0], None, accumulate=True)
+    g2.add(R[5], X[5], torch.empty(256, 256, device=dev), None)
+    g2.flush()
+    assert ((again[0].double() - ref[0]).abs().max() / ref[0].abs().max()).item() < 1e-5
+    assert ((again[1].double() - refb[0]).abs().max() / refb[0].abs().max()).item() < 1e-5
+
+
+def test_wgrad_group_rejects_what_it_cannot_take():
+    """the C entry point's argument checks (no GPU work is launched for a rejected list)"""
+    import ctypes as C
+    from hold_amd import _lib
+    L = _lib.lib()
+    it = (_lib.WgradItem * 3)()
+    for a in it:
+        a.R = a.X = a.dW = 256  # never dereferenced: every case below is rejected before the launch
+        a.ldr = a.ldx = a.lddw = 256
+        a.N = 256
+    ws = C.c_void_p(256)
+    assert L.hold_wgrad_group_x6(it, 0, 4096, ws, None) != 0           # empty list
+    assert L.hold_wgrad_group_x6(it, 25, 4096, ws, None) != 0          # too many pairs
+    assert L.hold_wgrad_group_x6(it, 1, 4100, ws, None) != 0           # P not a multiple of 16
+    it[0].ldr = 128
+    assert L.hold_wgrad_group_x6(it, 1, 4096, ws, None) != 0           # R narrower than 256 floats in memory
+    it[0].ldr = 256
+    it[0].N = 300
+    assert L.hold_wgrad_group_x6(it, 1, 4096, ws, None) != 0           # more than 256 rows
+    it[0].N = 256
+    it[0].R = 260
+    assert L.hold_wgrad_group_x6(it, 1, 4096, ws, None) != 0           # misaligned operand
+    it[0].R = 256
+    it[1].dW = 512
+    assert L.hold_wgrad_group_x6(it, 3, 4096, ws, None) != 0           # pairs of one destination not adjacent
+
+
 def test_fused_sdf_matches_layered_path():
     """hold_fused_sdf (LDS-resident 8-layer trunk) against the layer-by-layer GEMM path on the same weights."""
     import numpy as np
