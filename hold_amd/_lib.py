@@ -120,7 +120,7 @@ SIGNATURES = {
     "hold_ray_points": [_P, _P, _P, _I, _I, _L, _P, _I, _P],
     "hold_embed_fwd": [_P, _I, _I, _I, _P, _L, _P, _I, _P, _I, _P, _I, _L, _P],
     "hold_embed_bwd": [_P, _I, _I, _P, _L, _P, _I, _P, _I, _I, _P],
-    "hold_embed_bwd2": [_P, _I, _I, _P, _L, _P, _I, _P, _I, _P, _I, _P, _I, _P],
+    "hold_embed_bwd2": [_P, _I, _I, _P, _L, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P],
     "hold_knn_invlbs_fwd": [_P, _I, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _P],
     "hold_invskin_fwd": [_P, _I, _L, _L, _P, _P, _I, _P, _I, _P],
     "hold_raygen": [_P, _P, _P, _I, _L, _L, _P, _P, _P],

@@ -85,9 +85,13 @@ __global__ void embed_bwd_kernel(const float* __restrict__ x, int ldx, int L, co
 
 // double backward of g = E^T ge:  gebar[p][j] = dE_j/dx_dim(j) * gbar[p][dim(j)];
 //                                 xbar[p][dim] += gbar[p][dim] * sum_j d2E_j/dx_dim^2 * ge[p][j]
+// gebar2 (optional): a second copy of gebar's E columns -- the skip layer's side columns of the ascending sweep live in
+// columns 217.. of t_3, which is also where `ge` itself lives (field.py), so gebar2 MAY ALIAS ge: a thread reads the two
+// ge entries of a frequency before it writes them (no other thread touches them), hence no __restrict__ on either.
 __global__ void embed_bwd2_kernel(const float* __restrict__ x, int ldx, int L, const float* __restrict__ bw, long P,
-                                  const float* __restrict__ ge, int ldge, const float* __restrict__ gbar, int ldgb,
-                                  float* __restrict__ gebar, int ldgeb, float* __restrict__ xbar, int ldxb) {
+                                  const float* ge, int ldge, const float* __restrict__ gbar, int ldgb,
+                                  float* __restrict__ gebar, int ldgeb, float* __restrict__ xbar, int ldxb,
+                                  float* gebar2, int ldgeb2) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P * 3) return;
   const long p = i / 3;
@@ -96,7 +100,10 @@ __global__ void embed_bwd2_kernel(const float* __restrict__ x, int ldx, int L, c
   const float gb = gbar[p * ldgb + dim];
   const float* g = ge + p * ldge;
   float* o = gebar + p * ldgeb;
-  o[dim] = gb * (bw ? bw[dim] : 1.f);
+  float* o2 = gebar2 ? gebar2 + p * ldgeb2 : nullptr;
+  const float v0 = gb * (bw ? bw[dim] : 1.f);
+  o[dim] = v0;
+  if (o2) o2[dim] = v0;
   float acc = 0.f;
   for (int k = 0; k < L; ++k) {
     const float f = (float)(1 << k);
@@ -104,9 +111,15 @@ __global__ void embed_bwd2_kernel(const float* __restrict__ x, int ldx, int L, c
     sincosf(xv * f, &s, &c);
     const int js = 3 + 6 * k + dim, jc = js + 3;
     const float ws = bw ? bw[js] : 1.f, wc = bw ? bw[jc] : 1.f;
-    o[js] = gb * f * c * ws;
-    o[jc] = -gb * f * s * wc;
-    acc += -f * f * (s * ws * g[js] + c * wc * g[jc]);
+    const float gs = g[js], gc = g[jc];
+    const float vs = gb * f * c * ws, vc = -gb * f * s * wc;
+    o[js] = vs;
+    o[jc] = vc;
+    if (o2) {
+      o2[js] = vs;
+      o2[jc] = vc;
+    }
+    acc += -f * f * (s * ws * gs + c * wc * gc);
   }
   if (xbar) xbar[p * ldxb + dim] += gb * acc;
 }
@@ -617,11 +630,11 @@ extern "C" int hold_embed_bwd(const float* x, int32_t ldx, int32_t L, const floa
 
 extern "C" int hold_embed_bwd2(const float* x, int32_t ldx, int32_t L, const float* barf_w, int64_t P, const float* ge,
                                int32_t ldge, const float* gbar, int32_t ldgb, float* gebar, int32_t ldgeb, float* xbar,
-                               int32_t ldxb, hold_stream_t st) {
-  if (!x || !ge || !gbar || !gebar) return HOLD_E_ARG;
+                               int32_t ldxb, float* gebar2, int32_t ldgeb2, hold_stream_t st) {
+  if (!x || !ge || !gbar || !gebar || gebar == ge) return HOLD_E_ARG;
   if (P == 0) return HOLD_OK;
   hipLaunchKernelGGL(embed_bwd2_kernel, dim3(nblk(P * 3)), dim3(256), 0, (hipStream_t)st, x, ldx, L, barf_w, (long)P, ge,
-                     ldge, gbar, ldgb, gebar, ldgeb, xbar, ldxb);
+                     ldge, gbar, ldgb, gebar, ldgeb, xbar, ldxb, gebar2, ldgeb2);
   return ok();
 }
 

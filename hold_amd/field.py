@@ -418,7 +418,8 @@ class NodeField:
             outs = [t[l - 1] if (keep_all or l - 1 in (0, 3)) else None for l in range(7, 0, -1)]
             K.chain(K.CHAIN_DSP, P, t[7], pk["chain_bwd"], 7, 32, skip_layer=3, aux1=[h[l - 1] for l in range(7, 0, -1)],
                     out=outs, wpack_x6=pk.get("chain_bwd_x6"), wpack_r6=pk.get("chain_bwd_r6") if USE_R6_BWD else None)
-            K.copy_cols(t[3][:, sp.skip_out:], ge, sp.E, P)  # raw columns 217.. = d sdf / d (skip embedding)
+            # raw columns 217.. of t_3 = d sdf / d (skip embedding): `ge` IS that view (self._ge_buffer), no copy
+            assert ge.data_ptr() == t[3].data_ptr() + 4 * sp.skip_out
         else:
             for l in range(7, 0, -1):
                 if l == 4:
@@ -428,7 +429,14 @@ class NodeField:
                     G.gemm_nt(t[3], WT[3], t[2], epi=G.EPI_MUL_DSP, aux1=h[2], K=sp.skip_pad)
                 else:
                     G.gemm_nt(t[l], WT[l], t[l - 1], epi=G.EPI_MUL_DSP, aux1=h[l - 1])
-        G.gemm_nt(t[0], WT[0], ge, N=sp.K0, accumulate=True)
+        G.gemm_nt(t[0], WT[0], ge, N=ge.shape[1], accumulate=True)
+
+    def _ge_buffer(self, t, P):
+        """d sdf / d embedding [P, E]: with the layer chains it stays where the descending sweep leaves its skip part --
+        columns 217.. of t_3 (row stride 256) -- and layer 0's part is accumulated there; otherwise a [P, K0] buffer."""
+        if USE_CHAIN:
+            return t[3][:, self.spec.skip_out:]
+        return self.pool.get("ge", P, self.spec.K0)
 
     def sdf_only(self, pk, x, P, ppf, dfm, barf_w, out_sdf):
         """no-grad SDF query of the sampler (sdf_func_with_deformer, volsdf_utils.py:150-169).  out_sdf [P,1]."""
@@ -467,7 +475,7 @@ class NodeField:
         WT = pk["WT"]
         # t[3] always has its own buffer: its columns 217..219 are K-padding of the next GEMM and must stay zero
         t = [pool.get(f"t{l}" if (training or l == 3) else f"t_pp{l & 1}", P, 256) for l in range(8)]
-        ge = pool.get("ge", P, sp.K0)
+        ge = self._ge_buffer(t, P)
         self._reverse_sweep(pk, h, t, ge, P, keep_all=training)
         g = pool.get("g", P, 4)
         K.embed_bwd(xc, sp.L, P, ge, g, barf_w=barf_w)
@@ -502,7 +510,7 @@ class NodeField:
                     grad=g)
 
     # ------------------------------------------------------------------ shared backward sweeps
-    def _second_order_sweep(self, pk, h, t, gebar, dW, P, grp=None):
+    def _second_order_sweep(self, pk, h, t, gebar, dW, P, grp=None, side_in_t3=False):
         """ascending sweep of the double backward: tbar_l = W_l vbar_l, ubar_l = tbar_l * s_l,
         a2_l = 100 * tbar_l * t_l * (1 - s_l); dW_l += t_l^T vbar_l.  Returns (a2[8], ubar_7)."""
         sp, pool, W = self.spec, self.bpool, pk["W"]
@@ -510,10 +518,10 @@ class NodeField:
         if USE_CHAIN:
             vb = [pool.get(f"vbc{l}", P, 256) for l in range(8)]
             wr6 = pk.get("trunk_r6") if USE_R6_BWD else None
-            if wr6 is not None:
+            if wr6 is not None and not side_in_t3:
                 # register-resident sweep (csrc/rchain.hip): it takes the skip layer's side columns (the next input's columns
-                # 217.. = the embedding cotangent) from aux2[3][:, 217:] -- that part of t_3 held the raw d sdf / d embedding
-                # products, which the forward copied out to `ge` right after its reverse sweep and nobody reads again
+                # 217.. = the embedding cotangent) from aux2[3][:, 217:]; the callers let hold_embed_bwd2 write them there
+                # (side_in_t3), this copy is for anyone who did not
                 K.copy_cols(gebar, t[3][:, sp.skip_out:], sp.E, P)
             K.chain(K.CHAIN_DBWD, P, gebar, pk["fused"][0], 8, 5, skip_layer=3, side=gebar, aux1=h, aux2=t, out=vb,
                     out2=a2, wpack_x6=pk.get("chain_fwd_x6"), wpack_r6=wr6)
@@ -548,8 +556,9 @@ class NodeField:
 
     def _first_order_sweep(self, pk, h, a2, r7, in0, dW, dWb, ebar, P, grp=None):
         """descending sweep r_{l-1} = (W_l^T r_l) * s_{l-1} + a2_{l-1} from r_7 down to r_0 with
-        dW_l += r_l^T in_l, db_l += sum r_l; the skip columns of W_4^T r_4 go to ebar[:, :39] (if given).
-        Returns r_0."""
+        dW_l += r_l^T in_l, db_l += sum r_l; with `ebar` true the skip columns of W_4^T r_4 are kept.
+        Returns (r_0, ebar) -- with the layer chains ebar is the view r_3[:, 217:] (row stride 256) the sweep wrote them
+        to (no copy; r_3's weight gradient only reduces the rows < 217), otherwise a [P, K0] buffer; None if not asked."""
         sp, pool, WT = self.spec, self.bpool, pk["WT"]
         if USE_CHAIN:
             r = [pool.get(f"rbc{l}", P, 256) for l in range(7)] + [r7]
@@ -559,16 +568,16 @@ class NodeField:
                     # register-resident sweep, with or without the additive side input: since round 4 its side traffic moves
                     # as whole 128-byte lines through LDS (rtile_kernel: 140 vs 122 TF-eq for hold_chain_x6 with a2)
                     wpack_r6=pk.get("chain_bwd_r6") if USE_R6_BWD else None)
-            if ebar is not None:
-                K.copy_cols(r[3][:, sp.skip_out:], ebar, sp.E, P)
+            ebar = r[3][:, sp.skip_out:] if ebar else None
             wg = G.wgrad if grp is None else grp.add
             for l in range(7, 0, -1):
                 if l == 3:
                     wg(r[3], h[2], dW[3], dWb[3], N=sp.skip_out, accumulate=True)
                 else:
                     wg(r[l], h[l - 1], dW[l], dWb[l], accumulate=True)
-            return r[0]
+            return r[0], ebar
         rb_ = [pool.get(f"rb{i}", P, 256) for i in range(2)]
+        ebar = pool.get("ebar", P, sp.K0) if ebar else None
         cur = r7
         A2 = lambda i: None if a2 is None else a2[i]
         for l in range(7, 0, -1):
@@ -590,7 +599,7 @@ class NodeField:
                 G.wgrad(cur, h[l - 1], dW[l], dWb[l], accumulate=True)
                 G.gemm_nt(cur, WT[l], nxt, epi=G.EPI_MUL_DSP, aux1=h[l - 1], aux2=A2(l - 1))
             cur = nxt
-        return cur
+        return cur, ebar
 
     # ------------------------------------------------------------------ ImplicitNet.forward (shape_net.py:84-130)
     def sdf_feat_forward(self, pk, xc, P, barf_w):
@@ -613,13 +622,12 @@ class NodeField:
         G.wgrad(ob, h[7], dW[8], dWb[8], N=257, accumulate=True)
         r7 = pool.get("r7", P, 256)
         G.gemm_nt(ob, WT[8], r7, epi=G.EPI_MUL_DSP, aux1=h[7], K=260)
-        ebar = pool.get("ebar", P, sp.K0)
         grp = G.WgradGroup() if (USE_CHAIN and USE_WGRAD_GROUP) else None
-        cur = self._first_order_sweep(pk, h, None, r7, sv["in0"], dW, dWb, ebar, P, grp)
+        cur, ebar = self._first_order_sweep(pk, h, None, r7, sv["in0"], dW, dWb, True, P, grp)
         G.wgrad(cur, sv["in0"], dW[0], dWb[0], K=sp.K0, accumulate=True)
         if grp is not None:
             grp.flush()
-        G.gemm_nt(cur, WT[0], ebar, N=sp.K0, accumulate=True)
+        G.gemm_nt(cur, WT[0], ebar, N=ebar.shape[1], accumulate=True)
         xbar = pool.get("xbar", P, 4)
         K.embed_bwd(xc, sp.L, P, ebar, xbar, barf_w=sv["barf_w"])
         d0 = torch.zeros(256, pk["iw0_cols"], device=dev)
@@ -638,7 +646,7 @@ class NodeField:
         in0, h = self._trunk(pk, xc, P, barf_w, keep_all=True)
         WT = pk["WT"]
         t = [pool.get(f"t{l}", P, 256) for l in range(8)]
-        ge = pool.get("ge", P, sp.K0)
+        ge = self._ge_buffer(t, P)
         self._reverse_sweep(pk, h, t, ge, P, keep_all=True)
         g = pool.get("g", P, 4)
         K.embed_bwd(xc, sp.L, P, ge, g, barf_w=barf_w)
@@ -656,13 +664,15 @@ class NodeField:
         gb = pool.get("gbar", P, 4)
         K.copy_cols(gbar.contiguous(), gb, 3, P)
         gebar = pool.get("gebar", P, sp.K0)
-        K.embed_bwd2(xc, sp.L, P, sv["ge"], gb, gebar, xbar=None, barf_w=sv["barf_w"])
+        # in chain mode ge lives in t_3's skip columns, where the ascending sweep wants gebar next: written in place
+        K.embed_bwd2(xc, sp.L, P, sv["ge"], gb, gebar, xbar=None, barf_w=sv["barf_w"],
+                     gebar2=t[3][:, sp.skip_out:] if USE_CHAIN else None)
         grp = G.WgradGroup() if (USE_CHAIN and USE_WGRAD_GROUP) else None
-        a2, u7 = self._second_order_sweep(pk, h, t, gebar, dW, P, grp)
+        a2, u7 = self._second_order_sweep(pk, h, t, gebar, dW, P, grp, side_in_t3=USE_CHAIN)
         d_w8sdf = torch.zeros(256, device=dev)
         G.wcolsum(u7, d_w8sdf, N=256)
         # first-order sweep driven only by the second-order terms a2_l (out_bar = 0  =>  r_7 = a2_7)
-        cur = self._first_order_sweep(pk, h, a2, a2[7], sv["in0"], dW, dWb, None, P, grp)
+        cur, _ = self._first_order_sweep(pk, h, a2, a2[7], sv["in0"], dW, dWb, False, P, grp)
         G.wgrad(cur, sv["in0"], dW[0], dWb[0], K=sp.K0, accumulate=True)
         if grp is not None:
             grp.flush()
@@ -738,8 +748,9 @@ class NodeField:
         xbar = pool.get("xbar", P, 4)
         K.copy_cols(d_rin[:, RIN_X:RIN_X + 3], xbar, 3, P)
         gebar = pool.get("gebar", P, sp.K0)
-        K.embed_bwd2(xc, sp.L, P, sv["ge"], gbar, gebar, xbar=xbar, barf_w=sv["barf_w"])
-        a2, u7 = self._second_order_sweep(pk, h, t, gebar, dW, P, grp)
+        K.embed_bwd2(xc, sp.L, P, sv["ge"], gbar, gebar, xbar=xbar, barf_w=sv["barf_w"],
+                     gebar2=t[3][:, sp.skip_out:] if USE_CHAIN else None)
+        a2, u7 = self._second_order_sweep(pk, h, t, gebar, dW, P, grp, side_in_t3=USE_CHAIN)
         # gradient of the sdf row of W8: ubar_7 (second-order path) + the first-order term d_sdf^T h7, both as
         # deterministic (weighted) column sums -- a 257th wgrad row would cost a whole 128-row tile
         d_sdf = d_sdf.reshape(P)
@@ -754,10 +765,9 @@ class NodeField:
         r7 = pool.get("r7", P, 256)
         G.gemm_nt(d_feat, pk["WT8_feat"], r7, epi=G.EPI_MUL_DSP, aux1=h[7], aux2=a2[7], K=256, r1_row=d_sdf,
                   r1_col=pk["w8_sdf"])
-        ebar = pool.get("ebar", P, sp.K0)
-        cur = self._first_order_sweep(pk, h, a2, r7, sv["in0"], dW, dWb, ebar, P, grp)
+        cur, ebar = self._first_order_sweep(pk, h, a2, r7, sv["in0"], dW, dWb, True, P, grp)
         G.wgrad(cur, sv["in0"], dW[0], dWb[0], K=sp.K0, accumulate=True)
-        G.gemm_nt(cur, WT[0], ebar, N=sp.K0, accumulate=True)
+        G.gemm_nt(cur, WT[0], ebar, N=ebar.shape[1], accumulate=True)
         K.embed_bwd(xc, sp.L, P, ebar, xbar, barf_w=sv["barf_w"], accumulate=True)
         if grp is not None:
             grp.flush()

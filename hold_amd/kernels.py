@@ -44,9 +44,11 @@ def embed_bwd(x, L, P, ge, gx, barf_w=None, accumulate=False):
     call("hold_embed_bwd", ptr(x), _ld(x), L, ptr(barf_w), P, ptr(ge), _ld(ge), ptr(gx), _ld(gx), int(accumulate))
 
 
-def embed_bwd2(x, L, P, ge, gbar, gebar, xbar=None, barf_w=None):
+def embed_bwd2(x, L, P, ge, gbar, gebar, xbar=None, barf_w=None, gebar2=None):
+    """gebar2: optional second copy of gebar's columns; may be the buffer `ge` itself lives in (see hold_hip.h)"""
     call("hold_embed_bwd2", ptr(x), _ld(x), L, ptr(barf_w), P, ptr(ge), _ld(ge), ptr(gbar), _ld(gbar), ptr(gebar),
-         _ld(gebar), ptr(xbar), _ld(xbar) if xbar is not None else 0)
+         _ld(gebar), ptr(xbar), _ld(xbar) if xbar is not None else 0, ptr(gebar2),
+         _ld(gebar2) if gebar2 is not None else 0)
 
 
 def knn_invlbs(x, P, pts_per_frame, verts, skin_w, tfs=None, w_out=None, xc_out=None):

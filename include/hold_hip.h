@@ -130,10 +130,13 @@ int hold_embed_fwd(const float* x, int32_t ldx, int32_t d_in, int32_t L, const f
  * code/src/engine/volsdf_utils.py:89-96 (gradient of sdf w.r.t. canonical points). */
 int hold_embed_bwd(const float* x, int32_t ldx, int32_t L, const float* barf_w, int64_t P, const float* ge,
                    int32_t ldge, float* gx, int32_t ldgx, int32_t accumulate, hold_stream_t stream);
-/* double backward of the line above: gebar = (d embed/dx) gbar ; xbar += gbar * (d2 embed/dx2 . ge) */
+/* double backward of the line above: gebar = (d embed/dx) gbar ; xbar += gbar * (d2 embed/dx2 . ge).
+ * gebar2 (NULL to disable): a second copy of gebar's 3 + 6 L columns; it MAY alias ge (each entry of ge is read before the
+ * same thread overwrites it) -- the host keeps ge in the skip columns of t_3, where the ascending sweep of the double
+ * backward (hold_chain_r6, HOLD_CHAIN_DBWD) expects gebar afterwards.  gebar itself must not alias ge. */
 int hold_embed_bwd2(const float* x, int32_t ldx, int32_t L, const float* barf_w, int64_t P, const float* ge,
                     int32_t ldge, const float* gbar, int32_t ldgb, float* gebar, int32_t ldgeb, float* xbar,
-                    int32_t ldxb, hold_stream_t stream);
+                    int32_t ldxb, float* gebar2, int32_t ldgeb2, hold_stream_t stream);
 
 /* KNN(K=15) skinning-weight lookup against the frame's posed (or the canonical) MANO vertices, fused
  * with inverse LBS when xc_out != NULL:  w = sum_k softmax-like conf_k * W[idx_k]  (detached),
