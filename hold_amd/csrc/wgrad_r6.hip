@@ -15,6 +15,10 @@
 // Roofline: bf16 MFMA pipe (6 limb products per algorithmic product); HBM 2 KiB per point (each operand row once).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#ifdef HOLD_DEV
+#include <stdio.h>
+#include <stdlib.h>
+#endif
 
 #include "../../include/hold_hip.h"
 
@@ -96,7 +100,11 @@ constexpr int rs(int f) { return 85 * f / 8; }
 constexpr int ws(int f) { return 11 + 85 * f / 8; }
 
 // the steps [s0, s1) of one (R, X) pair by one workgroup -> its partial tile out[256][256] (and out_b[256])
-template <bool BIAS>
+// ABL (developer builds only, results garbage): 1 = no fragment reads / limb splits in the steps (the first step's limbs
+// are reused), 2 = no LDS-DMA in the steps, 3 = no MFMAs -- what each of the three streams costs on its own
+// DIST = how many steps ahead of the MFMAs the rows are requested (3 or 4 -- with 4 the request made during step t goes to
+// the slot of step t itself, whose rows were consumed by the preparation that ran during step t - 1)
+template <bool BIAS, int ABL = 0, int DIST = 3>
 __device__ __forceinline__ void wgrad_r6_body(const float* R, int ldr, const float* X, int ldx, long s0, long s1,
                                               float* out, float* out_b) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -113,7 +121,7 @@ __device__ __forceinline__ void wgrad_r6_body(const float* R, int ldr, const flo
   const char* mrow0 = reinterpret_cast<const char*>(M) + (wave & 1) * 8 * rowb;  // this wave's first row of step 0
   const uint32_t dst0 = (uint32_t)((wave >> 1) * 16384 + (wave & 1) * 8 * 1024);
   // rows of step u (beyond the range: the last step again, which keeps the vmcnt arithmetic uniform); p walks the rows
-  auto step_src = [&](long u) { return mrow0 + (u < s1 ? u : s1 - 1) * 16 * rowb; };
+  auto step_src = [&](long u) { return mrow0 + (ABL == 4 ? s0 + (u & 1) : (u < s1 ? u : s1 - 1)) * 16 * rowb; };
   // ---- fragment reads: column c = 32 f' + li of the wave's 128 (f' = 0..3), rows 8 hh .. 8 hh + 7 of the 16; the row
   // half's swizzle flips bit 5 of the column = bit 7 of the byte address, so fragment f' is an XOR of the base address
   const uint32_t rdA = (uint32_t)((8 * hh) * 1024 + ((128 * wn + li) ^ (32 * hh)) * 4);
@@ -133,13 +141,13 @@ __device__ __forceinline__ void wgrad_r6_body(const float* R, int ldr, const flo
 
   if (s0 < s1) {
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
+    for (int u = 0; u < DIST; ++u) {
       const char* p = step_src(s0 + u);
 #pragma unroll
       for (int i = 0; i < 8; ++i) dma_piece(p + i * rowb, dvoff, (uint32_t)((int)((s0 + u) % NST) * STAGE) + dst0 + i * 1024);
     }
-    const char* dptr = step_src(s0 + 3);  // rows of the step requested during the running one
-    WG_WAIT_VM(16);
+    const char* dptr = step_src(s0 + DIST);  // rows of the step requested during the running one
+    WG_WAIT_VM(8 * (DIST - 1));
     __builtin_amdgcn_s_barrier();
 
     Limbs8 L0, L1;
@@ -173,26 +181,28 @@ __device__ __forceinline__ void wgrad_r6_body(const float* R, int ldr, const flo
 
     // One step: 96 MFMAs on the limbs C of step t; behind each a slice of the preparation of step t + 1 into N.
     auto step = [&](long t, Limbs8& C, Limbs8& N) {
-      WG_WAIT_VM(8);  // the rows of step t + 1 have landed (younger: the eight pieces of step t + 2)
+      if (ABL == 2) WG_WAIT_VM(0); else
+      WG_WAIT_VM(8 * (DIST - 2));  // the rows of step t + 1 have landed (younger: the pieces of the steps t + 2 .. t + DIST - 1)
       __builtin_amdgcn_s_barrier();  // ... in every wave; and every wave is done reading the slot of step t
       const uint32_t sb = (uint32_t)((int)((t + 1) % NST) * STAGE);
-      const uint32_t db = (uint32_t)((int)((t + 3) % NST) * STAGE) + dst0;
+      const uint32_t db = (uint32_t)((int)((t + DIST) % NST) * STAGE) + dst0;
       const char* p = dptr;
-      dptr = (t + 4 < s1) ? dptr + 16 * rowb : dptr;
+      dptr = (ABL != 4 && t + DIST + 1 < s1) ? dptr + 16 * rowb : dptr;
       if (BIAS && t + 1 >= s1) sel[0] = sel[1] = false;
 #pragma unroll
       for (int m = 0; m < 96; ++m) {
         const int aa = m / 24, pr = (m % 24) / 4, bb = m % 4;  // four accumulators in rotation
         const int il = (pr == 2 || pr == 3) ? 1 : (pr == 5 ? 2 : 0);  // (R limb, X limb): 00 01 10 11 02 20
         const int jl = (pr == 1 || pr == 3) ? 1 : (pr == 4 ? 2 : 0);
-        acc[aa][bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, C.l[aa][il]),
-                                                              __builtin_bit_cast(bf16x8, C.l[4 + bb][jl]), acc[aa][bb], 0, 0, 0);
-        if (m % 12 == 5) {
+        if (ABL != 3)
+          acc[aa][bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, C.l[aa][il]),
+                                                                __builtin_bit_cast(bf16x8, C.l[4 + bb][jl]), acc[aa][bb], 0, 0, 0);
+        if (ABL != 2 && m % 12 == 5) {
           dma_piece(p, dvoff, db + (m / 12) * 1024);
           p += rowb;
         }
 #pragma unroll
-        for (int f = 0; f < 8; ++f) {
+        for (int f = 0; f < (ABL == 1 ? 0 : 8); ++f) {
           if (m >= rs(f) && m < rs(f) + 8) {
             const int e = m - rs(f);
             fs[f & 1].x[e] = *reinterpret_cast<const float*>(frag_addr(f, sb) + e * 1024);
@@ -218,8 +228,8 @@ __device__ __forceinline__ void wgrad_r6_body(const float* R, int ldr, const flo
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) asm volatile("" : "+a"(acc[i][j][r]));  // the accumulators live in the AGPR half
-      step(t, L0, L1);
-      if (t + 1 < s1) step(t + 1, L1, L0);
+      step(t, L0, ABL == 1 ? L0 : L1);
+      if (t + 1 < s1) step(t + 1, ABL == 1 ? L0 : L1, L0);
     }
     WG_WAIT_VM(0);  // no LDS-DMA may still be in flight when the workgroup's LDS is released
   }
@@ -243,11 +253,11 @@ __device__ __forceinline__ void wgrad_r6_body(const float* R, int ldr, const flo
   }
 }
 
-template <bool BIAS>
+template <bool BIAS, int ABL = 0, int DIST = 3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wgrad_r6_kernel(WArgs a) {
   const long s0 = (long)blockIdx.x * a.spw;
   const long s1 = s0 + a.spw < a.nsteps ? s0 + a.spw : a.nsteps;
-  wgrad_r6_body<BIAS>(a.R, a.ldr, a.X, a.ldx, s0, s1, a.part + (long)blockIdx.x * 65536,
+  wgrad_r6_body<BIAS, ABL, DIST>(a.R, a.ldr, a.X, a.ldx, s0, s1, a.part + (long)blockIdx.x * 65536,
                       BIAS ? a.part_b + (long)blockIdx.x * 256 : nullptr);
 }
 
@@ -359,6 +369,22 @@ int hold_wgrad_r6_partials(const float* R, int ldr, const float* X, int ldx, lon
   if (G > a.nsteps) G = a.nsteps;
   a.spw = (int)((a.nsteps + G - 1) / G);
   G = (a.nsteps + a.spw - 1) / a.spw;  // every workgroup owns at least one step
+#ifdef HOLD_DEV  // timing ablations (developer build only): what the limb preparation / the LDS-DMA / the MFMAs cost alone
+  if (const char* ab = getenv("HOLD_WGRAD_ABL")) {
+    const int v = atoi(ab);
+    static bool warned = false;
+    if (v && !warned) fprintf(stderr, "libholdhip: HOLD_WGRAD_ABL=%d -- timing ablation, hold_wgrad_x6 results are WRONG\n", v);
+    warned = true;
+    if (v >= 1 && v <= 6) {  // 4: rows from two L2-resident steps; 5: requests four steps ahead; 6: both
+      auto k = v == 1 ? wgrad_r6_kernel<false, 1> : v == 2 ? wgrad_r6_kernel<false, 2> : v == 3 ? wgrad_r6_kernel<false, 3>
+             : v == 4 ? wgrad_r6_kernel<false, 4> : v == 5 ? wgrad_r6_kernel<false, 0, 4> : wgrad_r6_kernel<false, 4, 4>;
+      if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+        return HOLD_E_LAUNCH;
+      hipLaunchKernelGGL(k, dim3((unsigned)G), dim3(256), LDS_BYTES, s, a);
+      return hipGetLastError() == hipSuccess ? (int)G : HOLD_E_LAUNCH;
+    }
+  }
+#endif
   if (part_b)
     hipLaunchKernelGGL((wgrad_r6_kernel<true>), dim3((unsigned)G), dim3(256), LDS_BYTES, s, a);
   else
