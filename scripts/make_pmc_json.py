@@ -23,7 +23,8 @@ groups = {"fused_sdf_kernel": ["rmlp_kernel<true,false,0>", "fused_sdf_x6p_kerne
           "sampler_beta_kernel": ["sampler_beta_kernel"], "sampler_sample_kernel": ["sampler_sample_kernel"],
           "composite_fwd_kernel": ["composite_fwd_kernel"], "composite_bwd_kernel": ["composite_bwd_kernel"],
           "gemm_nt_kernel": ["gemm_nt_kernel"],
-          "wgrad_kernel": ["wgrad_r6_kernel<true>", "wgrad_r6_kernel<false>", "wgrad_r6_kernel", "wgrad_lds_kernel", "wgrad_kernel"]}
+          "wgrad_kernel": ["wgrad_r6_kernel<true,0,3>", "wgrad_r6_kernel<false,0,3>", "wgrad_r6_kernel<true>", "wgrad_r6_kernel<false>",
+                           "wgrad_r6_kernel", "wgrad_r6_group_kernel", "wgrad_lds_kernel", "wgrad_kernel"]}
 notes = {
     "fused_sdf_kernel": "sampler queries: 16 B in (xc row) + 4 B out per point; the 2.8 MiB limb pack stays in L2",
     "chain_kernel": "hold_chain_x6: the first-order backward sweep (DSP + a2: reads 2 + writes 1 KiB per point and layer, 7 layers) and "
