@@ -814,6 +814,24 @@ __global__ void seed_dsp_kernel(const float* __restrict__ h, int ldh, const floa
   t[p * ldt + n] = w[n] * (-expm1f(-100.0f * h[p * ldh + n]));
 }
 
+// the same for rows of N % 4 == 0 floats with 16-byte aligned rows: four consecutive n per thread, 16-byte accesses (one
+// 64-bit division per four elements instead of per element; 1.06 -> ~0.7 ms at 1.6 M x 256, same bits)
+__global__ __launch_bounds__(256) void seed_dsp4_kernel(const float* __restrict__ h, int ldh, const float* __restrict__ w,
+                                                       int N4, long P, float* __restrict__ t, int ldt) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P * N4) return;
+  const long p = i / N4;
+  const int n = (int)(i - p * N4) * 4;
+  const float4 hv = *reinterpret_cast<const float4*>(h + p * ldh + n);
+  const float4 wv = *reinterpret_cast<const float4*>(w + n);
+  float4 o;
+  o.x = wv.x * (-expm1f(-100.0f * hv.x));
+  o.y = wv.y * (-expm1f(-100.0f * hv.y));
+  o.z = wv.z * (-expm1f(-100.0f * hv.z));
+  o.w = wv.w * (-expm1f(-100.0f * hv.w));
+  *reinterpret_cast<float4*>(t + p * ldt + n) = o;
+}
+
 // column sums: out[n] += sum_p X[p][n]   (n < N <= 512); blocks stride over rows
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int ldx, int N, long P,
                                                     long rows_per_block, float* __restrict__ out) {
@@ -849,6 +867,11 @@ extern "C" int hold_seed_dsp(const float* h, int32_t ldh, const float* w, int32_
                              hold_stream_t st) {
   if (!h || !w || !t || N <= 0) return HOLD_E_ARG;
   if (P == 0) return HOLD_OK;
+  if (!(N & 3) && !(ldh & 3) && !(ldt & 3) && !(((uintptr_t)h | (uintptr_t)w | (uintptr_t)t) & 15)) {
+    hipLaunchKernelGGL(seed_dsp4_kernel, dim3(nblk((long)P * (N / 4))), dim3(256), 0, (hipStream_t)st, h, ldh, w, N / 4,
+                       (long)P, t, ldt);
+    return ok();
+  }
   hipLaunchKernelGGL(seed_dsp_kernel, dim3(nblk((long)P * N)), dim3(256), 0, (hipStream_t)st, h, ldh, w, N, (long)P, t,
                      ldt);
   return ok();

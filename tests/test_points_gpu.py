@@ -92,3 +92,25 @@ def test_embed_backward_and_double_backward_match_autograd(barf):
     xbar_b = torch.ones(P, 4, device=dev)
     K.embed_bwd2(x, L, P, ge0, gbar, gebar_b, xbar=xbar_b, barf_w=bw)
     assert torch.equal(gebar_b[:, :E], gebar[:, :E]) and torch.equal(xbar_b, xbar)
+
+
+def test_seed_dsp_vector_and_scalar_paths():
+    """hold_seed_dsp: t = w * softplus'(h) recovered from h = softplus(a) (beta = 100): the 16-byte path (N % 4 == 0, aligned
+    rows) and the element path (a weight vector at a 4-byte-aligned address) give the same bits, both equal fp64 to 1e-6"""
+    from hold_amd import kernels as K
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    P = 10007
+    a = torch.randn(P, 256, device=dev) * 0.05
+    h = torch.nn.functional.softplus(a, beta=100)
+    w_al = torch.randn(256, device=dev)
+    w_un = torch.empty(260, device=dev)[1:257]  # 4-byte aligned only: the element path
+    w_un.copy_(w_al)
+    t1 = torch.full((P, 256), 7.0, device=dev)
+    t2 = torch.full((P, 256), 7.0, device=dev)
+    K.seed_dsp(h, w_al, 256, P, t1)
+    K.seed_dsp(h, w_un, 256, P, t2)
+    torch.cuda.synchronize()
+    assert torch.equal(t1, t2)
+    ref = w_al.double() * torch.sigmoid(100 * a.double())
+    assert float((t1.double() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
