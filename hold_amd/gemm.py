@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -140,6 +141,9 @@ class WgradGroup:
     round 4 call 17), while at the 125 k points of the 1 280-ray step the grouped launch takes 4.5 % off the whole step."""
     MAX = 24
     MAX_P = 1 << 19
+    # above MAX_P: the two pairs of one destination in one launch (128 workgroups each, half the partial tiles) -- measured
+    # neutral at 1.6 M points (185.4 vs 184.5 TF-eq for the family, bench line within the noise; GPU call 24): off
+    PAIRS_ABOVE = os.environ.get("HOLD_WGRAD_PAIRS", "0") == "1"
 
     def __init__(self):
         self.items = []
@@ -152,18 +156,25 @@ class WgradGroup:
         if not items:
             return
         P = items[0][0].shape[0]
-        ok = (config.x6() and P % 16 == 0 and 4096 <= P <= self.MAX_P and len(items) <= self.MAX
+        ok = (config.x6() and P % 16 == 0 and P >= 4096 and len(items) <= self.MAX
               and all(R.shape[0] == P and X.shape[0] == P and _ld(R) >= 256 and _ld(X) >= 256 and _ld(dW) >= 256
                       and 0 < N <= 256 for R, X, dW, db, N, acc in items))
-        if not ok:
-            for R, X, dW, db, N, acc in items:
-                wgrad(R, X, dW, db, N=N, K=256, accumulate=acc)
-            return
         # pairs of one destination next to each other, destinations in order of first appearance
         order = {}
         for it in items:
             order.setdefault(it[2].data_ptr(), len(order))
         items.sort(key=lambda it: order[it[2].data_ptr()])
+        if ok and P <= self.MAX_P:
+            return self._launch(items, P)
+        runs = [[it for it in items if order[it[2].data_ptr()] == d] for d in range(len(order))]
+        for run in runs:
+            if ok and self.PAIRS_ABOVE and len(run) > 1:  # the pairs of ONE destination together: half the partial tiles
+                self._launch(run, P)
+            else:
+                for R, X, dW, db, N, acc in run:
+                    wgrad(R, X, dW, db, N=N, K=256, accumulate=acc)
+
+    def _launch(self, items, P):
         seen = {}
         for R, X, dW, db, N, acc in items:  # a destination accumulates if any of its pairs was asked to
             seen[dW.data_ptr()] = seen.get(dW.data_ptr(), False) or acc
