@@ -163,6 +163,14 @@ __device__ __forceinline__ float knn_d2(float px, float py, float pz, float vx, 
   return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
 }
 
+// two vertices at once on the packed fp32 instructions (v_pk_add / v_pk_mul / v_pk_fma): per element the operations and
+// their order are knn_d2's, so the bits are the same
+typedef float knn_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ knn_f2 knn_d2x2(knn_f2 px, knn_f2 py, knn_f2 pz, knn_f2 vx, knn_f2 vy, knn_f2 vz) {
+  const knn_f2 dx = px - vx, dy = py - vy, dz = pz - vz;
+  return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+}
+
 // insertion into the ascending (distance, index) list, strict '<' in visiting order: of equal distances the vertex
 // visited first (lower index) stays in front -- pytorch3d knn_points' order for the K smallest
 __device__ __forceinline__ void knn_insert(float (&bd)[KNN], int (&bi)[KNN], float dist, int i) {
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(256) void knn_invlbs_kernel(const float* __restrict
                                                         const float* __restrict__ skin, const float* __restrict__ tfs,
                                                         float* __restrict__ w_out, float* __restrict__ xc_out,
                                                         int ldxc) {
-  __shared__ float sv[3][MAXV];
+  __shared__ __attribute__((aligned(16))) float sv[3][MAXV];
   __shared__ uint32_t smask[KNN_WORDS][256];
   __shared__ float st[NB * 16];
   const long blocks_per_frame = (ppf + 255) / 256;
@@ -228,17 +236,21 @@ __global__ __launch_bounds__(256) void knn_invlbs_kernel(const float* __restrict
     }
   }
   const float tau = bd[KNN - 1];  // nv >= 4 * KNN is checked by the host entry: 15 subset vertices exist
-  // ---- pass 2: filter ----
+  // ---- pass 2: filter (two vertices per step: the vertex arrays are 8-byte aligned and padded to MAXV, an odd nv reads one
+  // unused entry whose bit is masked) ----
   const int nwords = (nv + 31) >> 5;
+  const knn_f2 px2 = {px, px}, py2 = {py, py}, pz2 = {pz, pz};
   for (int w = 0; w < nwords; ++w) {
     uint32_t m = 0;
     const int i0 = w * 32;
 #pragma unroll 8
-    for (int b = 0; b < 32; ++b) {
+    for (int b = 0; b < 32; b += 2) {
       const int i = i0 + b;
       if (i < nv) {
-        const float d = knn_d2(px, py, pz, sv[0][i], sv[1][i], sv[2][i]);
-        m |= (d <= tau) ? (1u << b) : 0u;
+        const knn_f2 d = knn_d2x2(px2, py2, pz2, *reinterpret_cast<const knn_f2*>(&sv[0][i]),
+                                  *reinterpret_cast<const knn_f2*>(&sv[1][i]), *reinterpret_cast<const knn_f2*>(&sv[2][i]));
+        m |= (d[0] <= tau) ? (1u << b) : 0u;
+        m |= (d[1] <= tau && i + 1 < nv) ? (2u << b) : 0u;
       }
     }
     smask[w][threadIdx.x] = m;
