@@ -189,7 +189,7 @@ __device__ __forceinline__ void knn_insert(float (&bd)[KNN], int (&bi)[KNN], flo
 }
 
 // K = 15 nearest vertices per point, three passes (one thread per point, the frame's vertices in LDS):
-//   1. threshold: the 15 smallest distances to every 4th vertex, kept by a branch-free min/max chain (no indices).  The
+//   1. threshold: the 15 smallest distances to every 4th vertex, kept sorted by one median-of-three per slot (no indices).  The
 //      15th of them, tau, is an upper bound of the 15th smallest distance to ALL vertices.
 //   2. filter: one bit per vertex, d <= tau (~8 % of the vertices pass), 32 vertices per mask word in LDS.
 //   3. selection: the insertion sort with indices over the set bits only, in index order -- the same result as
@@ -226,14 +226,16 @@ __global__ __launch_bounds__(256) void knn_invlbs_kernel(const float* __restrict
   // ---- pass 1: tau ----
 #pragma unroll
   for (int k = 0; k < KNN; ++k) bd[k] = 3.0e38f;
+  // sorted insertion without a dependent chain: with bd ascending, the new k-th smallest is the MEDIAN of the old
+  // (k-1)-th, the old k-th and d (v_med3_f32: one operation per slot, all from the old values, instead of a min / max pair)
   for (int i = 0; i < nv; i += KNN_SUB) {
-    float d = knn_d2(px, py, pz, sv[0][i], sv[1][i], sv[2][i]);
+    const float d = knn_d2(px, py, pz, sv[0][i], sv[1][i], sv[2][i]);
+    float nb[KNN];
+    nb[0] = fminf(bd[0], d);
 #pragma unroll
-    for (int k = 0; k < KNN; ++k) {
-      const float lo = fminf(bd[k], d);
-      d = fmaxf(bd[k], d);
-      bd[k] = lo;
-    }
+    for (int k = 1; k < KNN; ++k) nb[k] = __builtin_amdgcn_fmed3f(bd[k - 1], bd[k], d);
+#pragma unroll
+    for (int k = 0; k < KNN; ++k) bd[k] = nb[k];
   }
   const float tau = bd[KNN - 1];  // nv >= 4 * KNN is checked by the host entry: 15 subset vertices exist
   // ---- pass 2: filter (two vertices per step: the vertex arrays are 8-byte aligned and padded to MAXV, an odd nv reads one
