@@ -500,13 +500,16 @@ def main():
             if args.shape_report:
                 json.dump(gemm_shapes(prof), open(args.shape_report, "w"), indent=1)
             split = {"fused_sdf_kernel", "wgrad_kernel", "chain_kernel", "gemm_nt_kernel", "trunk_r6_kernel", "rchain_kernel",
-                     "rchain_bg_kernel", "rchain_a2_kernel", "rchain_dbwd_kernel", "rgemm_kernel"} if x6 else set()
+                     "rchain_bg_kernel", "rchain_a2_kernel", "rchain_dbwd_kernel", "rgemm_kernel", "rnarrow_kernel"} if x6 else set()
             labels = {"gemm_nt_kernel": ("gemm_nt_kernel<x6> (one layer per launch, 3-limb split on v_mfma_f32_32x32x16_bf16)"
                                          if x6 else "gemm_nt_kernel (one layer per launch, v_mfma_f32_32x32x2_f32)"),
                       "trunk_r6_kernel": "rmlp_kernel<STORE> (forward trunk, 8 layers per launch, register-resident, 3-limb split on "
                                          "v_mfma_f32_32x32x16_bf16)",
                       "rgemm_kernel": "rgemm_kernel (rendering-net layers, their input gradients, lin8 features: one 256-wide layer "
                                       "per launch, register-resident, 3-limb split on v_mfma_f32_32x32x16_bf16)",
+                      "rnarrow_kernel": "rnarrow_kernel (the N <= 64 layers: d sdf / d embedding, the non-feature columns of the colour "
+                                        "net's input gradient; A streamed once, ceil(N / 32) output tiles, 3-limb split on "
+                                        "v_mfma_f32_32x32x16_bf16)",
                       "rchain_kernel": "rsweep_kernel<DSP> (descending sweep of the normal path, 7 layers per launch, register-resident, "
                                        "side I/O as whole 128-byte lines through LDS, 3-limb split on v_mfma_f32_32x32x16_bf16)",
                       "rchain_bg_kernel": "rsweep_kernel<DSP, skip 172> (the background net's first-order backward sweep, 7 layers per "

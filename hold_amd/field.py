@@ -429,7 +429,7 @@ class NodeField:
                     G.gemm_nt(t[3], WT[3], t[2], epi=G.EPI_MUL_DSP, aux1=h[2], K=sp.skip_pad)
                 else:
                     G.gemm_nt(t[l], WT[l], t[l - 1], epi=G.EPI_MUL_DSP, aux1=h[l - 1])
-        G.gemm_nt(t[0], WT[0], ge, N=ge.shape[1], accumulate=True)
+        G.gemm_narrow(t[0], WT[0], ge, N=ge.shape[1], accumulate=True)
 
     def _ge_buffer(self, t, P):
         """d sdf / d embedding [P, E]: with the layer chains it stays where the descending sweep leaves its skip part --
@@ -627,7 +627,7 @@ class NodeField:
         G.wgrad(cur, sv["in0"], dW[0], dWb[0], K=sp.K0, accumulate=True)
         if grp is not None:
             grp.flush()
-        G.gemm_nt(cur, WT[0], ebar, N=ebar.shape[1], accumulate=True)
+        G.gemm_narrow(cur, WT[0], ebar, N=ebar.shape[1], accumulate=True)
         xbar = pool.get("xbar", P, 4)
         K.embed_bwd(xc, sp.L, P, ebar, xbar, barf_w=sv["barf_w"])
         d0 = torch.zeros(256, pk["iw0_cols"], device=dev)
@@ -726,7 +726,7 @@ class NodeField:
         d_rin = pool.get("d_rin", P, sp.Kr)
         if USE_R6_GEMM and "RT_r6" in pk:  # the 256 feature columns register-resident, the 16 / 48 others a narrow GEMM
             G.gemm_r6(cur, pk["RT_r6"][0], d_rin[:, :FEAT], K=256)
-            G.gemm_nt(cur, RT[0][FEAT:], d_rin[:, FEAT:], N=sp.Kr - FEAT)
+            G.gemm_narrow(cur, RT[0][FEAT:], d_rin[:, FEAT:], N=sp.Kr - FEAT)
         else:
             G.gemm_nt(cur, RT[0], d_rin, N=sp.Kr)
         B = n_frames
@@ -767,7 +767,7 @@ class NodeField:
                   r1_col=pk["w8_sdf"])
         cur, ebar = self._first_order_sweep(pk, h, a2, r7, sv["in0"], dW, dWb, True, P, grp)
         G.wgrad(cur, sv["in0"], dW[0], dWb[0], K=sp.K0, accumulate=True)
-        G.gemm_nt(cur, WT[0], ebar, N=ebar.shape[1], accumulate=True)
+        G.gemm_narrow(cur, WT[0], ebar, N=ebar.shape[1], accumulate=True)
         K.embed_bwd(xc, sp.L, P, ebar, xbar, barf_w=sv["barf_w"], accumulate=True)
         if grp is not None:
             grp.flush()

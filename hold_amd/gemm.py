@@ -130,6 +130,25 @@ def wgrad(R, X, dW, db=None, *, N=None, K=None, accumulate=False, splits=None):
     return dW
 
 
+USE_NARROW = os.environ.get("HOLD_NARROW", "1") != "0"
+
+
+def gemm_narrow(A, W, C, *, N=None, accumulate=False):
+    """C[:, :N] (+)= A[:, :256] @ W[:N, :256].T for N <= 64 (hold_gemm_narrow_x6, csrc/rnarrow.hip): A streamed once, only
+    ceil(N / 32) output tiles of MFMAs.  Falls back to hold_gemm_nt (same contract) outside its domain: not split precision,
+    fewer than 4 096 points, operands it cannot address."""
+    P = A.shape[0]
+    N = C.shape[1] if N is None else N
+    if not (USE_NARROW and config.x6() and P >= 4096 and 0 < N <= 64 and A.shape[1] >= 256 and W.shape[1] >= 256
+            and _ld(A) % 4 == 0 and _ld(W) % 4 == 0 and A.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0):
+        return gemm_nt(A, W, C, N=N, K=256, accumulate=accumulate)
+    e0 = _prof_begin()
+    check(_lib.lib().hold_gemm_narrow_x6(ptr(A), _ld(A), ptr(W), _ld(W), ptr(C), _ld(C), P, N, 1 if accumulate else 0,
+                                         stream_ptr()), "hold_gemm_narrow_x6")
+    _prof_end(e0, 2.0 * P * N * 256, "rnarrow_kernel", 4.0 * P * (256 + N * (2 if accumulate else 1)))
+    return C
+
+
 class WgradGroup:
     """Weight gradients over the same P points collected and issued as ONE launch (hold_wgrad_group_x6): a compute unit
     works on one (pair, share of the points), so the launch writes one partial tile per compute unit for all pairs

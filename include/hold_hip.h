@@ -91,6 +91,15 @@ int hold_wgrad_x6(const float* R, int32_t ldr, const float* X, int32_t ldx, int3
                   float* dW, int32_t lddw, float* db, int32_t accumulate, int32_t splits, float* workspace,
                   hold_stream_t stream);
 
+/* Narrow layer, split-precision arithmetic of hold_gemm_nt_x6:  C[p][n] (+)= sum_k A[p][k] W[n][k],  K = 256, N <= 64
+ * (hold_amd/csrc/rnarrow.hip).  For the GEMMs of the path whose output is a few dozen columns wide -- d sdf / d embedding
+ * (N = 39: torch autograd's `grad_output @ lin0.weight`, reference code/src/networks/shape_net.py:108-116) and the
+ * non-feature columns of the colour net's input gradient (N = 16 / 48, code/src/networks/texture_net.py:89-101): A is
+ * streamed once, only ceil(N / 32) output tiles are computed.  A and W 16-byte aligned with leading dimensions that are
+ * multiples of 4 and >= 256; C any 4-byte aligned view with ldc >= N. */
+int hold_gemm_narrow_x6(const float* A, int32_t lda, const float* W, int32_t ldw, float* C, int32_t ldc, int64_t P,
+                        int32_t N, int32_t accumulate, hold_stream_t stream);
+
 /* Several weight gradients over the SAME P points in one launch (the 15 of a node's implicit-net backward -- torch
  * autograd's per-Linear `grad_output.T @ input`, reference code/src/networks/shape_net.py:84-130 -- plus the colour
  * net's): item i contributes  R_i[:, :N]^T X_i[:, :256]  (and the column sums of R_i[:, :N] when db is given) to its

@@ -235,6 +235,64 @@ def test_wgrad_group_matches_fp64_and_single_launches(P):
     assert ((again[1].double() - refb[0]).abs().max() / refb[0].abs().max()).item() < 1e-5
 
 
+@pytest.mark.parametrize("P,N,where,acc", [(4096 + 17, 39, "t3", True), (8192, 39, "t3", False), (5000, 40, "own", True),
+                                          (4099, 16, "rin", False), (131072 + 5, 48, "rin", False), (4128, 64, "own", True),
+                                          (4096, 1, "own", False), (70001, 33, "own", True)])
+def test_narrow_gemm_matches_fp64_and_the_tile_kernel(P, N, where, acc):
+    """hold_gemm_narrow_x6 (csrc/rnarrow.hip): C[:, :N] (+)= A[:, :256] W[:N, :256]^T for the shapes of the path -- N = 39 into
+    the 4-byte-aligned columns 217.. of a 256-wide buffer (d sdf / d embedding in place in t_3), N = 16 / 48 into the columns
+    256.. of the colour net's input gradient, N = 40 into a buffer of its own, the edge widths 1 / 33 / 64 -- with a partial last
+    32-point tile, accumulate on and off, sentinels around the destination and W rows beyond N poisoned; against fp64 and
+    against hold_gemm_nt_x6"""
+    import hold_amd
+    from hold_amd import gemm
+    if hold_amd.precision() != "f32x6":
+        pytest.skip("split-precision path")
+    dev = _dev()
+    torch.manual_seed(P + N)
+    A = torch.randn(P, 260, device=dev)[:, :256] if N % 2 else torch.randn(P, 256, device=dev)
+    Wb = torch.randn(72, 256, device=dev) / 16
+    Wb[N:] = float("nan")
+    W = Wb[:N]
+    if where == "t3":
+        host = torch.full((P + 1, 256), 7.0, device=dev)
+        C = host[:P, 217:217 + N]
+    elif where == "rin":
+        host = torch.full((P + 1, 256 + N + 4), 7.0, device=dev)
+        C = host[:P, 256:256 + N]
+    else:
+        host = torch.full((P + 1, N + 3), 7.0, device=dev)
+        C = host[:P, :N]
+    C.copy_(torch.randn(P, N, device=dev))
+    C0 = C.clone()
+    ref = A.double() @ W.double().t() + (C0.double() if acc else 0)
+    C_nt = C0.clone()
+    gemm.gemm_nt(A, W, C_nt, N=N, K=256, accumulate=acc)
+    gemm.gemm_narrow(A, W, C, N=N, accumulate=acc)
+    torch.cuda.synchronize()
+    sc = float(ref.abs().max())
+    assert torch.isfinite(C).all()
+    assert float((C.double() - ref).abs().max()) < 2e-6 * sc, float((C.double() - ref).abs().max()) / sc
+    assert float((C - C_nt).abs().max()) < 2e-6 * sc
+    # nothing outside the N columns of the P rows was touched
+    keep = torch.ones_like(host, dtype=torch.bool)
+    c0 = 217 if where == "t3" else (256 if where == "rin" else 0)
+    keep[:P, c0:c0 + N] = False
+    assert torch.all(host[keep] == 7.0)
+
+
+def test_narrow_gemm_rejects_what_it_cannot_take():
+    import ctypes as C
+    from hold_amd import _lib
+    L = _lib.lib()
+    p = C.c_void_p(256)
+    assert L.hold_gemm_narrow_x6(p, 256, p, 256, p, 64, 4096, 65, 0, None) != 0   # wider than 64
+    assert L.hold_gemm_narrow_x6(p, 128, p, 256, p, 64, 4096, 39, 0, None) != 0   # A narrower than K = 256 in memory
+    assert L.hold_gemm_narrow_x6(p, 256, p, 256, p, 16, 4096, 39, 0, None) != 0   # ldc < N
+    assert L.hold_gemm_narrow_x6(C.c_void_p(260), 256, p, 256, p, 64, 4096, 39, 0, None) != 0   # misaligned A
+    assert L.hold_gemm_narrow_x6(p, 256, p, 256, p, 64, 0, 39, 0, None) == 0     # nothing to do
+
+
 def test_wgrad_group_rejects_what_it_cannot_take():
     """the C entry point's argument checks (no GPU work is launched for a rejected list)"""
     import ctypes as C
