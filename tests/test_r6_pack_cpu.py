@@ -157,3 +157,62 @@ def test_wgrad_r6_lds_image_and_fragment_addresses():
                     assert lds[addr // 4] == rows[8 * hh + e, 128 * wn + 32 * f + li], (wn, f, e, lane)
                     banks.add((addr // 4) % 64)
                 assert len(banks) == 64, (wn, f, e)
+
+
+def test_rnarrow_lds_images_fragment_addresses_and_result_layout():
+    """csrc/rnarrow.hip restated on the CPU for one 32-point tile and N = 39 outputs (two output tiles): the LDS-DMA placement of
+    a K quarter's raw rows (piece i, lane l -> row 4 i + l / 16, physical chunk l % 16 receives the logical chunk
+    (l % 16) ^ (row % 16)), the A-fragment reads (row li, logical chunks 4 ks + 2 hh, + 1 at physical chunk ^ (li % 16); the 16
+    rows of a read phase on 16 distinct bank groups), the planes of W ([limb][n-tile][k-step][lane]: output 32 nt + l % 32,
+    k = 16 ks + 8 (l / 32) ..), the MFMA operand roles (A = points, B = outputs) and the epilogue's element addresses must
+    reproduce C = A W^T."""
+    rng = np.random.default_rng(5)
+    N, NT = 39, 2
+    A = rng.standard_normal((32, 256))
+    W = rng.standard_normal((N, 256))
+    # W planes (limbs not modelled: one exact plane)
+    wl = np.zeros((NT, 16, 64, 8))
+    for u in range(NT * 16 * 64):
+        l, ks, nt = u & 63, (u >> 6) & 15, u >> 10
+        n, k0 = 32 * nt + (l & 31), 16 * ks + 8 * (l >> 5)
+        if n < N:
+            wl[nt, ks, l] = W[n, k0:k0 + 8]
+    acc = np.zeros((NT, 16, 64))
+    for q in range(4):
+        stage = np.full(32 * 64, np.nan)  # [32 rows][64 floats], in floats
+        for i in range(8):
+            for l in range(64):
+                row, pch = 4 * i + (l >> 4), l & 15
+                src = 64 * q + 4 * (pch ^ (row & 15))
+                dst = (i * 1024 + l * 16) // 4
+                assert dst == row * 64 + pch * 4
+                stage[dst:dst + 4] = A[row, src:src + 4]
+        assert not np.isnan(stage).any()
+        for ks in range(4):
+            A_lane = np.zeros((64, 8))
+            for phase in range(4):  # ds_read_b128: 16 lanes per phase
+                groups = set()
+                for l in range(16 * phase, 16 * phase + 16):
+                    hh, li = l >> 5, l & 31
+                    byte = li * 256 + (((4 * ks + 2 * hh) ^ (li & 15)) << 4)
+                    groups.add((byte // 16) % 16)
+                assert len(groups) == 16, (q, ks, phase)
+            for l in range(64):
+                hh, li = l >> 5, l & 31
+                for c in range(2):
+                    byte = li * 256 + (((4 * ks + 2 * hh + c) ^ (li & 15)) << 4)
+                    A_lane[l, 4 * c:4 * c + 4] = stage[byte // 4:byte // 4 + 4]
+                assert np.array_equal(A_lane[l], A[li, 64 * q + 16 * ks + 8 * hh:64 * q + 16 * ks + 8 * hh + 8])
+            for nt in range(NT):
+                mfma_32x32x16(A_lane, wl[nt, 4 * q + ks], acc[nt])
+    ref = A @ W.T
+    for nt in range(NT):
+        for l in range(64):
+            hh, li = l >> 5, l & 31
+            col = 32 * nt + li
+            for r in range(16):
+                p = 4 * hh + 8 * (r >> 2) + (r & 3)  # the epilogue's o[(8 (r >> 2) + (r & 3)) ldc] from row p0 + 4 hh
+                if col < N:
+                    assert abs(acc[nt, r, l] - ref[p, col]) < 1e-10, (nt, l, r)
+                else:
+                    assert acc[nt, r, l] == 0.0
