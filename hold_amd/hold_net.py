@@ -859,7 +859,10 @@ class Background(nn.Module):
             G.gemm_nt(h[l - 1], W[l], h[l], bias=b[l], epi=G.EPI_SOFTPLUS)
         rin = pool.get("rin", P, self.Kr)
         sdf = pool.get("sdf", P, 1)
-        G.gemm_nt(h[7], W[8], rin[:, 59:59 + FEAT], bias=b[8], N=257, n_split=256, out_raw=sdf)
+        # lin8 = 256 feature rows as one full-tile GEMM + the sdf row as a row dot (as the foreground nets do: N = 257 costs a
+        # second 256-wide column tile for the one extra output)
+        G.gemm_nt(h[7], W[8], rin[:, 59:59 + FEAT], bias=b[8], N=256)
+        K.rowdot(h[7], iw[8][0].contiguous(), 256, ib[8][:1].contiguous(), P, sdf)
         dirs = pool.get("dirs", P, 4)
         K.frame_bcast(ray_dirs, P, S, dirs, 0)
         K.embed_fwd(dirs, 3, 4, P, rin, cond=latent, pts_per_frame=ppf)
