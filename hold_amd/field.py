@@ -11,7 +11,10 @@ Buffers (fp32, ray-major points p = ray*S + s):
   in0    [P,K0]  embedding (+cond)                        h[l] [P,256] softplus outputs (h[3] = [h3|embed])
   rin    [P,Kr]  render-net input [feat256,xc,n,pose8(,time32)] -- the reference's column order with the feature block
                  moved to the front (16-byte aligned for lin8's output / its cotangent); pack_weights permutes lin0
-  t[l]   [P,256] reverse-sweep d sdf/d a_l               ge   [P,K0]  d sdf/d embed       g [P,4] d sdf/d xc
+  t[l]   [P,256] reverse-sweep d sdf/d a_l               g    [P,4]   d sdf/d xc
+  ge     [P,E]   d sdf/d embed: with the layer chains the view t[3][:, 217:] (row stride 256; the descending sweep leaves
+                 the skip part there, layer 0's part is accumulated in place, hold_embed_bwd2 overwrites it in place with the
+                 side columns of the ascending sweep); a [P,K0] buffer on the layer-by-layer route
 """
 from __future__ import annotations
 
