@@ -1,0 +1,61 @@
+"""The bench line's contract, checked on the committed output of the default command (profiles/r04_bench_final.json is what
+`python bench.py` printed on an MI355X, scripts/lease_logs/r4_call32.sh) and on bench.py's command line -- no GPU needed."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line():
+    return json.load(open(os.path.join(ROOT, "profiles", "r04_bench_final.json")))
+
+
+def test_bench_line_carries_every_contract_field():
+    d = _line()
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    # the metric is BASELINE.json's (typography aside: the driver compares the words)
+    norm = lambda s: s.replace("×", "x").split(";")[0].strip()
+    assert norm(d["metric"]) == norm(base["metric"])
+    for k, t in (("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                 ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
+        assert isinstance(d[k], t), (k, type(d[k]))
+    assert d["unit"] == "rays/s" and d["higher_is_better"] is True and d["scaling"] in ("weak", "strong")
+    assert d["data"] == "synthetic" and d["n_gpus"] == 1 and "vs_baseline" in d and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    # value = whole-job rays / the timed region: one 512 x 512 frame per step
+    assert abs(d["value"] - 512 * 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_line_roofline_and_cpu_baseline_objects():
+    d = _line()
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["peak"] in (8000.0, 2500.0)  # HBM GB/s, dense bf16 MFMA TFLOP/s (MI355X_MICROARCH.md)
+    assert 0.0 < r["frac"] < 1.0 and r["traffic"] and r["traffic"] > 0.5 * r["algorithmic_bytes_per_launch_avg"]
+    # both floors for every MFMA family, and the families account for the time they claim
+    fam = {k: v for k, v in r["kernels"].items() if "mfma_frac" in v}
+    assert len(fam) >= 8
+    for k, v in fam.items():
+        assert v["bound"] == ("hbm" if v["floor_ms"]["hbm"] > v["floor_ms"]["mfma"] else "mfma"), k
+        assert v["floor_ms"][v["bound"]] <= v["avg_launch_ms"] * 1.001, k  # no family beats its own roofline
+    share = sum(v["time_share"] for v in fam.values())
+    assert abs(share - r["end_to_end"]["time_in_mfma_kernels"]) < 1e-6 and 0.5 < share < 1.0
+    c = d["cpu_baseline"]
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] in ("port", "reference")
+    assert c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
+
+
+def test_bench_command_line_defaults():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr[-500:]
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in out.stdout
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    # with no flags: one GPU (the driver's N = 1 run), and nothing under oracle/ outside the cpu_baseline leg
+    assert '"--gpus", type=int, default=1' in src
