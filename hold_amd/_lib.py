@@ -171,6 +171,8 @@ SIGNATURES = {
     "hold_fused_sdf_x6": [_P, _I, _L, _P, _P, _P, _F, _P, _P, _I, _P],
     "hold_fused_sdf_r6": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _I, _P],
     "hold_trunk_r6": [_P, _I, _L, _P, _P, _P, C.POINTER(C.c_void_p), _I, _P],
+    "hold_fused_sdf_h3": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "hold_trunk_h3": [_P, _I, _L, _P, _P, _P, _P, C.POINTER(C.c_void_p), _I, _P],
     "hold_mano_lbs_fwd": [C.POINTER(ManoModel), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "hold_mano_lbs_bwd": [C.POINTER(ManoModel), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
 }
@@ -186,6 +188,8 @@ def _declare(L):
     L.hold_fused_sdf_pack_floats.restype = C.c_int64
     L.hold_fused_sdf_x6_pack_bytes.restype = C.c_int64
     L.hold_trunk_r6_pack_bytes.restype = C.c_int64
+    L.hold_trunk_h3_pack_bytes.restype = C.c_int64
+    L.hold_trunk_h3_act_scale.restype = C.c_float
     L.hold_gemm_r6_pack_bytes.restype = C.c_int64
     L.hold_gemm_r6_pack_bytes.argtypes = [C.c_int32]
     L.hold_chain_r6_pack_bytes.restype = C.c_int64
@@ -239,7 +243,7 @@ def stream_ptr():
 def ptr(t):
     if t is None:
         return None
-    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.int64, torch.uint8, torch.int8, torch.bool, torch.bfloat16), (t.device, t.dtype)
+    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.int64, torch.uint8, torch.int8, torch.bool, torch.bfloat16, torch.float16), (t.device, t.dtype)
     return C.c_void_p(t.data_ptr())
 
 

@@ -8,6 +8,13 @@
            measured 1.4e-6 max abs against the fp32 MFMA kernel on 524 288 points; the whole parity suite runs green
            in both modes at the same tolerances).
 
+``f16x3``  as ``f32x6``, except that the kernels that exist in the two-limb fp16 arithmetic use it: every fp32 operand, scaled
+           by an exact power of two, is split into hi = RN_f16(x), lo = RN_f16(x - hi) and THREE of the four limb products
+           (hi hi + hi lo + lo hi) are issued on v_mfma_f32_32x32x16_f16 with fp32 accumulation -- half the matrix
+           instructions of ``f32x6`` at the same measured error against fp64 (csrc/rmlp_h3.hip: the sampler's SDF query
+           hold_fused_sdf_h3 and the training forward trunk hold_trunk_h3).  Every other MFMA kernel
+           runs its ``f32x6`` variant in this mode.
+
 Set once per process with ``hold_amd.set_precision(...)`` (or HOLD_PRECISION in the environment of the Python host);
 the C ABI itself is stateless -- the mode only decides WHICH entry point the host calls.
 """
@@ -15,7 +22,7 @@ from __future__ import annotations
 
 import os
 
-_MODES = ("f32", "f32x6")
+_MODES = ("f32", "f32x6", "f16x3")
 _precision = os.environ.get("HOLD_PRECISION", "f32x6")
 if _precision not in _MODES:
     raise ValueError(f"HOLD_PRECISION must be one of {_MODES}, got {_precision!r}")
@@ -33,7 +40,13 @@ def precision() -> str:
 
 
 def x6() -> bool:
-    return _precision == "f32x6"
+    """the limb-split kernel families (bf16 three-limb; in mode f16x3 the kernels without an fp16 variant still run these)"""
+    return _precision in ("f32x6", "f16x3")
+
+
+def h3() -> bool:
+    """two-limb fp16 variants where they exist (csrc/rmlp_h3.hip)"""
+    return _precision == "f16x3"
 
 
 # ---- weight-pack invalidation -------------------------------------------------------------------------------------

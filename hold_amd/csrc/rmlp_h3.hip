@@ -1,0 +1,527 @@
+// Register-resident trunk of the ImplicitNet in the TWO-LIMB fp16 arithmetic "f16x3" (gfx950): lin0..lin7 of
+// ImplicitNet.forward (code/src/networks/shape_net.py:84-130), the structure of csrc/rmlp.hip -- one wave per SIMD owns
+// 32 points for the whole network, a layer's accumulator registers become the next layer's MFMA B operand after softplus +
+// limb split in registers, the weight limbs are the only stream (LDS-DMA ring shared by the four waves) -- with HALF the
+// matrix instructions per product:
+//
+//   x = hi + lo,  hi = RN_f16(s x),  lo = RN_f16(s x - hi)      (s = an exact power of two per operand)
+//   w x ~ hi_w hi_x + hi_w lo_x + lo_w hi_x                      3 x v_mfma_f32_32x32x16_f16, fp32 accumulation
+//
+// against the six bf16 limb products of rmlp.hip.  The representation keeps 22-23 significand bits wherever the scaled value
+// is >= 2^-2 (hi: 11 bits, lo: a signed 11-bit correction of at most half an ulp of hi) and an ABSOLUTE 2^-25 / s below
+// (lo becomes an fp16 subnormal: the matrix core takes fp16 subnormals unflushed -- scripts/probes/h3_probe.hip checks
+// exactly that on the hardware); the dropped lo_w lo_x term is <= 2^-22 of the product, signed at random (round to nearest),
+// where the truncation split of the bf16 scheme drops same-signed terms <= 2^-23.  Measured against fp64 the two schemes
+// are indistinguishable (scripts/split_precision_study.py; tests/test_rmlp_gpu.py holds this kernel to <= 1.5 x the error of
+// hold_fused_sdf_r6 on 524 288 points).  Scales: weights by s_w[l] = 2^k with max |W_l| s_w in [2^13, 2^14) (host, per matrix,
+// at pack time -- hold_amd/field.py:pack_h3); activations by the constant SA = 2^6 (softplus outputs and the embedding:
+// full precision from 2^-8 up, absolute 4.7e-10 below; an activation >= 1023 would overflow fp16 -- to +inf, i.e. loudly).
+// The accumulators hold s_w SA a_l; the epilogue multiplies by c3[l] = 1 / s_w[l] (exact) and carries SA through softplus.
+//
+// Per k step: 16 KiB of weight limbs (8 n-tiles x 2 limbs x 1 KiB fragments, 24 KiB in rmlp.hip), 24 MFMAs (48), and a
+// limb split of 4 instructions per two values (v_cvt_pk_f16_f32, 2 x v_fma_mix_f32, v_cvt_pk_f16_f32; 11 in rmlp.hip).
+//
+// Entry points: hold_fused_sdf_h3 (sampler query) and hold_trunk_h3 (training forward: stores h_0..h_7 in fp32, unscaled).
+// Roofline: f16 MFMA pipe (3 limb products issued per algorithmic product); HBM bytes as rmlp.hip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "../../include/hold_hip.h"
+#include "rmlp_h3_sched.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int NW = 4;                 // waves per workgroup (one per SIMD)
+constexpr int BPTS = 32 * NW;         // points per workgroup pass
+constexpr int PIECE = 1024;           // one MFMA A fragment for a wave: 64 lanes x 16 B
+constexpr int NPC = 16;               // pieces per k step: [8 n-tiles][2 limbs]
+constexpr int SLOT = NPC * PIECE;
+constexpr int RING = 5;               // LDS slots; NSTEP % RING == 0 keeps slot = step % RING across blocks
+constexpr int L0S = 3, LKS = 16;      // k steps of layer 0 (K = 48, 39 used) and of the 256-wide layers
+constexpr int NSTEP = L0S + 7 * LKS;  // 115 k steps per block of points
+constexpr int NE = 39, EMB_STR = 52, SKIP_OUT = 217;
+constexpr int NGAP = 24;              // MFMAs per k step
+constexpr int OFF_BIAS = RING * SLOT;               // [8][256] fp32, pre-scaled by s_w[l] SA on the host
+constexpr int OFF_W8 = OFF_BIAS + 8 * 256 * 4;      // [256] fp32
+constexpr int OFF_EMB = OFF_W8 + 256 * 4;           // [4 waves][32 points][EMB_STR] fp32 (wave-private), scaled by SA
+constexpr int OFF_BARF = OFF_EMB + NW * 32 * EMB_STR * 4;  // [64] fp32: SA x BARF weights of the 39 embedding columns
+constexpr int LDS_BYTES = OFF_BARF + 64 * 4;
+static_assert(NSTEP % RING == 0, "slot index must not depend on the block iteration");
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+
+constexpr float SA = 64.0f;                            // activation scale (a power of two)
+constexpr float KE = -144.26950408889634f / SA;        // exp2 argument per unit of the SCALED pre-activation
+constexpr float CL = 0.0069314718056f * SA;            // ln2 / 100, scaled
+
+struct H3Args {
+  const float* xc; int ldx; long P;
+  const char* wpack;    // hold_trunk_h3_pack_bytes() bytes, [NSTEP][16 pieces][64 lanes][8 f16]
+  const float* bias;    // [8][256], bias_l s_w[l] SA
+  const float* c3;      // [8] 1 / s_w[l]
+  const float* w8;      // [256] sdf row of lin8 (HEAD)
+  const float* b8;      // device scalar: bias of the sdf row (HEAD)
+  const float* barf;    // [39] or null
+  float* sdf; int lds;  // HEAD output
+  float* h[8]; int ldh; // STORE outputs ([P][ldh], columns 0..255)
+};
+
+__device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ float bitsf(uint32_t x) { return __builtin_bit_cast(float, x); }
+
+// max(y, 0) as ONE v_max_i32 (fmaxf costs a canonicalising v_max y,y first)
+__device__ __forceinline__ float relu1(float y) {  // sign bit set <=> negative as an integer
+  const int b = __builtin_bit_cast(int, y);
+  return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
+// value-only softplus of an UNSCALED pre-activation (the last layer of the sampler query)
+__device__ __forceinline__ float sp_fast(float y) {
+  const float e = __builtin_amdgcn_exp2f(-144.26950408889634f * fabsf(y));
+  return fmaf(0.0069314718056f, __builtin_amdgcn_logf(1.0f + e), relu1(y));
+}
+// training softplus (see rmlp.hip): log1p by series where 1 + e would round e away; y > 0.2 returns y
+__device__ __forceinline__ float sp_train(float y) {
+  const float e = __builtin_amdgcn_exp2f(-144.26950408889634f * fabsf(y));
+  const float lg = 0.0069314718056f * __builtin_amdgcn_logf(1.0f + e);
+  const float ser = (0.01f * e) * fmaf(e, fmaf(e, 0.33333334f, -0.5f), 1.0f);
+  const float l = (e > 1e-3f) ? lg : ser;
+  const float r = relu1(y) + l;
+  return (y > 0.2f) ? y : r;
+}
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const float* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, p ? bytes : 0u, 0x00020000);
+}
+
+// 16-byte row-fragment store, column offset in the immediate + s_nop 3 (the gfx950 store-data hazard of rmlp.hip)
+__device__ __forceinline__ void store4(const f32x4& v, rsrc_t rs, uint32_t voff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, voff, 0, 0);
+  asm volatile("s_nop 3");
+}
+
+struct Limbs { u32x4 l[2]; };  // two f16x8 B fragments (hi, lo), as dwords (dword d = elements 2 d, 2 d + 1)
+
+// round-to-nearest pack of two fp32 values into one dword of f16 (v_cvt_pk_f16_f32)
+__device__ __forceinline__ uint32_t cvt_pk(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+// x - (float) half `sel` of the packed f16 dword hi: ONE v_fma_mix_f32 (exact: hi has 11 significant bits inside x's 24)
+template <int SEL>
+__device__ __forceinline__ float resid(uint32_t hi, float x) {
+  float r;
+#ifdef HOLD_H3_SPLIT_PLAIN
+  const f16x2 h = __builtin_bit_cast(f16x2, hi);
+  r = x - (float)h[SEL];
+#else
+  if (SEL == 0)
+    asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi), "v"(x));
+  else
+    asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi), "v"(x));
+#endif
+  return r;
+}
+
+// LDS-DMA of wave `wave`'s four 1 KiB pieces of k step `step` into ring slot `slot` (inline assembly: see rmlp.hip --
+// hipcc models the builtin as a FLAT access and would wait lgkmcnt(0) at every later ds_read; completion counted by hand)
+__device__ __forceinline__ void dma_step(const char* wpack, uint32_t lane16, int step, int slot, int wave) {
+  const char* src = wpack + (long)step * SLOT + wave * (4 * PIECE);  // wave-uniform
+  const uint32_t dst = (uint32_t)(slot * SLOT + wave * (4 * PIECE));  // dynamic LDS starts at byte 0 of the allocation
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(lane16), "s"(src), "s"(dst)
+      : "memory");
+}
+
+// one 1 KiB piece (wave-uniform source, lane offset lane16) to LDS byte `dst`; M0 is not saved (nothing else uses it)
+__device__ __forceinline__ void dma_piece(const char* src, uint32_t lane16, uint32_t dst) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1"
+      :
+      : "v"(lane16), "s"(src), "s"(dst)
+      : "memory");
+}
+
+// Placement of a k step's micro-operations behind its 24 MFMAs: gap G issues the operations op(k), begin(G) <= k < end(G).
+struct SchedNone {
+  static constexpr int begin(int) { return 0; }
+  static constexpr int end(int) { return 0; }
+  static constexpr int op(int k) { return k; }
+};
+template <int N>
+struct SchedUniform {  // N operations in index order, evenly
+  static constexpr int begin(int G) { return N * G / NGAP; }
+  static constexpr int end(int G) { return N * (G + 1) / NGAP; }
+  static constexpr int op(int k) { return k; }
+};
+// the generated tables (scripts/gen_h3_schedule.py): transcendentals one per gap, every gap inside the MFMA's 32 cycles
+template <bool HEAD>
+struct SchedEpi {
+  static constexpr int N = HEAD ? H3_SCHED_HEAD_N : H3_SCHED_STORE_N;
+  static constexpr int end(int G) {
+    constexpr unsigned char eh[NGAP] = H3_SCHED_HEAD_END;
+    constexpr unsigned char es[NGAP] = H3_SCHED_STORE_END;
+    return HEAD ? eh[G] : es[G];
+  }
+  static constexpr int begin(int G) { return G ? end(G - 1) : 0; }
+  static constexpr int op(int k) {
+    constexpr unsigned char oh[H3_SCHED_HEAD_N] = H3_SCHED_HEAD_ORDER;
+    constexpr unsigned char os[H3_SCHED_STORE_N] = H3_SCHED_STORE_ORDER;
+    return HEAD ? oh[k < H3_SCHED_HEAD_N ? k : 0] : os[k < H3_SCHED_STORE_N ? k : 0];
+  }
+};
+
+#define H3_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+template <bool HEAD, bool STORE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rmlp_h3_kernel(H3Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, li = lane & 31;
+  const uint32_t lane16 = lane * 16;
+  float* embw = reinterpret_cast<float*>(smem + OFF_EMB) + wave * (32 * EMB_STR);
+  const char* ring_lane = smem + lane * 16;
+  const float b8 = HEAD ? *a.b8 : 0.f;  // read on the device: a host copy of a trained parameter costs a stream drain
+
+  // ---- once per workgroup: biases (+ the sdf row) into LDS, the first four k steps into the ring ----
+  for (int i = tid; i < 8 * 256; i += 256) reinterpret_cast<float*>(smem + OFF_BIAS)[i] = a.bias[i];
+  if (HEAD) reinterpret_cast<float*>(smem + OFF_W8)[tid] = a.w8[tid];
+  if (tid < 64) reinterpret_cast<float*>(smem + OFF_BARF)[tid] = SA * ((a.barf && tid < NE) ? a.barf[tid] : 1.0f);
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 4; ++s) dma_step(a.wpack, lane16, s, s, wave);
+
+  f32x16 P[8], Q[8];
+  u32x4 A[2][4];  // weight fragments of two n-tiles x two limbs, double-buffered
+  Limbs Bc, Bn;
+
+  auto read_pair = [&](int slot, int pair, u32x4 (&dst)[4]) {
+    const char* base = ring_lane + slot * SLOT + pair * (4 * PIECE);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const u32x4*>(base + i * PIECE);
+  };
+  auto init_bias = [&](int layer) {
+    const float* bl = reinterpret_cast<const float*>(smem + OFF_BIAS) + layer * 256 + 4 * hh;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bl + 32 * nt + 8 * g);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Q[nt][4 * g + k] = b[k];
+      }
+  };
+
+  int first = 1;
+  for (long blk = blockIdx.x; blk * BPTS < a.P; blk += gridDim.x) {
+    const long p0 = blk * BPTS + wave * 32;  // this wave's first point
+    long prow = p0 + li;
+    const bool prow_ok = prow < a.P;
+    prow = prow_ok ? prow : a.P - 1;
+    // ---- SA x embedding of this wave's 32 points -> wave-private LDS [32][EMB_STR] (embedders.py:18-50): lane half hh takes
+    // the frequencies 3 hh .. 3 hh + 2 of its point (9 sincosf), half 0 also the raw coordinates, half 1 the zero padding
+    {
+      const float* xr = a.xc + prow * a.ldx;
+      const float x3[3] = {xr[0], xr[1], xr[2]};
+      float* er = embw + li * EMB_STR;
+      const float* bw = reinterpret_cast<const float*>(smem + OFF_BARF);
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        const int k = 3 * hh + kk;
+        const float f = (float)(1 << k);
+#pragma unroll
+        for (int dim = 0; dim < 3; ++dim) {
+          float sn, cs;
+          sincosf(x3[dim] * f, &sn, &cs);
+          const int j = 3 + 6 * k + dim;
+          er[j] = sn * bw[j];
+          er[j + 3] = cs * bw[j + 3];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) er[hh ? NE + i : i] = hh ? 0.f : x3[i] * bw[i];
+#pragma unroll
+      for (int i = 3; i < 9; ++i)
+        if (hh) er[NE + i] = 0.f;
+    }
+    if (first) {  // step 0 of the very first block: everybody's pieces landed
+      H3_WAIT_VM(12);
+      __builtin_amdgcn_s_barrier();
+      read_pair(0, 0, A[0]);
+      first = 0;
+    }
+
+    // One k step of the layer being accumulated into Q (`t` = step index in the block's stream, ring slot t % RING) with an
+    // EXPLICIT schedule: 4 groups (pairs of n-tiles) x 6 MFMAs; behind every MFMA stands a fixed slice of everything else --
+    // one fragment read for the next group (gaps 0..3 of a group), one DMA piece (gaps 1 and 4 of the two groups behind the
+    // rendezvous), and the micro-operations nops G / 24 .. nops (G + 1) / 24 - 1 of the NEXT step's epilogue (G = the gap's
+    // index in the step) -- closed by a full scheduling barrier: with one wave per SIMD the wave must be back at the next
+    // MFMA within the 32 cycles the current one runs.
+    auto kstep = [&](int t, auto sch, auto&& mop) {
+      using S = decltype(sch);
+      const int slot = t % RING;
+#pragma unroll
+      for (int pair = 0; pair < 4; ++pair) {
+        if (pair == 2) {  // mid-step rendezvous: step t + 1 complete in LDS, slot of step t - 1 free
+          H3_WAIT_VM(8);
+          __builtin_amdgcn_s_barrier();
+        }
+        const char* rd = ring_lane + (pair < 3 ? slot * SLOT + (pair + 1) * (4 * PIECE) : ((t + 1) % RING) * SLOT);
+        const char* src = a.wpack + (long)((t + 4) % NSTEP) * SLOT + wave * (4 * PIECE) + (pair & 1) * (2 * PIECE);
+        const uint32_t dst = (uint32_t)(((t + 4) % RING) * SLOT + wave * (4 * PIECE) + (pair & 1) * (2 * PIECE));
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+          const int pr = m >> 1, tl = m & 1;           // (w limb, act limb): hi hi, hi lo, lo hi
+          const int wl = pr == 2 ? 1 : 0, al = pr == 1 ? 1 : 0;
+          Q[2 * pair + tl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[pair & 1][2 * tl + wl]),
+                                                                   __builtin_bit_cast(f16x8, Bc.l[al]), Q[2 * pair + tl],
+                                                                   0, 0, 0);
+          if (m < 4) A[(pair + 1) & 1][m] = *reinterpret_cast<const u32x4*>(rd + m * PIECE);
+          if (pair >= 2 && (m == 1 || m == 4)) dma_piece(src + (m >> 2) * PIECE, lane16, dst + (m >> 2) * PIECE);
+          const int G = 6 * pair + m;
+#pragma unroll
+          for (int u = 0; u < 12; ++u) {  // constant trip count (the slice bounds fold once pair and m are unrolled)
+            const int k = S::begin(G) + u;
+            if (k < S::end(G)) mop(S::op(k));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      Bc = Bn;
+    };
+    auto no_mop = [](int) {};
+
+    // limb split of dword d from two (scaled) values, as four micro-operations (op = 0..3); results pinned: pure VALU code
+    // has no side effects, so without the pin LLVM sinks the whole next-step epilogue to its first use
+    struct SplitState { uint32_t hi[4]; float ra[4], rb[4]; };
+    auto split_op = [&](int op, int d, float x0, float x1, Limbs& out, SplitState& ss) {
+      if (op == 0) {
+        ss.hi[d] = cvt_pk(x0, x1);
+        asm volatile("" : "+v"(ss.hi[d]));
+        out.l[0][d] = ss.hi[d];
+      } else if (op == 1) {
+        ss.ra[d] = resid<0>(ss.hi[d], x0);
+      } else if (op == 2) {
+        ss.rb[d] = resid<1>(ss.hi[d], x1);
+      } else {
+        uint32_t lo = cvt_pk(ss.ra[d], ss.rb[d]);
+        asm volatile("" : "+v"(lo));
+        out.l[1][d] = lo;
+      }
+    };
+
+    // ---- layer 0: B limbs straight from the (scaled) embedding (natural k order 16 j + 8 hh + e) ----
+    SplitState ss;
+    auto emb_mop = [&](int j, int k, Limbs& out) {  // k = 0..15: round-major over the four dwords
+      const int op = k >> 2, d = k & 3;
+      const float* er = embw + li * EMB_STR + 16 * j + 8 * hh + 2 * d;
+      split_op(op, d, er[0], er[1], out, ss);
+    };
+    init_bias(0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) emb_mop(0, k, Bc);
+#pragma unroll
+    for (int j = 0; j < L0S; ++j) {
+      if (j + 1 < L0S)
+        kstep(j, SchedUniform<16>(), [&](int k) { emb_mop(j + 1, k, Bn); });
+      else
+        kstep(j, SchedNone(), no_mop);
+    }
+
+    // ---- layers 1..7: input = SA x softplus(c3 x the previous layer's accumulators) ----
+    float part = 0.f;  // HEAD: this lane's share of w8 . h7
+    // STORE: h rows through a buffer descriptor (rows >= P fall outside num_records: the hardware drops those stores)
+    rsrc_t hrs = make_rsrc(nullptr, 0);
+    const uint32_t hbytes = (uint32_t)(a.P * a.ldh * 4);
+    const uint32_t hvoff = (uint32_t)(((p0 + li) * a.ldh + 4 * hh) * 4);
+    // Epilogue of k step j = (nt, q) of the finished layer: its 8 values P[nt][8 q + i] (features 32 nt + 16 q + 8 (i / 4) +
+    // 4 hh + i % 4) as a flat list of micro-operations in ROUND-MAJOR order (micro-operation k of the softplus part = round
+    // k / 8 on value k % 8), so consecutive micro-operations are independent and a dependent pair is eight apart.
+    //   sampler query (8 rounds): y, ys = c3 y, KE |ys|, exp2, 1 + e, log2, max(ys, 0), CL log2 + max  [skip override]
+    //   training (16 rounds): y, ys, KE |ys|, exp2, 1 + e, series x 4, log2, CL log2, select, max, +, threshold [override],
+    //                         1 / SA (the stored value)
+    //   then the limb split of the four dwords (16 micro-operations, round-major) and, training, the two 16-byte stores
+    struct EpiState { float y[8], u[8], e[8], ser[8], r[8], o[8]; };
+    constexpr int NR = HEAD ? 8 : 16;
+    constexpr int NOPS = 8 * NR + 16 + (STORE ? 2 : 0);
+    static_assert(NOPS == SchedEpi<HEAD>::N, "regenerate rmlp_h3_sched.h");
+    auto epi_mop = [&](int layer, float c3, int j, int k, Limbs& out, EpiState& st) {
+      const int nt = j >> 1, q = j & 1;
+      if (k < 8 * NR) {
+        const int rd = k >> 3, i = k & 7;
+        auto skip = [&](float r) {  // skip connection: columns 217.. of layer 3's output are the embedding (shape_net.py:122-123)
+          if (j >= 13) {
+            const int m = 32 * nt + 16 * q + 8 * (i >> 2) + 4 * hh + (i & 3) - SKIP_OUT;
+            const float ev = embw[li * EMB_STR + (m < 0 ? 0 : m)];
+            r = (layer == 4 && m >= 0) ? ev : r;
+          }
+          return r;
+        };
+        // every result is pinned (empty volatile asm): the instruction selector's list scheduler is free to place pure VALU code
+        // anywhere between its operands and its first user, and without the pins it collects the whole epilogue in
+        // front of the limb split (the first volatile user) instead of leaving each slice behind its MFMA
+#define H3_PIN(x) asm volatile("" : "+v"(x))
+        if (rd == 0) { st.y[i] = P[nt][8 * q + i]; H3_PIN(st.y[i]); }
+        else if (rd == 1) { st.y[i] = c3 * st.y[i]; H3_PIN(st.y[i]); }
+        else if (rd == 2) { st.e[i] = KE * fabsf(st.y[i]); H3_PIN(st.e[i]); }
+        else if (rd == 3) { st.e[i] = __builtin_amdgcn_exp2f(st.e[i]); H3_PIN(st.e[i]); }
+        else if (rd == 4) { st.u[i] = 1.0f + st.e[i]; H3_PIN(st.u[i]); }
+        else if (HEAD) {
+          if (rd == 5) { st.u[i] = __builtin_amdgcn_logf(st.u[i]); H3_PIN(st.u[i]); }
+          else if (rd == 6) { st.r[i] = relu1(st.y[i]); H3_PIN(st.r[i]); }
+          else { st.r[i] = skip(fmaf(CL, st.u[i], st.r[i])); H3_PIN(st.r[i]); }
+        } else {
+          if (rd == 5) { st.ser[i] = fmaf(st.e[i], 0.33333334f, -0.5f); H3_PIN(st.ser[i]); }
+          else if (rd == 6) { st.ser[i] = fmaf(st.e[i], st.ser[i], 1.0f); H3_PIN(st.ser[i]); }
+          else if (rd == 7) { st.e[i] = (0.01f * SA) * st.e[i]; H3_PIN(st.e[i]); }
+          else if (rd == 8) { st.ser[i] = st.e[i] * st.ser[i]; H3_PIN(st.ser[i]); }
+          else if (rd == 9) { st.u[i] = __builtin_amdgcn_logf(st.u[i]); H3_PIN(st.u[i]); }
+          else if (rd == 10) { st.u[i] = CL * st.u[i]; H3_PIN(st.u[i]); }
+          else if (rd == 11) { st.u[i] = (st.e[i] > 1e-5f * SA) ? st.u[i] : st.ser[i]; H3_PIN(st.u[i]); }  // e > 1e-3: log(1 + e) accurate
+          else if (rd == 12) { st.r[i] = relu1(st.y[i]); H3_PIN(st.r[i]); }
+          else if (rd == 13) { st.r[i] = st.r[i] + st.u[i]; H3_PIN(st.r[i]); }
+          else if (rd == 14) { st.r[i] = skip((st.y[i] > 0.2f * SA) ? st.y[i] : st.r[i]); H3_PIN(st.r[i]); }
+          else { st.o[i] = (1.0f / SA) * st.r[i]; H3_PIN(st.o[i]); }
+        }
+      } else if (k < 8 * NR + 16) {
+        const int s = k - 8 * NR, op = s >> 2, d = s & 3;
+        split_op(op, d, st.r[2 * d], st.r[2 * d + 1], out, ss);
+      } else {  // STORE: the four consecutive features of half h2
+        const int h2 = k - (8 * NR + 16);
+        const f32x4 v = {st.o[4 * h2], st.o[4 * h2 + 1], st.o[4 * h2 + 2], st.o[4 * h2 + 3]};
+        store4(v, hrs, hvoff + (32 * nt + 16 * q + 8 * h2) * 4);
+      }
+    };
+    for (int layer = 1; layer < 8; ++layer) {
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        P[nt] = Q[nt];
+        // the finished layer stays in the ACCUMULATOR half of the register file (read once, through v_accvgpr_read)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+a"(P[nt][r]));
+      }
+      init_bias(layer);
+      const float c3 = a.c3[layer - 1];
+      const int t0 = L0S + (layer - 1) * LKS;
+      EpiState st;
+      if (STORE) hrs = make_rsrc(a.h[layer - 1], hbytes);
+#pragma unroll
+      for (int k = 0; k < NOPS; ++k) epi_mop(layer, c3, 0, k, Bc, st);
+#pragma unroll
+      for (int j = 0; j < LKS; ++j) {
+        if (j + 1 < LKS)
+          kstep(t0 + j, SchedEpi<HEAD>(), [&](int k) { epi_mop(layer, c3, j + 1, k, Bn, st); });
+        else
+          kstep(t0 + j, SchedNone(), no_mop);
+      }
+    }
+    // ---- output of layer 7 ----
+    {
+      const float c1 = a.c3[7] * (1.0f / SA);
+      const float* w8l = reinterpret_cast<const float*>(smem + OFF_W8);
+      const rsrc_t h7rs = make_rsrc(STORE ? a.h[7] : nullptr, STORE ? hbytes : 0);
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int f0 = 32 * nt + 8 * g + 4 * hh;
+          f32x4 v;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = HEAD ? sp_fast(c1 * Q[nt][4 * g + k]) : sp_train(c1 * Q[nt][4 * g + k]);
+          if (HEAD) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(w8l + f0);
+            part += v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+          }
+          if (STORE)
+            store4(v, h7rs, hvoff + (32 * nt + 8 * g) * 4);
+        }
+      if (HEAD) {
+        const float s = part + __shfl_xor(part, 32) + b8;
+        if (hh == 0 && prow_ok) a.sdf[prow * a.lds] = s;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t hold_trunk_h3_pack_bytes(void) { return (int64_t)NSTEP * SLOT; }
+extern "C" float hold_trunk_h3_act_scale(void) { return SA; }
+
+static int rmlp_h3_launch(const H3Args& a, bool head, hipStream_t s) {
+  static int n_cu = 0;
+  static bool attr_set = false;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return HOLD_E_LAUNCH;
+    n_cu = prop.multiProcessorCount;
+  }
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)rmlp_h3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)rmlp_h3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LDS_BYTES) != hipSuccess)
+      return HOLD_E_LAUNCH;
+    attr_set = true;
+  }
+  const long blocks = (a.P + BPTS - 1) / BPTS;
+  const dim3 grid((unsigned)(blocks < n_cu ? blocks : n_cu));
+  if (head)
+    hipLaunchKernelGGL((rmlp_h3_kernel<true, false>), grid, dim3(256), LDS_BYTES, s, a);
+  else
+    hipLaunchKernelGGL((rmlp_h3_kernel<false, true>), grid, dim3(256), LDS_BYTES, s, a);
+  return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+}
+
+// SDF-only query of the sampler in the f16x3 arithmetic (the contract of hold_fused_sdf_r6 + the per-layer weight scales).
+extern "C" int hold_fused_sdf_h3(const float* xc, int32_t ldx, int64_t P, const void* wpack_h3, const float* bias_scaled,
+                                 const float* c3, const float* w8, const float* b8, const float* barf_w, float* sdf,
+                                 int32_t ld_sdf, hold_stream_t st) {
+  if (!xc || !wpack_h3 || !bias_scaled || !c3 || !w8 || !b8 || !sdf || ldx < 3 || ld_sdf < 1 || P < 0) return HOLD_E_ARG;
+  if (((uintptr_t)wpack_h3 & 15) || ((uintptr_t)w8 & 15) || ((uintptr_t)bias_scaled & 15)) return HOLD_E_ARG;
+  if (P == 0) return HOLD_OK;
+  H3Args a = {};
+  a.xc = xc; a.ldx = ldx; a.P = (long)P; a.wpack = (const char*)wpack_h3; a.bias = bias_scaled; a.c3 = c3; a.w8 = w8;
+  a.b8 = b8; a.barf = barf_w; a.sdf = sdf; a.lds = ld_sdf;
+  return rmlp_h3_launch(a, true, (hipStream_t)st);
+}
+
+// Training forward trunk in the f16x3 arithmetic: h[l] [P][ldh] (l = 0..7) = softplus outputs of lin0..lin7 (fp32,
+// unscaled); columns 217..255 of h[3] receive the embedding (the contract of hold_trunk_r6).
+extern "C" int hold_trunk_h3(const float* xc, int32_t ldx, int64_t P, const void* wpack_h3, const float* bias_scaled,
+                             const float* c3, const float* barf_w, float* const* h, int32_t ldh, hold_stream_t st) {
+  if (!xc || !wpack_h3 || !bias_scaled || !c3 || !h || ldx < 3 || ldh < 256 || (ldh & 3) || P < 0) return HOLD_E_ARG;
+  if (((uintptr_t)wpack_h3 & 15) || ((uintptr_t)bias_scaled & 15)) return HOLD_E_ARG;
+  H3Args a = {};
+  for (int l = 0; l < 8; ++l) {
+    if (!h[l] || ((uintptr_t)h[l] & 15)) return HOLD_E_ARG;
+    a.h[l] = h[l];
+  }
+  if (P == 0) return HOLD_OK;
+  if (((uint64_t)P + 128) * (uint64_t)ldh * 4 >= (1ull << 32)) return HOLD_E_ARG;  // 32-bit buffer offsets: split by rows
+  a.xc = xc; a.ldx = ldx; a.P = (long)P; a.wpack = (const char*)wpack_h3; a.bias = bias_scaled; a.c3 = c3; a.barf = barf_w;
+  a.ldh = ldh;
+  return rmlp_h3_launch(a, false, (hipStream_t)st);
+}

@@ -33,6 +33,7 @@ FUSED_SDF = os.environ.get("HOLD_FUSED_SDF", "1") != "0"  # sampler queries thro
 USE_CHAIN = os.environ.get("HOLD_CHAIN", "1") != "0"
 # register-resident trunk (csrc/rmlp.hip) for the sampler queries and the training forward trunk (f32x6 arithmetic only)
 USE_R6 = os.environ.get("HOLD_R6", "1") != "0"
+USE_H3_TRUNK = os.environ.get("HOLD_H3_TRUNK", "1") != "0"  # mode f16x3: the training forward trunk too (A/B switch)
 USE_R6_BWD = os.environ.get("HOLD_R6_BWD", "1") != "0"  # ... and for the descending sweeps (csrc/rchain.hip)
 # the 256 x 256 weight gradients of a backward as one grouped launch (gemm.WgradGroup / hold_wgrad_group_x6)
 USE_WGRAD_GROUP = os.environ.get("HOLD_WGRAD_GROUP", "1") != "0"
@@ -145,13 +146,14 @@ def _lay_x6_stack(l3):
 
 
 def _lay_r6_0(l3):
-    return l3.reshape(3, 8, 32, 3, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(-1)
+    T = l3.shape[0]  # limbs: 3 (bf16, hold_trunk_r6) or 2 (fp16, hold_trunk_h3)
+    return l3.reshape(T, 8, 32, 3, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(-1)
 
 
 def _lay_r6_stack(l3):
-    L = l3.shape[1]
-    g = l3[:, :, :, r6_kmap(l3.device)]  # [3 t, L, 256 out, 16 j, 2 h, 8 e]
-    return g.reshape(3, L, 8, 32, 16, 2, 8).permute(1, 4, 2, 0, 5, 3, 6).reshape(-1)
+    T, L = l3.shape[0], l3.shape[1]
+    g = l3[:, :, :, r6_kmap(l3.device)]  # [T limbs, L, 256 out, 16 j, 2 h, 8 e]
+    return g.reshape(T, L, 8, 32, 16, 2, 8).permute(1, 4, 2, 0, 5, 3, 6).reshape(-1)
 
 
 def pack_x6(W8, first_k=48):
@@ -196,6 +198,35 @@ def pack_r6(w0, S):
     m0[:, :w0.shape[1]] = w0
     p0 = _lay_r6_0(torch.stack(split_limbs(m0)))  # limbs [3, 256, 48] = (t, 32 nt + i, 16 j + 8 h + e)
     return torch.cat([p0, _lay_r6_stack(torch.stack(split_limbs(S)))]).contiguous()
+
+
+H3_ACT_SCALE = 64.0  # SA of csrc/rmlp_h3.hip (checked against hold_trunk_h3_act_scale() by kernels.fused_sdf_h3)
+
+
+def h3_scales(w0, S):
+    """per-matrix power-of-two weight scales of the f16x3 trunk: s_w[l] = 2^k with max |W_l| s_w in [2^13, 2^14) (frexp: exact,
+    no host read) -> [8] device tensor"""
+    amax = torch.cat([w0.abs().amax().view(1), S.abs().amax(dim=(1, 2))])
+    _, ex = torch.frexp(amax)  # amax = m 2^ex, m in [0.5, 1)
+    return torch.ldexp(torch.ones_like(amax), 14 - ex)
+
+
+def split_limbs_h(ws):
+    """two-limb fp16 decomposition of ALREADY SCALED values: hi = RN_f16(ws), lo = RN_f16(ws - hi)"""
+    hi = ws.to(torch.float16)
+    return [hi, (ws - hi.float()).to(torch.float16)]
+
+
+def pack_h3(w0, S):
+    """limb pack of hold_fused_sdf_h3 / hold_trunk_h3 (include/hold_hip.h): the k order and tiling of pack_r6 with TWO fp16
+    limbs of the scaled weights -> (fp16 [115 steps][8 nt][2 t][2 h][32 i][8 e], s_w [8])"""
+    dev = S.device
+    sw = h3_scales(w0, S)
+    m0 = torch.zeros(256, 48, device=dev)
+    m0[:, :w0.shape[1]] = w0
+    p0 = _lay_r6_0(torch.stack(split_limbs_h(m0 * sw[0])))
+    ps = _lay_r6_stack(torch.stack(split_limbs_h(S * sw[1:].view(7, 1, 1))))
+    return torch.cat([p0, ps]).contiguous(), sw
 
 
 def pack_r6_stack(S):
@@ -264,7 +295,11 @@ def pack_plan(K0, device):
         N += 65536
         ISTf = IS.transpose(1, 2).flip(0)  # descending sweeps: layer j = W_{7-j}^T
         l3 = lambda I: torch.stack([I + t * N for t in range(3)])
+        l2 = lambda I: torch.stack([I + t * N for t in range(2)])
         i32 = lambda t: t.to(torch.int32).contiguous()
+        seg = torch.cat([torch.zeros(n0, dtype=torch.long, device=device),
+                         1 + torch.arange(7, device=device).repeat_interleave(65536),
+                         torch.full((65536,), 8, dtype=torch.long, device=device)])  # matrix index of every source element
         frag0 = I0[:, :K0].reshape(8, 32, K0 // 8, 2, 4).permute(2, 0, 3, 1, 4).reshape(-1)
         _PLANS[key] = dict(
             N=N,
@@ -272,6 +307,7 @@ def pack_plan(K0, device):
             chain_bwd=i32(frag_pack_stack(ISTf)),
             fused_x6=i32(torch.cat([_lay_x6(l3(I0), 48), _lay_x6_stack(l3(IS))])),
             trunk_r6=i32(torch.cat([_lay_r6_0(l3(I0)), _lay_r6_stack(l3(IS))])),
+            trunk_h3=i32(torch.cat([_lay_r6_0(l2(I0)), _lay_r6_stack(l2(IS))])), seg=seg,
             chain_bwd_x6=i32(_lay_x6_stack(l3(ISTf))),
             chain_bwd_r6=i32(_lay_r6_stack(l3(ISTf))),
             w8_feat_r6=i32(_lay_gemm_r6(l3(I8), 16)))
@@ -331,6 +367,12 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool, trunk=None):
         pk["chain_bwd_x6"] = limbs.index_select(0, plan["chain_bwd_x6"])
         pk["chain_bwd_r6"] = limbs.index_select(0, plan["chain_bwd_r6"])
         pk["w8_feat_r6"] = limbs.index_select(0, plan["w8_feat_r6"])  # hold_gemm_r6 pack of lin8's feature rows
+    if config.h3():  # two-limb fp16 stream of the forward trunk (csrc/rmlp_h3.hip) + its scales, all on the device
+        sw = h3_scales(w0, S)
+        sw9 = torch.cat([sw, torch.ones(1, device=dev)])
+        pk["trunk_h3"] = torch.stack(split_limbs_h(src * sw9[plan["seg"]])).reshape(-1).index_select(0, plan["trunk_h3"])
+        pk["bias8_h3"] = (bias8 * (sw * H3_ACT_SCALE).view(8, 1)).contiguous()
+        pk["c3_h3"] = (1.0 / sw).contiguous()
     if rw is None:  # implicit net only (ImplicitNet.forward / gradient)
         return pk
     return _pack_render(pk, spec, rw, rb, need_bwd, dev)
@@ -393,7 +435,10 @@ class NodeField:
             # accumulator registers; the embedding matrix itself is only needed by the backward (layer-0 weight gradient)
             if need_in0:
                 K.embed_fwd(xc, 3, sp.L, P, in0, barf_w=barf_w)
-            K.trunk_r6(xc, P, pk["trunk_r6"], pk["fused"][1], barf_w, h)
+            if USE_H3_TRUNK and "trunk_h3" in pk:
+                K.trunk_h3(xc, P, pk["trunk_h3"], pk["bias8_h3"], pk["c3_h3"], barf_w, h)
+            else:
+                K.trunk_r6(xc, P, pk["trunk_r6"], pk["fused"][1], barf_w, h)
             return in0, h
         K.embed_fwd(xc, 3, sp.L, P, in0, out2=h[3][:, sp.skip_out:], barf_w=barf_w)
         W, b = pk["W"], pk["b"]
@@ -445,6 +490,9 @@ class NodeField:
         """no-grad SDF query of the sampler (sdf_func_with_deformer, volsdf_utils.py:150-169).  out_sdf [P,1]."""
         self.gen += 1  # overwrites the pooled canonical points a pending backward would read
         xc, _ = self._deform(x, P, ppf, dfm, want_w=False)
+        if FUSED_SDF and USE_R6 and "trunk_h3" in pk:
+            K.fused_sdf_h3(xc, P, pk["trunk_h3"], pk["bias8_h3"], pk["c3_h3"], pk["w8_sdf"], pk["b8_sdf"], barf_w, out_sdf)
+            return
         if FUSED_SDF and USE_R6 and "trunk_r6" in pk:
             K.fused_sdf_r6(xc, P, pk["trunk_r6"], pk["fused"][1], pk["w8_sdf"], pk["b8_sdf"], barf_w, out_sdf)
             return

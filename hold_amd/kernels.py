@@ -136,6 +136,20 @@ def fused_sdf_r6(xc, P, wpack_r6, bias8, w8, b8, barf_w, out_sdf):
     _g._prof_end(e0, 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256), "fused_sdf_kernel", 20.0 * P)
 
 
+def fused_sdf_h3(xc, P, wpack_h3, bias8_scaled, c3, w8, b8, barf_w, out_sdf):
+    """the sampler's SDF query in the two-limb fp16 arithmetic (csrc/rmlp_h3.hip): wpack_h3 / bias8_scaled / c3 from
+    field.pack_weights in mode f16x3 (field.pack_h3); otherwise the contract of fused_sdf_r6"""
+    L = _lib.lib()
+    assert wpack_h3.numel() * wpack_h3.element_size() == L.hold_trunk_h3_pack_bytes() and wpack_h3.dtype == torch.float16
+    assert b8.is_cuda and b8.numel() == 1 and b8.dtype == torch.float32 and c3.numel() == 8 and c3.dtype == torch.float32
+    from . import field as _f, gemm as _g
+    assert L.hold_trunk_h3_act_scale() == _f.H3_ACT_SCALE
+    e0 = _g._prof_begin()
+    call("hold_fused_sdf_h3", ptr(xc), _ld(xc), P, ptr(wpack_h3), ptr(bias8_scaled), ptr(c3), ptr(w8), ptr(b8),
+         ptr(barf_w), ptr(out_sdf), _ld(out_sdf))
+    _g._prof_end(e0, 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256), "fused_sdf_kernel", 20.0 * P)
+
+
 def _max_rows(ld):
     """largest row count per launch of the kernels with 32-bit byte offsets: they reject (P + 128) * ld * 4 >= 2^32"""
     return ((1 << 32) // (4 * ld) - 129) // 128 * 128
@@ -157,6 +171,22 @@ def trunk_r6(xc, P, wpack_r6, bias8, barf_w, h):
         arr = (C.c_void_p * 8)(*[t[r0:].data_ptr() for t in h])
         e0 = _g._prof_begin()
         call("hold_trunk_r6", ptr(xc[r0:]), _ld(xc), n, ptr(wpack_r6), ptr(bias8), ptr(barf_w), arr, ld)
+        _g._prof_end(e0, 2.0 * n * (40 * 256 + 6 * 65536 + 217 * 256), "trunk_r6_kernel", n * (16.0 + 8 * 1024))
+
+
+def trunk_h3(xc, P, wpack_h3, bias8_scaled, c3, barf_w, h):
+    """training forward trunk in the two-limb fp16 arithmetic: the contract of trunk_r6 (h in fp32, unscaled)"""
+    import ctypes as C
+    assert wpack_h3.numel() * wpack_h3.element_size() == _lib.lib().hold_trunk_h3_pack_bytes()
+    from . import gemm as _g
+    ld = h[0].stride(0)
+    assert all(t.stride(0) == ld and t.stride(1) == 1 for t in h)
+    step = min(_TRUNK_MAX_ROWS, _max_rows(ld))
+    for r0 in range(0, P, step):
+        n = min(step, P - r0)
+        arr = (C.c_void_p * 8)(*[t[r0:].data_ptr() for t in h])
+        e0 = _g._prof_begin()
+        call("hold_trunk_h3", ptr(xc[r0:]), _ld(xc), n, ptr(wpack_h3), ptr(bias8_scaled), ptr(c3), ptr(barf_w), arr, ld)
         _g._prof_end(e0, 2.0 * n * (40 * 256 + 6 * 65536 + 217 * 256), "trunk_r6_kernel", n * (16.0 + 8 * 1024))
 
 

@@ -363,6 +363,27 @@ int hold_trunk_r6(const float* xc, int32_t ldx, int64_t P, const void* wpack_r6,
                   float* const* h, int32_t ldh, hold_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The same trunk in the TWO-LIMB fp16 arithmetic "f16x3" (hold_amd/csrc/rmlp_h3.hip; shape_net.py:84-130): every operand
+ * x, scaled by an exact power of two s, is hi + lo with hi = RN_f16(s x), lo = RN_f16(s x - hi); the products
+ * hi_w hi_x + hi_w lo_x + lo_w hi_x go to v_mfma_f32_32x32x16_f16 with fp32 accumulation -- three matrix instructions per
+ * product instead of six, 16 KiB of weight limbs per k step instead of 24; error against fp64 as hold_fused_sdf_r6
+ * (tests/test_rmlp_gpu.py holds it to <= 1.5 x that kernel's).  Activations are scaled by hold_trunk_h3_act_scale() = 2^6
+ * inside the kernel (an activation >= 1023 overflows fp16 to +inf: the output is then inf / NaN, never silently wrong);
+ * weights by a per-matrix s_w[l] = 2^k chosen by the caller with max |W_l| s_w[l] < 2^15 ([2^13, 2^14) recommended).
+ * wpack_h3: hold_trunk_h3_pack_bytes() bytes of fp16, [115 k steps][8 n-tiles nt][2 limbs t][2 halves h][32 rows i][8 e],
+ *   the k steps, rows and k order of wpack_r6, limb_t of s_w[l] W_l.
+ * bias_scaled: [8][256] = bias_l s_w[l] hold_trunk_h3_act_scale();  c3: [8] = 1 / s_w[l] (device memory).
+ * hold_fused_sdf_h3 / hold_trunk_h3: otherwise the contracts of hold_fused_sdf_r6 / hold_trunk_r6 (outputs in fp32, unscaled).
+ * ---------------------------------------------------------------------------------------- */
+int64_t hold_trunk_h3_pack_bytes(void);
+float hold_trunk_h3_act_scale(void);
+int hold_fused_sdf_h3(const float* xc, int32_t ldx, int64_t P, const void* wpack_h3, const float* bias_scaled,
+                      const float* c3, const float* w8, const float* b8, const float* barf_w, float* sdf, int32_t ld_sdf,
+                      hold_stream_t stream);
+int hold_trunk_h3(const float* xc, int32_t ldx, int64_t P, const void* wpack_h3, const float* bias_scaled, const float* c3,
+                  const float* barf_w, float* const* h, int32_t ldh, hold_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * LDS-resident layer chains of the ImplicitNet for the TRAINING path (hold_amd/csrc/chain.hip): up to 8 consecutive
  * 256-wide layers of one sweep in one launch; the running activation stays in LDS, per-layer side inputs are read
  * from and per-layer results written to HBM directly from the accumulators.  Replaces n_layers hold_gemm_nt calls of

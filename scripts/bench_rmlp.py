@@ -32,6 +32,11 @@ for P in PS:
     b8f = float(pk["b8_sdf"])
     ms = timeit(lambda: K.fused_sdf_x6(xc, P, pk["fused_x6"], bias8, pk["w8_sdf"], b8f, None, out))
     ms2 = timeit(lambda: K.fused_sdf_r6(xc, P, pk["trunk_r6"], bias8, pk["w8_sdf"], pk["b8_sdf"], None, out2))
+    pk3, sw = F.pack_h3(pk["W"][0], torch.stack([torch.nn.functional.pad(w, (0, 0, 0, 256 - w.shape[0])) for w in pk["W"][1:8]]))
+    bs3, c33 = (bias8 * (sw * F.H3_ACT_SCALE).view(8, 1)).contiguous(), (1.0 / sw).contiguous()
+    out3 = torch.empty(P, 1, device=dev)
+    ms3 = timeit(lambda: K.fused_sdf_h3(xc, P, pk3, bs3, c33, pk["w8_sdf"], pk["b8_sdf"], None, out3))
+    print(f"sdf query P={P}: h3 {ms3:.3f} ms {flops / ms3 / 1e9:.1f} TF-eq ({ms2 / ms3:.2f}x r6) | max diff to r6 {float((out3 - out2).abs().max()):.2e}", flush=True)
     print(f"sdf query P={P}: x6p {ms:.3f} ms {flops / ms / 1e9:.1f} TF-eq | r6 {ms2:.3f} ms {flops / ms2 / 1e9:.1f} TF-eq | "
           f"max diff {float((out - out2).abs().max()):.2e}", flush=True)
     if P * 256 * 4 * 9 < 60e9:
@@ -45,6 +50,11 @@ for P in PS:
         ms = timeit(chain)
         ms2 = timeit(lambda: K.trunk_r6(xc, P, pk["trunk_r6"], bias8, None, h2))
         fl = 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256)
+        h3b = [torch.empty(P, 256, device=dev) for _ in range(8)]
+        ms3 = timeit(lambda: K.trunk_h3(xc, P, pk3, bs3, c33, None, h3b))
+        print(f"fwd trunk P={P}: trunk_h3 {ms3:.3f} ms {fl / ms3 / 1e9:.1f} TF-eq ({ms2 / ms3:.2f}x trunk_r6) | max diff to r6 "
+              f"{max(float((a - b).abs().max()) for a, b in zip(h3b, h2)):.2e}", flush=True)
+        del h3b
         dl = [float((a - b).abs().max()) for a, b in zip(h, h2)]
         d = max(dl)
         if d > 1e-3:  # diagnostics: which layer / column, and which of the two kernels is off a torch fp32 trunk on 512 rows

@@ -94,6 +94,76 @@ def test_r6_stream_reproduces_the_trunk():
     assert np.abs(h7 - a).max() < 1e-9, np.abs(h7 - a).max()
 
 
+def test_h3_stream_is_the_r6_stream_in_two_fp16_limbs():
+    """hold_trunk_h3's weight stream (field.pack_h3, csrc/rmlp_h3.hip): the k order / tiling of pack_r6 (pinned to the lane
+    model above) with TWO fp16 limbs of the scaled weights: hi + lo = s_w W to 2^-22 relative (2^-25 absolute below the fp16
+    normal range of lo), s_w[l] an exact power of two with max |W_l| s_w in [2^13, 2^14); and the pack that
+    field.pack_weights gathers from the flat source in mode f16x3 is the same stream bit for bit."""
+    import hold_amd
+    from hold_amd import field as F
+    g = torch.Generator().manual_seed(11)
+    w0 = torch.randn(256, 40, generator=g) * 0.2
+    w0[:, 39] = 0
+    S = torch.randn(7, 256, 256, generator=g) * torch.tensor([0.08, 0.3, 0.001, 0.08, 2.0, 0.08, 0.08]).view(7, 1, 1)
+    S[2, SKIP:] = 0
+    pk, sw = F.pack_h3(w0, S)
+    assert pk.dtype == torch.float16 and pk.numel() * 2 == NSTEP * 16 * 1024
+    mant, ex = torch.frexp(sw)
+    assert torch.all(mant == 0.5)  # exact powers of two
+    amax = torch.cat([w0.abs().amax().view(1), S.abs().amax(dim=(1, 2))])
+    assert torch.all(amax * sw >= 2.0 ** 13) and torch.all(amax * sw < 2.0 ** 14)
+    h3 = pk.double().reshape(NSTEP, 8, 2, 2, 32, 8)
+    r6 = pack_r6(w0, S).double().reshape(NSTEP, 8, 3, 2, 32, 8).sum(2)  # exact fp32 weights in the stream's order
+    layer = torch.cat([torch.zeros(L0S, dtype=torch.long), 1 + torch.arange(7).repeat_interleave(LKS)])
+    scale = sw.double()[layer].view(NSTEP, 1, 1, 1, 1)
+    ws = r6 * scale
+    err = (h3.sum(2) - ws).abs()
+    assert torch.all(err <= ws.abs() * 2.0 ** -22 + 2.0 ** -25), float((err - ws.abs() * 2.0 ** -22).max())
+    hi = h3[:, :, 0]
+    assert torch.equal(hi, ws.to(torch.float32).to(torch.float16).double())  # limb 0 = RN_f16 of the scaled weight
+    # the flat-source gather of pack_weights
+    prev = hold_amd.precision()
+    hold_amd.set_precision("f16x3")
+    try:
+        spec = F.FieldSpec("object")
+        iw = [w0[:, :39].contiguous()] + [S[l].clone() for l in range(7)] + [torch.randn(257, 256, generator=g) * 0.05]
+        iw[3] = iw[3][:SKIP].contiguous()
+        ib = [torch.randn(w.shape[0], generator=g) * 0.1 for w in iw]
+        pkw = F.pack_weights(spec, iw, ib, None, None, need_bwd=False)
+        S2 = S.clone()
+        S2[3] = S2[3] / 2 ** 0.5  # pack_weights folds the skip concat's 1 / sqrt(2) into lin4
+        ref, sw2 = F.pack_h3(w0, S2)
+        assert torch.equal(pkw["trunk_h3"], ref)
+        assert torch.equal(pkw["c3_h3"], 1.0 / sw2)
+        b8 = torch.stack([torch.nn.functional.pad(b, (0, 256 - b.shape[0])) for b in ib[:8]])
+        assert torch.equal(pkw["bias8_h3"], b8 * (sw2 * F.H3_ACT_SCALE).view(8, 1))
+        assert "trunk_r6" in pkw  # the sweeps without an fp16 variant still find their bf16 streams
+    finally:
+        hold_amd.set_precision(prev)
+
+
+def test_h3_schedule_tables_are_permutations_that_respect_the_dependencies():
+    """hold_amd/csrc/rmlp_h3_sched.h (generated, committed) == what scripts/gen_h3_schedule.py prints; every table is a
+    permutation of the kernel's micro-operation indices in which an operation follows the ones it reads"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "gen_h3_schedule.py")], capture_output=True, text=True,
+                         check=True).stdout
+    assert out == open(os.path.join(root, "hold_amd", "csrc", "rmlp_h3_sched.h")).read()
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    import gen_h3_schedule as G
+    import re
+    for head, name in ((True, "H3_SCHED_HEAD"), (False, "H3_SCHED_STORE")):
+        order = [int(v) for v in re.search(r"#define %s_ORDER \{([^}]*)\}" % name, out).group(1).split(",")]
+        end = [int(v) for v in re.search(r"#define %s_END \{([^}]*)\}" % name, out).group(1).split(",")]
+        ops = G.build(head)
+        assert sorted(order) == sorted(ops) == list(range(len(order)))
+        pos = {k: i for i, k in enumerate(order)}
+        assert all(pos[d] < pos[k] for k, o in ops.items() for d in o["deps"])
+        assert len(end) == 24 and end[-1] == len(order) and all(a <= b for a, b in zip(end, end[1:]))
+        assert max(b - a for a, b in zip([0] + end, end)) <= 12  # the kernel's per-gap loop bound
+
+
 def test_gemm_r6_stream_reproduces_a_layer():
     """hold_gemm_r6 (csrc/rgemm.hip) on the same lane-level model: the B operand of k step e is the lane's own row, columns
     16 e + 8 (i / 4) + 4 hh + i % 4 (two 16-byte pieces at 16 e + 4 hh and 16 e + 8 + 4 hh); with the weight stream of
