@@ -52,11 +52,13 @@ def parse():
     ap.add_argument("--chunk", type=int, default=16384, help="rays per microbatch (~85 GB of saved activations per fg node)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=32)
-    ap.add_argument("--cpu-frames", type=int, default=3, help="frames (x 128 rays) of the reference's 10-frame step the cpu_baseline leg times")
+    ap.add_argument("--cpu-frames", type=int, default=1, help="frames (x 128 rays) of the reference's 10-frame step the cpu_baseline leg times")
     ap.add_argument("--mode", default="train", choices=["train", "render", "c3", "c5"])
     ap.add_argument("--loss", default="full", choices=["pixel", "full"])
     ap.add_argument("--two-hands", action="store_true", help="ARCTIC-style scene (right + left + object), config C4")
     ap.add_argument("--fp32-mfma", action="store_true", help="true-fp32 MFMA everywhere (no split-precision kernels)")
+    ap.add_argument("--precision", default=None, choices=["f32", "f32x6", "f16x3"],
+                    help="arithmetic of the MFMA kernels (hold_amd/config.py); default: the package default")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--op-sites", default=None, metavar="PATH",
                     help="diagnostic: count the non-view torch operators of ONE extra step by the hold_amd source line that "
@@ -79,15 +81,20 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(sc, sd_np, threads=32, repeats=1, n_frames=3):
+def cpu_baseline(sc, sd_np, threads=32, repeats=3, n_frames=1):
     """The CPU oracle (torch restatement of the reference's PyTorch path, oracle/hold_oracle.py + oracle/targets_oracle.py)
     timed on the host in the REFERENCE'S OWN step shape (VERDICT r3 missing #6): 10 frames x 128 random pixels = 1 280 rays
     (general.yaml:82, tempo_dataset.py:27-36), forward + the loss targets of a steady-state step (off-surface test of every
     canonical sample against the node's loss-target mesh, MANO-canonical SDF and eikonal samples, hold_utils.py:149-240) +
-    the full Loss (code/src/hold/loss.py:17-93) + backward.  BOUNDED SAMPLE: `n_frames` of the step's 10 frames (default 3 =
-    384 rays, about half a minute on 32 threads; every term is a sum over frames / rays, the cost is linear in them:
-    `--cpu-frames 10` times the whole 1 280-ray step, 114 s on the round's GPU box = 11.2 rays/s) -- the exact point-to-mesh
-    geometry of the loss targets (kaolin on a GPU in the reference) is 1.2e6 point-triangle tests per ray on the host."""
+    the full Loss (code/src/hold/loss.py:17-93) + backward.  BOUNDED SAMPLE: `n_frames` of the step's 10 frames (default 1 =
+    128 rays; every term is a sum over frames / rays, the cost is linear in them: `--cpu-frames 10` times the whole 1 280-ray
+    step, 114 s on round 4's GPU box), ONE untimed warm-up of the network part, then `repeats` (>= 3, BASELINE.md section 3:
+    median of repeated steps) timed steps with fresh pixel draws; median and spread are reported.  Each step is timed in TWO
+    parts (advisor r4): `network` = forward + Loss + backward, and `loss_target_geometry` = the exact point-to-mesh distances of
+    the loss targets, 1.2e6 point-triangle tests per ray on the host -- the reference computes those with kaolin ON A GPU
+    (volsdf_utils.py:172-217), so a CPU run of the reference would not contain them in this form: `value` is the whole step
+    (what this port costs on the host), `network_only_rays_per_s` the part a CPU run of the reference's own PyTorch code
+    spends in its networks; neither is a like-for-like ratio to quote against the GPU line."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from hold_amd import synthetic as syn
     from oracle import fitting_oracle as fo
@@ -116,10 +123,10 @@ def cpu_baseline(sc, sd_np, threads=32, repeats=1, n_frames=3):
     ov, of_ = to.subdivide_loop(ov[0].numpy(), of_.numpy())
     ov, of_ = torch.as_tensor(ov, dtype=torch.float32), torch.as_tensor(of_, dtype=torch.int64)
     bw = ho.barf_weights(4000, 6, 3)
-    times = []
-    for rep in range(repeats):
+    times, t_net, t_geo = [], [], []
+    for rep in range(-1, max(3, repeats)):  # rep -1 = the warm-up (network part only: thread pool, allocator, lazy inits)
         sdg = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in sd.items()}
-        g = torch.Generator().manual_seed(rep)
+        g = torch.Generator().manual_seed(rep + 1)
         pix = torch.randperm(W * W, generator=g)[:128].numpy()
         uv = syn.make_uv(W, W)[pix]
         b = syn.make_batch(sc, frames, uv, W, W)
@@ -147,26 +154,45 @@ def cpu_baseline(sc, sd_np, threads=32, repeats=1, n_frames=3):
         out["step"], out["epoch"] = 400, 0
         # loss targets (oracle/targets_oracle.py:loss_targets_hand / _object, in float32 and 512-point chunks: the exact
         # point-to-mesh geometry is 1.5e9 point-triangle tests per step, the bulk of the CPU step)
+        tg = 0.0
         for nid, mv, mf, thr in (("right", hv, hf, 0.01), ("object", ov, of_, 0.05)):
             xc = ex[nid]["x_c"].detach().view(-1, 3)
-            sdm = go.mesh_sdf(xc, mv, mf, chunk=512).view(N, -1)
-            out[f"{nid}.index_off_surface"] = sdm.min(dim=1).values > thr
+            tg0 = time.time()
+            if rep < 0:  # warm-up: every sample "off surface" (the geometry kernel has no state worth warming)
+                out[f"{nid}.index_off_surface"] = torch.ones(N, dtype=torch.bool)
+            else:
+                sdm = go.mesh_sdf(xc, mv, mf, chunk=512).view(N, -1)
+                out[f"{nid}.index_off_surface"] = sdm.min(dim=1).values > thr
+            tg += time.time() - tg0
             out[f"{nid}.grad_theta"] = to.grad_theta(sdg, nid, eik, None if nid == "right" else bw)
-        out["right.pts2mano_sdf_cano"] = go.mesh_sdf(cano.view(-1, 3), hv, hf, chunk=512).view(B, -1)
+        tg0 = time.time()
+        out["right.pts2mano_sdf_cano"] = (go.mesh_sdf(cano.view(-1, 3), hv, hf, chunk=512).view(B, -1) if rep >= 0 else
+                                          torch.zeros(B, cano.shape[1]))
+        tg += time.time() - tg0
         xs = cano.reshape(-1, 3)
         out["right.pred_sdf"] = ho.implicit_net(sdg, "nodes.right.implicit_network", xs, torch.zeros(xs.shape[0], 45), 6, None,
                                                 zero_cond=True)[:, 0].view(B, -1)
         ld = to.loss_forward({"gt.rgb": torch.from_numpy(b["gt.rgb"]), "gt.mask": torch.from_numpy(b["gt.mask"])}, out)
         ld["loss"].backward()
-        times.append(time.time() - t0)
+        if rep >= 0:
+            times.append(time.time() - t0)
+            t_geo.append(tg)
+            t_net.append(times[-1] - tg)
     med = float(np.median(times))
+    repeats = len(times)
     return {"value": N / med, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"{repeats} training step(s) of {len(frames)} frames x 128 random pixels = {N} rays -- the reference's step layout "
+            "repeats": repeats, "step_s": {"median": med, "min": float(min(times)), "max": float(max(times)),
+                                           "spread": float((max(times) - min(times)) / med), "all": [round(t, 3) for t in times]},
+            "network_only_rays_per_s": N / float(np.median(t_net)),
+            "parts_s": {"network_fwd_loss_bwd": [round(t, 3) for t in t_net], "loss_target_geometry": [round(t, 3) for t in t_geo]},
+            "like_for_like": False,
+            "sample": f"1 warm-up + {repeats} timed training steps of {len(frames)} frames x 128 random pixels = {N} rays -- the reference's step layout "
                       f"(general.yaml:82: 10 frames x 128 = 1 280 rays per step; a bounded sample of it, the cost is linear in frames; "
-                      f"--cpu-frames 10 times the whole step: 11.2 rays/s on this pool's box), forward + loss targets (off-surface test of every canonical sample against the "
+                      f"--cpu-frames 10 times the whole step: 11.2 rays/s on round 4's box), forward + loss targets (off-surface test of every canonical sample against the "
                       f"{hf.shape[0]}- / {of_.shape[0]}-face loss-target meshes, MANO-canonical SDF, eikonal samples) + the full Loss "
                       f"(rgb, semantics, eikonal, MANO-cano SDF, opacity sparsity) + backward -- the GPU step's terms, without its "
-                      f"clip + Adam; median step {med:.2f} s (all: {[round(t, 2) for t in times]}); kind 'port': oracle/hold_oracle.py + "
+                      f"clip + Adam; median step {med:.2f} s (all: {[round(t, 2) for t in times]}; of which the exact point-to-mesh geometry of the "
+                      f"loss targets, kaolin on a GPU in the reference, {float(np.median(t_geo)):.2f} s -- reported apart as parts_s); kind 'port': oracle/hold_oracle.py + "
                       f"oracle/targets_oracle.py, the torch-CPU restatement pinned to the reference by tests/golden -- the reference "
                       f"tree itself is not present on the GPU box; {cores} torch threads of {os.cpu_count()} host hardware threads "
                       f"(torch's intra-op pool stops scaling near 32 on these tensors)"}
@@ -252,7 +278,7 @@ def main():
     from hold_amd.optim import FlatAdam
     from hold_amd.train import render_frame, train_step
 
-    hold_amd.set_precision("f32" if args.fp32_mfma else "f32x6")
+    hold_amd.set_precision("f32" if args.fp32_mfma else (args.precision or hold_amd.config.DEFAULT_PRECISION))
     training = args.mode in ("train", "c3")
     W = H = args.res or (1024 if args.mode == "c5" else 512)
     n_frames = max(16, world) if args.mode == "c3" else max(8, world)
@@ -442,7 +468,12 @@ def main():
         S_node = smp.N_samples + 2 + smp.N_samples_extra
         fpr = flop_per_ray(list(net.nodes), mean_iters, S_node, smp.N_samples_eval, training)
         fpr4 = flop_per_ray(list(net.nodes), {n: 4.0 / len(net.nodes) for n in net.nodes}, S_node, smp.N_samples_eval, training)
-        x6 = hold_amd.precision() == "f32x6"
+        x6 = hold_amd.precision() in ("f32x6", "f16x3")
+        h3 = hold_amd.precision() == "f16x3"
+        # kernel families that run the two-limb fp16 arithmetic in mode f16x3 (3 limb products issued per algorithmic product on
+        # v_mfma_f32_32x32x16_f16, same dense peak as bf16); every other split-precision family issues 6 bf16 limb products
+        from hold_amd import field as _field
+        h3_fams = ({"fused_sdf_kernel"} | ({"trunk_r6_kernel"} if _field.USE_H3_TRUNK else set())) if h3 else set()
         scene = ("configs[3]-like ARCTIC two-hand (right+left+object+background), " if args.two_hands else
                  "hold_bottle1_itw-like single-hand (right+object+background), ")
         if args.mode == "c3":
@@ -466,7 +497,12 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if (args.split == "rays" and world > 1 and args.mode != "c3") else "weak",
             "vs_baseline": None,
-            "dtype": ("f32x6 (fp32 results; every MFMA product = exact 3-limb bf16 split of both fp32 operands, 6 of 9 limb "
+            "dtype": ("f16x3+f32x6 (fp32 results, fp32 accumulation everywhere; the forward trunk kernels -- sampler SDF queries and the "
+                      "training forward trunk -- split both fp32 operands, scaled by exact powers of two, into two fp16 limbs hi = "
+                      "RN(x), lo = RN(x - hi) and issue hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (3 MFMAs per product, error vs "
+                      "fp64 <= that of f32x6: tests/test_rmlp_gpu.py); every other MFMA kernel is f32x6; --precision f32x6 / "
+                      "--fp32-mfma select the other arithmetics)" if h3 else
+                      "f32x6 (fp32 results; every MFMA product = exact 3-limb bf16 split of both fp32 operands, 6 of 9 limb "
                       "products on v_mfma_f32_32x32x16_bf16, fp32 accumulate; --fp32-mfma for true-fp32 operands)"
                       if x6 else "f32"),
             "data": "synthetic",
@@ -477,6 +513,9 @@ def main():
                        "measured mean sampler rounds of the timed region",
                        "rays_per_s_at_sigmaI_4": total_rays / dt * fpr / fpr4,
                        "algorithmic_tflops_end_to_end": total_rays / dt * fpr / 1e12,
+                       "algorithmic_tflops_note": "SURVEY 8(d)'s constants credit every sampler query with lin8's 256 feature rows, "
+                       "which the query kernels rightly do not compute (0.918 vs 1.049 MFLOP per point): roofline.end_to_end."
+                       "executed_tflops_end_to_end counts the FLOP the MFMA kernels execute",
                        "weights_frozen": frozen is not None,
                        "loss_terms": args.loss if training else None,
                        "parallelism": (f"dp{world} (ONE frame, ray tiles per rank, sampler rounds synchronised by a 2-float MAX "
@@ -503,8 +542,10 @@ def main():
                      "rchain_bg_kernel", "rchain_a2_kernel", "rchain_dbwd_kernel", "rgemm_kernel", "rnarrow_kernel"} if x6 else set()
             labels = {"gemm_nt_kernel": ("gemm_nt_kernel<x6> (one layer per launch, 3-limb split on v_mfma_f32_32x32x16_bf16)"
                                          if x6 else "gemm_nt_kernel (one layer per launch, v_mfma_f32_32x32x2_f32)"),
-                      "trunk_r6_kernel": "rmlp_kernel<STORE> (forward trunk, 8 layers per launch, register-resident, 3-limb split on "
-                                         "v_mfma_f32_32x32x16_bf16)",
+                      "trunk_r6_kernel": ("rmlp_h3_kernel<STORE> (forward trunk, 8 layers per launch, register-resident, two fp16 limbs, "
+                                          "three products on v_mfma_f32_32x32x16_f16)" if "trunk_r6_kernel" in h3_fams else
+                                          "rmlp_kernel<STORE> (forward trunk, 8 layers per launch, register-resident, 3-limb split on "
+                                          "v_mfma_f32_32x32x16_bf16)"),
                       "rgemm_kernel": "rgemm_kernel (rendering-net layers, their input gradients, lin8 features: one 256-wide layer "
                                       "per launch, register-resident, 3-limb split on v_mfma_f32_32x32x16_bf16)",
                       "rnarrow_kernel": "rnarrow_kernel (the N <= 64 layers: d sdf / d embedding, the non-feature columns of the colour "
@@ -522,7 +563,9 @@ def main():
                       "chain_kernel": ("chain_x6_kernel (any sweep not routed to the register-resident kernels: 7-8 trunk layers per launch, "
                                        "LDS-resident, 3-limb split on v_mfma_f32_32x32x16_bf16)" if x6 else
                                        "chain_kernel (7-8 trunk layers per launch, LDS-resident, v_mfma_f32_32x32x2_f32)"),
-                      "fused_sdf_kernel": ("rmlp_kernel<HEAD> (sampler SDF queries: register-resident trunk, 3-limb split on "
+                      "fused_sdf_kernel": ("rmlp_h3_kernel<HEAD> (sampler SDF queries: register-resident trunk, two fp16 limbs, three "
+                                           "products on v_mfma_f32_32x32x16_f16)" if h3 else
+                                           "rmlp_kernel<HEAD> (sampler SDF queries: register-resident trunk, 3-limb split on "
                                            "v_mfma_f32_32x32x16_bf16)"
                                            if x6 else "fused_sdf_pipe_kernel (sampler SDF queries, v_mfma_f32_32x32x2_f32)"),
                       "wgrad_kernel": ("wgrad_r6_kernel + wgrad_lds_kernel<x6> (weight gradients: whole-dW register-resident "
@@ -533,9 +576,11 @@ def main():
             for name, (t_, fl_, n_, by_) in agg.items():
                 tf = fl_ / t_ / 1e12
                 is6 = name in split
-                # split-precision kernels are priced on the pipe they run on: 6 bf16 limb products issued per algorithmic
-                # product, against the dense bf16 MFMA peak; the algorithmic (fp32-equivalent) rate is a named extra
-                issued, peak = (6.0 * tf, BF16_MFMA_PEAK_TFLOPS) if is6 else (tf, FP32_MFMA_PEAK_TFLOPS)
+                nprod = (3.0 if name in h3_fams else 6.0) if is6 else 1.0
+                # split-precision kernels are priced on the pipe they run on: 6 bf16 (f16x3 families: 3 fp16) limb products issued
+                # per algorithmic product, against the dense bf16 / fp16 MFMA peak; the algorithmic (fp32-equivalent) rate is a
+                # named extra
+                issued, peak = (nprod * tf, BF16_MFMA_PEAK_TFLOPS) if is6 else (tf, FP32_MFMA_PEAK_TFLOPS)
                 # BOTH floors of the family: matrix pipe = issued FLOP / peak; HBM = bytes / 8 TB/s, with the
                 # measured bytes (PMC FETCH_SIZE / WRITE_SIZE of separate passes, per launch) when the round's profile has this
                 # family and the ALGORITHMIC bytes (operands once, results once) otherwise.  bound = the larger floor.
@@ -543,7 +588,7 @@ def main():
                 alg_b = by_ / n_
                 hbm_b = pmc_b if pmc_b else alg_b
                 t_launch = t_ / n_
-                floor_mfma = (fl_ / n_) * (6.0 if is6 else 1.0) / (peak * 1e12)
+                floor_mfma = (fl_ / n_) * nprod / (peak * 1e12)
                 floor_hbm = hbm_b / (HBM_PEAK_GBPS * 1e9)
                 bound = "hbm" if floor_hbm > floor_mfma else "mfma"
                 hbm_step += hbm_b * n_ / args.steps
@@ -554,14 +599,15 @@ def main():
                              "launches": n_, "avg_launch_ms": t_launch * 1e3, "time_share": t_ / dt,
                              "flop_per_launch_avg": fl_ / n_, "algorithmic_bytes_per_launch_avg": alg_b,
                              "traffic": pmc_b, "traffic_source": pmc_src,
-                             "arithmetic": "f32x6" if is6 else "f32", "fp32_equivalent_tflops": tf}
+                             "arithmetic": ("f16x3" if name in h3_fams else "f32x6") if is6 else "f32",
+                             "limb_products_issued_per_product": nprod, "fp32_equivalent_tflops": tf}
                 if bound == "hbm":
                     ent[name].update(achieved=alg_b / t_launch / 1e9, peak=HBM_PEAK_GBPS, unit="GB/s",
                                      frac=alg_b / t_launch / 1e9 / HBM_PEAK_GBPS)
                 else:
                     ent[name].update(achieved=issued, peak=peak, unit="TFLOP/s", frac=issued / peak)
                 if is6:
-                    ent[name]["note"] = ("mfma_achieved = bf16 MFMA FLOP/s issued (6 limb products per algorithmic fp32 product), "
+                    ent[name]["note"] = (f"mfma_achieved = {'fp16' if name in h3_fams else 'bf16'} MFMA FLOP/s issued ({nprod:.0f} limb products per algorithmic fp32 product), "
                                          "mfma_peak = dense bf16 MFMA; fp32_equivalent_tflops = algorithmic FLOP / time; bound = the "
                                          "larger of the two floors (issued FLOP / MFMA peak, HBM bytes / 8 TB/s); achieved / peak / "
                                          "frac are those of the bound")
@@ -591,8 +637,9 @@ def main():
             if "note" in d:
                 res["roofline"]["note"] = d["note"]
             mf = sum(v[1] for v in agg.values())
-            mf6 = sum((6.0 if k in split else 1.0) * v[1] for k, v in agg.items())
+            mf6 = sum(((3.0 if k in h3_fams else 6.0) if k in split else 1.0) * v[1] for k, v in agg.items())
             res["roofline"]["end_to_end"] = {"mfma_tflops_fp32_equivalent": mf / dt / 1e12,
+                                             "executed_tflops_end_to_end": mf / dt / 1e12,
                                              "mfma_tflops_issued": mf6 / dt / 1e12,
                                              "frac_of_bf16_mfma_peak_issued": (mf6 / dt / 1e12 / BF16_MFMA_PEAK_TFLOPS) if x6 else None,
                                              "frac_of_fp32_mfma_peak": None if x6 else mf / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
@@ -612,7 +659,6 @@ def main():
                 res["config"]["pose_refine"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1 and args.mode == "train" and not args.two_hands:
             res["cpu_baseline"] = cpu_baseline(sc, sd_np, args.cpu_threads, n_frames=args.cpu_frames)
-            res["config"]["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()

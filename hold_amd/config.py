@@ -1,14 +1,14 @@
 """Arithmetic selection for the MFMA kernels of the path.
 
 ``f32``    every matrix product on v_mfma_f32_32x32x2_f32 (true fp32 operands).
-``f32x6``  (default) every MFMA kernel of the path -- the sampler's fused SDF trunk (hold_fused_sdf_x6), the layer
+``f32x6``  every MFMA kernel of the path -- the sampler's fused SDF trunk (hold_fused_sdf_x6), the layer
            chains (hold_chain_x6), the single-layer GEMM (hold_gemm_nt_x6) and the weight gradients (hold_wgrad_x6) --
            splits every fp32 operand EXACTLY into three bf16 limbs and issues six of the nine limb products on
            v_mfma_f32_32x32x16_bf16 with fp32 accumulation (dropped terms <= 2^-23 relative: fp32-class results,
            measured 1.4e-6 max abs against the fp32 MFMA kernel on 524 288 points; the whole parity suite runs green
            in both modes at the same tolerances).
 
-``f16x3``  as ``f32x6``, except that the kernels that exist in the two-limb fp16 arithmetic use it: every fp32 operand, scaled
+``f16x3``  (default) as ``f32x6``, except that the kernels that exist in the two-limb fp16 arithmetic use it: every fp32 operand, scaled
            by an exact power of two, is split into hi = RN_f16(x), lo = RN_f16(x - hi) and THREE of the four limb products
            (hi hi + hi lo + lo hi) are issued on v_mfma_f32_32x32x16_f16 with fp32 accumulation -- half the matrix
            instructions of ``f32x6`` at the same measured error against fp64 (csrc/rmlp_h3.hip: the sampler's SDF query
@@ -23,7 +23,8 @@ from __future__ import annotations
 import os
 
 _MODES = ("f32", "f32x6", "f16x3")
-_precision = os.environ.get("HOLD_PRECISION", "f32x6")
+DEFAULT_PRECISION = "f16x3"
+_precision = os.environ.get("HOLD_PRECISION", DEFAULT_PRECISION)
 if _precision not in _MODES:
     raise ValueError(f"HOLD_PRECISION must be one of {_MODES}, got {_precision!r}")
 

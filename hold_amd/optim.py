@@ -139,27 +139,58 @@ class FlatAdam:
         return out
 
     def load_named_state(self, state):
-        """inverse of named_state(); every bucket parameter must be present, all with the same step count"""
+        """inverse of named_state().  Validated BEFORE anything is written (a failed load leaves the optimiser untouched):
+        every entry that is present must have the parameter's shape and all present entries the same step count; a bucket
+        parameter WITHOUT an entry (torch.optim.Adam creates a parameter's state at its first gradient) gets zero moments
+        under that common step -- what FlatAdam's own semantics give a parameter that never received a gradient."""
         names = {id(p): n for n, p in self.net.named_parameters()}
-        steps = set()
+        steps, todo = set(), []
         for p, off in zip(self.params, self.offsets):
-            st = state[names[id(p)]]
-            k = p.numel()
-            self.m[off:off + k].copy_(st["exp_avg"].reshape(-1).to(self.m.device))
-            self.v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1).to(self.v.device))
+            st = state.get(names[id(p)])
+            if st is None or not st:
+                todo.append((off, p.numel(), None, None))
+                continue
+            for key in ("step", "exp_avg", "exp_avg_sq"):
+                if key not in st:
+                    raise KeyError(f"FlatAdam.load_named_state: {names[id(p)]} has no {key!r}")
+            if tuple(st["exp_avg"].shape) != tuple(p.shape) or tuple(st["exp_avg_sq"].shape) != tuple(p.shape):
+                raise ValueError(f"FlatAdam.load_named_state: state of {names[id(p)]} has shape {tuple(st['exp_avg'].shape)}, "
+                                 f"the parameter {tuple(p.shape)}")
             steps.add(int(st["step"]))
-        if len(steps) != 1:
+            todo.append((off, p.numel(), st["exp_avg"], st["exp_avg_sq"]))
+        if len(steps) > 1:
             raise ValueError(f"FlatAdam keeps ONE step count for all parameters; the given state has {sorted(steps)}")
-        self.step_count = steps.pop()
+        for off, k, m, v in todo:
+            if m is None:
+                self.m[off:off + k].zero_()
+                self.v[off:off + k].zero_()
+            else:
+                self.m[off:off + k].copy_(m.reshape(-1).to(self.m.device))
+                self.v[off:off + k].copy_(v.reshape(-1).to(self.v.device))
+        self.step_count = steps.pop() if steps else 0
+
+    def reference_groups(self):
+        """the parameter groups of `HOLD.configure_optimizers` (code/src/hold/hold.py:79-101): ONE group per node with ALL of
+        node.params.parameters() at 0.1 lr -- frozen and zero-sized parameters included, as the reference includes them --
+        then one group with every remaining parameter of the model at lr.  Group COUNT and group SIZES are therefore those
+        of a reference checkpoint's `optimizer_states[0]["param_groups"]`.  Order inside a node group: module order here; the
+        reference builds it from a python `set`, so the index -> parameter assignment inside a node group of a reference
+        checkpoint is whatever that process's hashes gave (see load_reference_state)."""
+        groups, node_ids = [], set()
+        for node in self.net.nodes.values():
+            ps = list(node.params.parameters())
+            node_ids.update(id(p) for p in ps)
+            groups.append({"params": ps, "lr": self.lr * self.pose_lr_scale})
+        main = [p for p in self.net.parameters() if id(p) not in node_ids]
+        if main:
+            groups.append({"params": main, "lr": self.lr})
+        return groups
 
     def torch_optimizer(self):
-        """a torch.optim.Adam over this model's parameters with the reference's groups (pose tables at 0.1 lr, everything
-        else at lr) carrying this optimiser's state: what `HOLD.configure_optimizers` would hold at this point"""
-        low = self.params[:sum(1 for o in self.offsets if o < self.n_low)]
-        main = self.params[len(low):]
-        groups = ([{"params": low, "lr": self.lr * self.pose_lr_scale}] if low else []) + \
-                 ([{"params": main, "lr": self.lr}] if main else [])
-        opt = torch.optim.Adam(groups, lr=self.lr, betas=tuple(self.betas), eps=self.eps)
+        """a torch.optim.Adam with the reference's group structure (reference_groups) carrying this optimiser's state: what
+        `HOLD.configure_optimizers` would hold at this point.  Parameters outside the bucket (frozen, zero-sized) are in
+        their groups without state, as in the reference before their first gradient."""
+        opt = torch.optim.Adam(self.reference_groups(), lr=self.lr, betas=tuple(self.betas), eps=self.eps)
         self.export_to(opt)
         return opt
 
@@ -172,9 +203,51 @@ class FlatAdam:
                             "exp_avg_sq": self.v[off:off + k].view(p.shape).clone()}
 
     def import_from(self, opt):
-        """read them back from a torch optimiser (e.g. after `opt.load_state_dict(reference_checkpoint)`)"""
+        """read them back from a torch optimiser over this model's parameter objects (parameters torch holds no state for
+        yet get zero moments)"""
         names = {id(p): n for n, p in self.net.named_parameters()}
-        self.load_named_state({names[id(p)]: opt.state[p] for p in self.params})
+        self.load_named_state({names[id(p)]: opt.state[p] for p in self.params if p in opt.state and opt.state[p]})
+
+    def load_reference_state(self, opt_state_dict):
+        """Adam state of a REFERENCE checkpoint (`ckpt["optimizer_states"][0]`: {"state": {index: {...}}, "param_groups":
+        [{"params": [indices], ...}, ...]}) -> this optimiser.  The group structure must be the reference's (one group per
+        node, then the main group: reference_groups()); the main group's order is `model.parameters()` order, the same
+        here, so its entries map by position.  Inside a NODE group the reference's order comes from a python set: entries
+        are matched to that node's parameters by SHAPE, and where two parameters of a node share a shape (MANO's
+        global_orient / transl tables) and carry different state the assignment is ambiguous and this raises -- pass
+        `torch.optim.Adam.load_state_dict` + import_from instead if the order is known."""
+        groups = self.reference_groups()
+        pg = opt_state_dict["param_groups"]
+        if len(pg) != len(groups) or any(len(a["params"]) != len(b["params"]) for a, b in zip(pg, groups)):
+            raise ValueError("FlatAdam.load_reference_state: group structure differs: checkpoint "
+                             f"{[len(a['params']) for a in pg]}, model {[len(b['params']) for b in groups]}")
+        names = {id(p): n for n, p in self.net.named_parameters()}
+        state, named = opt_state_dict["state"], {}
+        n_nodes = len(self.net.nodes)
+        for gi, (a, b) in enumerate(zip(pg, groups)):
+            if gi >= n_nodes:  # main group: positional
+                for idx, p in zip(a["params"], b["params"]):
+                    if idx in state and state[idx]:
+                        named[names[id(p)]] = state[idx]
+                continue
+            entries = [state[idx] for idx in a["params"] if idx in state and state[idx]]
+            by_shape = {}
+            for p in b["params"]:
+                by_shape.setdefault(tuple(p.shape), []).append(p)
+            for shape, ps in by_shape.items():
+                cand = [e for e in entries if tuple(e["exp_avg"].shape) == shape]
+                if not cand:
+                    continue
+                if len(ps) == 1 and len(cand) == 1:
+                    named[names[id(ps[0])]] = cand[0]
+                elif all(torch.equal(c["exp_avg"], cand[0]["exp_avg"]) and torch.equal(c["exp_avg_sq"], cand[0]["exp_avg_sq"])
+                         for c in cand) and len(cand) == len(ps):
+                    for p_, c in zip(ps, cand):
+                        named[names[id(p_)]] = c
+                else:
+                    raise ValueError(f"FlatAdam.load_reference_state: {len(ps)} parameters of node group {gi} share the shape "
+                                     f"{shape}; the reference orders a node group by a python set, the assignment is ambiguous")
+        self.load_named_state(named)
 
     def state_dict(self):
         """optimiser state for checkpoint / resume (the reference's Lightning checkpoints carry Adam's moments and step

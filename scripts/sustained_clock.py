@@ -25,15 +25,24 @@ def _read(p):
 
 
 def find_device_files():
-    """sysfs directory of the (one) AMD GPU of the box and its hwmon directory"""
-    out = {}
+    """sysfs directory + hwmon directory of THE GPU torch sees as cuda:0 -- the box's /sys lists every card of the host (GPU
+    call 1 read card0: another, idle, device), so the card is matched by the PCI address of the torch device"""
+    pr = torch.cuda.get_device_properties(0)
+    want = None
+    try:
+        want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+    except AttributeError:
+        pass
+    out = {"pci": want}
     for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
         if _read(os.path.join(card, "vendor")) != "0x1002":
             continue
+        real = os.path.realpath(card)
+        if want and want not in real:
+            continue
         hw = sorted(glob.glob(os.path.join(card, "hwmon", "hwmon*")))
-        out = dict(card=card, hwmon=hw[0] if hw else None)
-        if _read(os.path.join(card, "pp_dpm_sclk")) is not None:
-            break
+        out.update(card=card, real=real, hwmon=hw[0] if hw else None)
+        break
     return out
 
 
@@ -110,17 +119,27 @@ def run_loop(name, fn, flops, issued_per_alg):
     time.sleep(0.3)
     idle_n = len(smp.rows)
     e0.record()
-    t_smi, res = None, {}
+    res = {"smi": [], "stop": False}
+
+    def poll_smi():  # rocm-smi sees the right device (ROCR_VISIBLE_DEVICES); one reading takes a few hundred ms
+        time.sleep(SECONDS * 0.25)
+        while not res["stop"]:
+            r = smi()
+            r["t"] = time.time()
+            res["smi"].append(r)
+            time.sleep(0.2)
+
+    t_smi = threading.Thread(target=poll_smi, daemon=True)
+    t_smi.start()
     for i in range(n):
         fn()
-        if i == n // 2 and t_smi is None:
-            t_smi = threading.Thread(target=lambda: res.__setitem__("smi", smi()), daemon=True)
-            t_smi.start()
+        if i % 64 == 63:
+            torch.cuda.current_stream().synchronize()  # keep the host within 64 launches of the device: the loop's wall time = device time
     e1.record(); torch.cuda.synchronize()
+    res["stop"] = True
     ms = e0.elapsed_time(e1) / n
     smp.stop = True; smp.join()
-    if t_smi is not None:
-        t_smi.join(timeout=25)
+    t_smi.join(timeout=25)
     # samples of the steady state: skip the first 25 % of the loop (ramp) and what was read before / after it
     rows = smp.rows[idle_n:]
     rows = rows[len(rows) // 4:]
@@ -128,14 +147,26 @@ def run_loop(name, fn, flops, issued_per_alg):
                sclk_mhz_hwmon=stats(rows, "sclk_hz", 1e-6), sclk_mhz_dpm=stats(rows, "pp_dpm_sclk"), mclk_mhz_dpm=stats(rows, "pp_dpm_mclk"),
                mclk_mhz_hwmon=stats(rows, "mclk_hz", 1e-6),
                power_w=stats(rows, "power_uw", 1e-6) or stats(rows, "power_in_uw", 1e-6), tj_c=stats(rows, "tj_mc", 1e-3),
-               busy=stats(rows, "busy"), idle_before=smp.rows[:idle_n][-1] if idle_n else None, rocm_smi=res.get("smi") if t_smi else None)
-    clk = (out["sclk_mhz_hwmon"] or out["sclk_mhz_dpm"] or {}).get("median")
+               busy=stats(rows, "busy"), idle_before=smp.rows[:idle_n][-1] if idle_n else None, rocm_smi=res["smi"])
+    # rocm-smi readings taken INSIDE the loop (after its first quarter)
+    sm = []
+    for r in res["smi"]:
+        try:
+            o = next(iter(json.loads(r["out"]).values()))
+            sm.append({"sclk_smi": float(o["sclk clock speed:"].strip("()").lower().replace("mhz", "")),
+                       "power_smi": float(o["Current Socket Graphics Package Power (W)"]),
+                       "tj_smi": float(o["Temperature (Sensor junction) (C)"])})
+        except Exception:  # noqa
+            pass
+    out["rocm_smi_sclk_mhz"], out["rocm_smi_power_w"], out["rocm_smi_tj_c"] = stats(sm, "sclk_smi"), stats(sm, "power_smi"), stats(sm, "tj_smi")
+    clk = (out["rocm_smi_sclk_mhz"] or out["sclk_mhz_hwmon"] or out["sclk_mhz_dpm"] or {}).get("median")
     if clk:
         # MFMA peak at the measured clock: 256 CUs x 4 SIMDs x 1024 FLOP per cycle (32x32x16 in 8 passes of 4 cycles) -- bf16 / f16 dense
         out["mfma_peak_tflops_at_sustained_clock"] = 256 * 4 * 1024 * clk * 1e6 / 1e12
         out["mfma_frac_at_sustained_clock"] = out["issued_tflops"] / out["mfma_peak_tflops_at_sustained_clock"]
         out["mfma_frac_at_2p4_ghz_headline"] = out["issued_tflops"] / 2500.0
-    print(json.dumps({k: v for k, v in out.items() if k not in ("rocm_smi", "idle_before")}), flush=True)
+    print(json.dumps({k: (v if not isinstance(v, dict) or "median" not in v else {"median": v["median"], "min": v["min"], "max": v["max"], "n": v["n"]})
+                      for k, v in out.items() if k not in ("rocm_smi", "idle_before")}), flush=True)
     return out
 
 

@@ -10,7 +10,7 @@ def _dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=["f32x6", "f32"])
+@pytest.fixture(params=["f16x3", "f32x6", "f32"])
 def arith(request):
     """run a test under both arithmetics: hold_gemm_nt_x6 / hold_gemm_nt (same tolerances)"""
     import hold_amd

@@ -18,14 +18,15 @@ def test_library_exports_every_declared_symbol():
     dev_only = set(re.findall(r"\b(?:int|int64_t)\s+(hold_[a-z0-9_]+)\s*\(", "".join(re.findall(r"#ifdef HOLD_DEV.*?#endif", hdr, re.S))))
     assert dev_only == set(_lib.DEV_SIGNATURES)  # diagnostics: developer build only, absent from the product library
     hdr = re.sub(r"#ifdef HOLD_DEV.*?#endif", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(?:int|int64_t)\s+(hold_[a-z0-9_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(?:int|int64_t|float)\s+(hold_[a-z0-9_]+)\s*\(", hdr))
     assert len(declared) >= 27
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
     assert declared - {"hold_abi_version", "hold_wgrad_workspace_floats", "hold_fused_sdf_pack_floats", "hold_chain_pack_floats", "hold_fused_sdf_x6_pack_bytes",
                        "hold_silhouette_workspace_floats", "hold_reduce_workspace_floats", "hold_chain_x6_pack_bytes", "hold_trunk_r6_pack_bytes", "hold_chain_r6_pack_bytes", "hold_gemm_r6_pack_bytes",
-                       "hold_wcolsum_workspace_floats", "hold_head3_workspace_floats", "hold_wgrad_group_workspace_floats"} == set(_lib.SIGNATURES)
+                       "hold_wcolsum_workspace_floats", "hold_head3_workspace_floats", "hold_wgrad_group_workspace_floats", "hold_trunk_h3_pack_bytes",
+                       "hold_trunk_h3_act_scale"} == set(_lib.SIGNATURES)
     assert L.hold_abi_version() == 1
     assert not any(hasattr(L, n) for n in dev_only)
     # the product library reads no environment variables (stateless C ABI): no getenv import in the shared object
@@ -317,6 +318,109 @@ def test_row_split_size_passes_the_kernels_32_bit_offset_check():
     assert K._TRUNK_MAX_ROWS == K._max_rows(256) == K._CHAIN_MAX_ROWS
 
 
+def test_flat_adam_loads_an_optimizer_state_shaped_like_the_reference_checkpoint():
+    """round-4 advisor (medium): `HOLD.configure_optimizers` (code/src/hold/hold.py:79-101) builds ONE 0.1 lr group PER NODE
+    from ALL of node.params.parameters() -- frozen and zero-sized parameters included -- and a main group with every other
+    parameter.  A state dict with exactly that structure, produced by a plain torch.optim.Adam built the reference's way over
+    a model with a frozen table and a zero-sized weight, must (a) load into FlatAdam.torch_optimizer() through torch's own
+    load_state_dict (group count and sizes agree), (b) come back through import_from, and (c) load directly through
+    load_reference_state, which maps node groups by shape and refuses an ambiguous assignment; a failed load leaves the
+    optimiser untouched (advisor, low)."""
+    import torch
+    from torch import nn
+    from hold_amd.optim import FlatAdam
+
+    class _Params(nn.Module):
+        def __init__(self, two_same):
+            super().__init__()
+            self.pose = nn.Embedding(4, 6)
+            self.betas = nn.Embedding(1, 10)
+            self.betas.weight.requires_grad_(False)  # frozen, as GenericParams.freeze leaves the shape table
+            self.transl = nn.Embedding(4, 3)
+            if two_same:
+                self.orient = nn.Embedding(4, 3)
+
+    class _Node(nn.Module):
+        def __init__(self, two_same):
+            super().__init__()
+            self.params = _Params(two_same)
+            self.net = nn.Linear(5, 3)
+            self.empty = nn.Linear(0, 8, bias=False)  # the object's lin_pose.weight is [8, 0]
+
+    class _Net(nn.Module):
+        def __init__(self, two_same=False):
+            super().__init__()
+            self.nodes = nn.ModuleDict({"right": _Node(two_same), "object": _Node(False)})
+            self.bg = nn.Linear(7, 2)
+
+    def reference_adam(model, lr):  # the reference's construction, with list() in place of the set for a defined order
+        node_params, groups = set(), []
+        for node in model.nodes.values():
+            ps = list(node.params.parameters())
+            node_params.update(ps)
+            groups.append({"params": ps, "lr": lr * 0.1})
+        groups.append({"params": [p for p in model.parameters() if p not in node_params], "lr": lr})
+        return torch.optim.Adam(groups, lr=lr, eps=1e-8)
+
+    torch.manual_seed(0)
+    net = _Net()
+    ref = reference_adam(net, 5e-4)
+    for p in net.parameters():
+        if p.requires_grad and p.numel():
+            p.grad = torch.randn_like(p)
+    for _ in range(3):
+        ref.step()
+    sd = ref.state_dict()
+    assert [len(g["params"]) for g in sd["param_groups"]] == [3, 3, 8]  # 3 tables per node; 2 x (W, b, empty W) + bg W, b
+    opt = FlatAdam(net, lr=5e-4)
+    t = opt.torch_optimizer()
+    assert [len(g["params"]) for g in t.param_groups] == [3, 3, 8]
+    t.load_state_dict(sd)  # (a): round 4 raised here on group count and sizes
+    opt.import_from(t)     # (b)
+    assert opt.step_count == 3
+    for p, off in zip(opt.params, opt.offsets):
+        assert torch.equal(opt.m[off:off + p.numel()].view(p.shape), ref.state[p]["exp_avg"])
+        assert torch.equal(opt.v[off:off + p.numel()].view(p.shape), ref.state[p]["exp_avg_sq"])
+    m0, v0 = opt.m.clone(), opt.v.clone()
+    opt.m.zero_(); opt.v.zero_(); opt.step_count = 0
+    opt.load_reference_state(sd)  # (c)
+    assert opt.step_count == 3 and torch.equal(opt.m, m0) and torch.equal(opt.v, v0)
+    # a state whose entries disagree on the step count is rejected BEFORE anything is written
+    bad = {k: dict(v) for k, v in opt.named_state().items()}
+    first = next(iter(bad))
+    bad[first]["step"] = torch.tensor(9.0)
+    bad[first]["exp_avg"] = bad[first]["exp_avg"] + 1
+    with pytest.raises(ValueError):
+        opt.load_named_state(bad)
+    assert opt.step_count == 3 and torch.equal(opt.m, m0) and torch.equal(opt.v, v0)
+    wrong = {k: dict(v) for k, v in opt.named_state().items()}
+    wrong[first]["exp_avg"] = torch.zeros(2, 2)
+    with pytest.raises(ValueError):
+        opt.load_named_state(wrong)
+    assert torch.equal(opt.m, m0)
+    # a parameter torch holds no state for yet (no gradient so far) gets zero moments under the common step
+    part = opt.named_state()
+    del part[first]
+    opt.load_named_state(part)
+    off0 = opt.offsets[0]
+    assert opt.step_count == 3 and float(opt.m[off0:off0 + opt.params[0].numel()].abs().max()) == 0.0
+    # two tables of one shape in a node group with different state: the reference's set order decides -> ambiguous -> raises
+    net2 = _Net(two_same=True)
+    ref2 = reference_adam(net2, 5e-4)
+    for p in net2.parameters():
+        if p.requires_grad and p.numel():
+            p.grad = torch.randn_like(p)
+    ref2.step()
+    opt2 = FlatAdam(net2, lr=5e-4)
+    with pytest.raises(ValueError, match="ambiguous"):
+        opt2.load_reference_state(ref2.state_dict())
+    t2 = opt2.torch_optimizer()
+    t2.load_state_dict(ref2.state_dict())  # with the order known (same construction) torch's positional load is exact
+    opt2.import_from(t2)
+    for p, off in zip(opt2.params, opt2.offsets):
+        assert torch.equal(opt2.m[off:off + p.numel()].view(p.shape), ref2.state[p]["exp_avg"])
+
+
 def test_flat_adam_state_interchange_with_torch_adam_and_rehome_errors():
     """round-3 advisor: FlatAdam's moments must be exportable to / importable from torch.optim.Adam's per-parameter state
     (what the reference's Lightning checkpoints carry, hold.py:79-101), and rehome() must refuse a parameter that moved to
@@ -344,8 +448,10 @@ def test_flat_adam_state_interchange_with_torch_adam_and_rehome_errors():
     opt.v.copy_(torch.rand(opt.n))
     opt.step_count = 17
     t = opt.torch_optimizer()
-    assert len(t.param_groups) == 2 and t.param_groups[0]["lr"] == 5e-5 and t.param_groups[1]["lr"] == 5e-4
-    assert {id(p) for p in t.param_groups[0]["params"]} == {id(net.nodes[n].params.weight) for n in net.nodes}
+    # the reference's group structure (hold.py:79-101): one 0.1 lr group per node, then the main group
+    assert [g["lr"] for g in t.param_groups] == [5e-5, 5e-5, 5e-4]
+    for g, n in zip(t.param_groups, net.nodes):
+        assert [id(p) for p in g["params"]] == [id(net.nodes[n].params.weight)]
     for p, off in zip(opt.params, opt.offsets):
         st = t.state[p]
         assert float(st["step"]) == 17 and torch.equal(st["exp_avg"].reshape(-1), opt.m[off:off + p.numel()])
