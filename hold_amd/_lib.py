@@ -118,6 +118,8 @@ SIGNATURES = {
     "hold_wgrad_x6": [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _P],
     "hold_gemm_narrow_x6": [_P, _I, _P, _I, _P, _I, _L, _I, _I, _P],
     "hold_wgrad_group_x6": [C.POINTER(WgradItem), _I, _L, _P, _P],
+    "hold_wgrad_group_h3": [C.POINTER(WgradItem), _I, _L, _P, _P],
+    "hold_wgrad_h3": [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _P],
     "hold_ray_points": [_P, _P, _P, _I, _I, _L, _P, _I, _P],
     "hold_embed_fwd": [_P, _I, _I, _I, _P, _L, _P, _I, _P, _I, _P, _I, _L, _P],
     "hold_embed_bwd": [_P, _I, _I, _P, _L, _P, _I, _P, _I, _I, _P],

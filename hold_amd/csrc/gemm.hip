@@ -1086,14 +1086,19 @@ extern "C" int64_t hold_wgrad_workspace_floats(int32_t N, int32_t K, int32_t spl
 // register-resident 256 x 256 variant (csrc/wgrad_r6.hip): fills <= max_splits partial tiles, returns their number
 int hold_wgrad_r6_partials(const float* R, int ldr, const float* X, int ldx, long P, int max_splits, float* part,
                            float* part_b, hipStream_t s);
+int hold_wgrad_h3_partials(const float* R, int ldr, const float* X, int ldx, long P, int n_valid, int max_splits, float* part,
+                           float* part_b, hipStream_t s);
 
 // mode 0: fp32 MFMA; 1 / 2: split precision (3 bf16 limbs x 6 products, fp32 accumulate) with the round-to-nearest /
-// truncating limb split (both decompose the 24-bit significand exactly)
+// truncating limb split (both decompose the 24-bit significand exactly); 3: as 2, with the whole-dW shapes in the two-limb
+// fp16 arithmetic (wgrad_h3_kernel, csrc/wgrad_r6.hip)
 static int wgrad_impl(const float* R, int32_t ldr, const float* X, int32_t ldx, int32_t P, int32_t N, int32_t K,
                       float* dW, int32_t lddw, float* db, int32_t accumulate, int32_t splits, float* workspace,
                       hold_stream_t stream, int mode, int xcols = -1) {
   if (!R || !X || !dW || !workspace || N <= 0 || K <= 0 || P < 0 || splits <= 0) return HOLD_E_ARG;
   if (xcols < 0) xcols = ldx;  // columns of a row of X that exist from the X pointer on
+  const bool h3 = mode == 3;
+  if (h3) mode = 2;  // every shape outside the whole-dW domain: the bf16 three-limb kernels
   hipStream_t s = (hipStream_t)stream;
   const long chunks = ((long)P + 31) / 32;
   if (splits > chunks) splits = (int)(chunks > 0 ? chunks : 1);
@@ -1123,12 +1128,13 @@ static int wgrad_impl(const float* R, int32_t ldr, const float* X, int32_t ldx, 
   long pstride = (long)N * K;  // floats between partial tiles
   int Kred = K;                // columns the reduction below covers
   if (r6) {
-    const int g = hold_wgrad_r6_partials(R, ldr, X, ldx, (long)P, splits, part, db ? part + (long)splits * 65536 : nullptr, s);
+    const int g = h3 ? hold_wgrad_h3_partials(R, ldr, X, ldx, (long)P, N, splits, part, db ? part + (long)splits * 65536 : nullptr, s)
+                     : hold_wgrad_r6_partials(R, ldr, X, ldx, (long)P, splits, part, db ? part + (long)splits * 65536 : nullptr, s);
     if (g < 0) return g;
     if (K > 256) {  // the remaining K - 256 columns of dW: tile kernel on (R, X + 256), its partials behind the first part's
       float* ws2 = part + (long)splits * (65536 + 256);
-      const int rc = wgrad_impl(R, ldr, X + 256, ldx, P, N, K - 256, dW + 256, lddw, nullptr, accumulate, splits, ws2, stream, mode,
-                                ldx - 256);
+      const int rc = wgrad_impl(R, ldr, X + 256, ldx, P, N, K - 256, dW + 256, lddw, nullptr, accumulate, splits, ws2, stream,
+                                h3 ? 3 : mode, ldx - 256);
       if (rc != HOLD_OK) return rc;
     }
     part_b = db ? part + (long)splits * 65536 : nullptr;
@@ -1207,6 +1213,14 @@ extern "C" int hold_wgrad_x6(const float* R, int32_t ldr, const float* X, int32_
   return wgrad_impl(R, ldr, X, ldx, P, N, K, dW, lddw, db, accumulate, splits, workspace, stream, mode);
 }
 
+// hold_wgrad_x6 with the whole-dW shapes (N in 129..256, K in 256..320, P a multiple of 16 >= 4 096) in the two-limb fp16
+// arithmetic: three v_mfma_f32_32x32x16_f16 per product, per-workgroup power-of-two operand scales from a sample of the
+// workgroup's rows (csrc/wgrad_r6.hip: wgrad_h3_body); every other shape exactly as hold_wgrad_x6
+extern "C" int hold_wgrad_h3(const float* R, int32_t ldr, const float* X, int32_t ldx, int32_t P, int32_t N, int32_t K,
+                             float* dW, int32_t lddw, float* db, int32_t accumulate, int32_t splits, float* workspace,
+                             hold_stream_t stream) {
+  return wgrad_impl(R, ldr, X, ldx, P, N, K, dW, lddw, db, accumulate, splits, workspace, stream, 3);
+}
 
 constexpr int HEAD3_BLOCKS = 2048;
 extern "C" int64_t hold_head3_workspace_floats(int32_t K) { return (int64_t)HEAD3_BLOCKS * (3 * (int64_t)K + 4); }

@@ -28,6 +28,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -253,6 +255,241 @@ __device__ __forceinline__ void wgrad_r6_body(const float* R, int ldr, const flo
   }
 }
 
+
+// =====================================================================================================================
+// The same weight gradient in the TWO-LIMB fp16 arithmetic "f16x3" (see csrc/rmlp_h3.hip): both operands, scaled by a power
+// of two, as hi = RN_f16(s x), lo = RN_f16(s x - hi); hi hi + hi lo + lo hi on v_mfma_f32_32x32x16_f16 -- 48 MFMAs per
+// 16-point step instead of 96, a limb split of 5 instructions per two values (v_pk_mul_f32 by the scale, v_cvt_pk_f16_f32,
+// 2 x v_fma_mix_f32, v_cvt_pk_f16_f32) instead of 9 + 2 pins, and the fragment's 8 rows read as 4 ds_read2st64_b32.
+// SCALES.  The operands are activations (O(1)) and loss cotangents (1e-9 .. 1e-3 and anything else): every WORKGROUP picks
+// its own pair of scales from a sample of ITS rows (every rows / 64-th row, all 256 -- for R: the first n_valid -- columns)
+// so that the sampled maximum lands in [2^6, 2^7): 2^9 of headroom below fp16's largest value for rows the sample did
+// not see (an overflow gives +-inf and a NaN gradient: loud, never silently wrong), full 22-23-bit precision for every value
+// within 2^-8 of the sampled maximum and an absolute 2^-31 of it below.  Workgroups need not agree: a partial tile is
+// multiplied by 1 / (s_R s_X) (exact) before it is written, the reduction adds unscaled fp32 tiles as before.
+struct LimbsH { u32x4 l[8][2]; };
+struct FragH { float x[8]; f32x2 xs[4]; uint32_t hi[4]; float ra[4], rb[4]; };
+
+__device__ __forceinline__ uint32_t cvt_pk_h(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+// micro-operation k (0..19) of the split of a fragment: operation k / 4 on value pair k % 4
+__device__ __forceinline__ void split_mop_h(FragH& s, u32x4 (&out)[2], int k, float scale) {
+  const int op = k >> 2, j = k & 3;
+  if (op == 0) {
+    f32x2 v = {s.x[2 * j], s.x[2 * j + 1]};
+    v = v * scale;
+    asm volatile("" : "+v"(v));
+    s.xs[j] = v;
+  } else if (op == 1) {
+    uint32_t h = cvt_pk_h(s.xs[j][0], s.xs[j][1]);
+    pin(h);
+    s.hi[j] = h;
+    out[0][j] = h;
+  } else if (op == 2) {
+    asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(s.ra[j]) : "v"(s.hi[j]), "v"(s.xs[j][0]));
+  } else if (op == 3) {
+    asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(s.rb[j]) : "v"(s.hi[j]), "v"(s.xs[j][1]));
+  } else {
+    uint32_t lo = cvt_pk_h(s.ra[j], s.rb[j]);
+    pin(lo);
+    out[1][j] = lo;
+  }
+}
+// preparation of step t + 1 behind the 48 MFMAs of step t: fragment f's four row-pair reads in the gaps [rsh(f), rsh(f) + 4),
+// its 20 split micro-operations in [wsh(f), wsh(f + 1)) -- two gaps behind its last read
+constexpr int rsh(int f) { return 42 * f / 8; }
+constexpr int wsh(int f) { return f >= 8 ? 48 : 6 + 42 * f / 8; }
+
+// power-of-two scale exponent for an operand whose sampled maximum is am: 2^k am in [2^6, 2^7); |k| <= 60
+__device__ __forceinline__ int scale_exp(float am) {
+  const int e = (int)((fbits(am) >> 23) & 0xffu);
+  int k = 133 - e;
+  k = k > 60 ? 60 : (k < -60 ? -60 : k);
+  return am > 0.f ? k : 0;
+}
+
+template <bool BIAS>
+__device__ __forceinline__ void wgrad_h3_body(const float* R, int ldr, const float* X, int ldx, int n_valid, long s0, long s1,
+                                              float* out, float* out_b) {
+  constexpr int DIST = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, li = lane & 31;
+  const int wn = wave >> 1, wk = wave & 1;
+
+  const float* M = (wave >> 1) ? X : R;
+  const long ldm = (wave >> 1) ? ldx : ldr;
+  const uint32_t dvoff = (uint32_t)((lane ^ (8 * (wave & 1))) * 16);
+  const long rowb = ldm * 4;
+  const char* mrow0 = reinterpret_cast<const char*>(M) + (wave & 1) * 8 * rowb;
+  const uint32_t dst0 = (uint32_t)((wave >> 1) * 16384 + (wave & 1) * 8 * 1024);
+  auto step_src = [&](long u) { return mrow0 + (u < s1 ? u : s1 - 1) * 16 * rowb; };
+  const uint32_t rdA = (uint32_t)((8 * hh) * 1024 + ((128 * wn + li) ^ (32 * hh)) * 4);
+  const uint32_t rdB = (uint32_t)(16384 + (8 * hh) * 1024 + ((128 * wk + li) ^ (32 * hh)) * 4);
+  auto frag_addr = [&](int f, uint32_t slot_base) {
+    return smem + slot_base + ((f < 4 ? rdA : rdB) ^ (uint32_t)((f & 3) << 7));
+  };
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum[2] = {0.f, 0.f};
+  float inv = 1.0f;
+
+  if (s0 < s1) {
+    // ---- this workgroup's scales: a sample of its rows (4 rows per pass: a row = 64 threads x 16 bytes) ----
+    float sR, sX;
+    {
+      const long r0 = s0 * 16, nrows = (s1 - s0) * 16;
+      long stride = nrows / 64;
+      stride = stride < 4 ? 4 : stride & ~3L;  // passes of four consecutive rows, `stride` rows apart
+      const int c4 = (tid & 63) * 4, sub = tid >> 6;
+      float amR = 0.f, amX = 0.f;
+      for (long r = 0; r + 4 <= nrows; r += stride) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(R + (r0 + r + sub) * (long)ldr + c4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(X + (r0 + r + sub) * (long)ldx + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (c4 + e < n_valid) amR = fmaxf(amR, fabsf(a[e]));  // columns >= n_valid of R are not the caller's data
+          amX = fmaxf(amX, fabsf(b[e]));
+        }
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        amR = fmaxf(amR, __shfl_xor(amR, o));
+        amX = fmaxf(amX, __shfl_xor(amX, o));
+      }
+      float* red = reinterpret_cast<float*>(smem);
+      if (lane == 0) { red[wave] = amR; red[4 + wave] = amX; }
+      __syncthreads();
+      amR = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+      amX = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+      __syncthreads();  // the ring's first slot is about to be overwritten by the LDS-DMA
+      const int kR = __builtin_amdgcn_readfirstlane(scale_exp(amR)), kX = __builtin_amdgcn_readfirstlane(scale_exp(amX));
+      sR = bitsf((uint32_t)(127 + kR) << 23);
+      sX = bitsf((uint32_t)(127 + kX) << 23);
+      inv = bitsf((uint32_t)(127 - kR - kX) << 23);
+    }
+#pragma unroll
+    for (int u = 0; u < DIST; ++u) {
+      const char* p = step_src(s0 + u);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dma_piece(p + i * rowb, dvoff, (uint32_t)((int)((s0 + u) % NST) * STAGE) + dst0 + i * 1024);
+    }
+    const char* dptr = step_src(s0 + DIST);
+    WG_WAIT_VM(8 * (DIST - 1));
+    __builtin_amdgcn_s_barrier();
+
+    LimbsH L0, L1;
+    FragH fs[2];
+    bool sel[2] = {wk == 0, wk == 1};
+    auto bias_add = [&](int f, const FragH& s) {
+      if (BIAS && f < 4) {
+        const f32x2 p0 = {s.x[0], s.x[1]}, p1 = {s.x[2], s.x[3]}, p2 = {s.x[4], s.x[5]}, p3 = {s.x[6], s.x[7]};
+        const f32x2 q = (p0 + p1) + (p2 + p3);
+        const float add = sel[f >> 1] ? q[0] + q[1] : 0.f;
+        bsum[f & 1] += add;
+      }
+    };
+    {  // limbs of the first step (not overlapped)
+      const uint32_t sb = (uint32_t)((int)(s0 % NST) * STAGE);
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        const char* p = frag_addr(f, sb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fs[0].x[e] = *reinterpret_cast<const float*>(p + e * 1024);
+        bias_add(f, fs[0]);
+#pragma unroll
+        for (int k = 0; k < 20; ++k) split_mop_h(fs[0], L0.l[f], k, f < 4 ? sR : sX);
+      }
+    }
+
+    auto step = [&](long t, LimbsH& C, LimbsH& N) {
+      WG_WAIT_VM(8 * (DIST - 2));
+      __builtin_amdgcn_s_barrier();
+      const uint32_t sb = (uint32_t)((int)((t + 1) % NST) * STAGE);
+      const uint32_t db = (uint32_t)((int)((t + DIST) % NST) * STAGE) + dst0;
+      const char* p = dptr;
+      dptr = (t + DIST + 1 < s1) ? dptr + 16 * rowb : dptr;
+      if (BIAS && t + 1 >= s1) sel[0] = sel[1] = false;
+#pragma unroll
+      for (int m = 0; m < 48; ++m) {
+        const int aa = m / 12, pr = (m % 12) / 4, bb = m % 4;  // four accumulators in rotation; (R limb, X limb): hh, hl, lh
+        const int il = pr == 2 ? 1 : 0, jl = pr == 1 ? 1 : 0;
+        acc[aa][bb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, C.l[aa][il]),
+                                                             __builtin_bit_cast(f16x8, C.l[4 + bb][jl]), acc[aa][bb], 0, 0, 0);
+        if (m % 6 == 2) {
+          dma_piece(p, dvoff, db + (m / 6) * 1024);
+          p += rowb;
+        }
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+          if (m >= rsh(f) && m < rsh(f) + 4) {  // two rows per gap: adjacent loads 1 KiB apart = one ds_read2st64_b32
+            const int e = 2 * (m - rsh(f));
+            const char* q = frag_addr(f, sb);
+            fs[f & 1].x[e] = *reinterpret_cast<const float*>(q + e * 1024);
+            fs[f & 1].x[e + 1] = *reinterpret_cast<const float*>(q + (e + 1) * 1024);
+          }
+          const int w0 = wsh(f), w1 = wsh(f + 1), len = w1 - w0;
+          if (m >= w0 && m < w1) {
+            if (m == w0) bias_add(f, fs[f & 1]);
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+              const int k = 20 * (m - w0) / len + u;
+              if (k < 20 * (m - w0 + 1) / len) split_mop_h(fs[f & 1], N.l[f], k, f < 4 ? sR : sX);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+
+    for (long t = s0; t < s1; t += 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) asm volatile("" : "+a"(acc[i][j][r]));
+      step(t, L0, L1);
+      if (t + 1 < s1) step(t + 1, L1, L0);
+    }
+    WG_WAIT_VM(0);
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = 128 * wn + 32 * i + 8 * (r >> 2) + 4 * hh + (r & 3);
+        out[n * 256 + 128 * wk + 32 * j + li] = acc[i][j][r] * inv;
+      }
+  if (BIAS) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float s = bsum[q] + __shfl_xor(bsum[q], 32);
+      if (hh == 0) out_b[128 * wn + 32 * (2 * wk + q) + li] = s;
+    }
+  }
+}
+
+template <bool BIAS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wgrad_h3_kernel(WArgs a, int n_valid) {
+  const long s0 = (long)blockIdx.x * a.spw;
+  const long s1 = s0 + a.spw < a.nsteps ? s0 + a.spw : a.nsteps;
+  wgrad_h3_body<BIAS>(a.R, a.ldr, a.X, a.ldx, n_valid, s0, s1, a.part + (long)blockIdx.x * 65536,
+                      BIAS ? a.part_b + (long)blockIdx.x * 256 : nullptr);
+}
+
 template <bool BIAS, int ABL = 0, int DIST = 3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wgrad_r6_kernel(WArgs a) {
   const long s0 = (long)blockIdx.x * a.spw;
@@ -267,7 +504,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // launches write n x 64 MiB -- at 125k points (the two-hand configuration's chunks) the partial tiles of a single launch
 // are half the operand bytes -- and one reduction pass replaces 2 n.
 constexpr int WG_MAX_ITEMS = 24;
-struct WPair { const float* R; const float* X; int ldr; int ldx; };
+struct WPair { const float* R; const float* X; int ldr; int ldx; int n; };
 struct WGroupArgs {
   WPair it[WG_MAX_ITEMS];
   long nsteps;
@@ -276,18 +513,22 @@ struct WGroupArgs {
   float* part_b;  // [n x gper][256]
 };
 
+template <bool H3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wgrad_r6_group_kernel(WGroupArgs a) {
   const int item = blockIdx.x / a.gper, share = blockIdx.x % a.gper;
   // a select chain, not a[item]: a dynamic index into the by-value argument would send the table through scratch
   const float* R = a.it[0].R;
   const float* X = a.it[0].X;
-  int ldr = a.it[0].ldr, ldx = a.it[0].ldx;
+  int ldr = a.it[0].ldr, ldx = a.it[0].ldx, nv = a.it[0].n;
 #pragma unroll
   for (int i = 1; i < WG_MAX_ITEMS; ++i)
-    if (item == i) { R = a.it[i].R; X = a.it[i].X; ldr = a.it[i].ldr; ldx = a.it[i].ldx; }
+    if (item == i) { R = a.it[i].R; X = a.it[i].X; ldr = a.it[i].ldr; ldx = a.it[i].ldx; nv = a.it[i].n; }
   const long s0 = (long)share * a.spw;
   const long s1 = s0 + a.spw < a.nsteps ? s0 + a.spw : a.nsteps;
-  wgrad_r6_body<true>(R, ldr, X, ldx, s0, s1, a.part + (long)blockIdx.x * 65536, a.part_b + (long)blockIdx.x * 256);
+  if (H3)
+    wgrad_h3_body<true>(R, ldr, X, ldx, nv, s0, s1, a.part + (long)blockIdx.x * 65536, a.part_b + (long)blockIdx.x * 256);
+  else
+    wgrad_r6_body<true>(R, ldr, X, ldx, s0, s1, a.part + (long)blockIdx.x * 65536, a.part_b + (long)blockIdx.x * 256);
 }
 
 // destination d of the group = the pairs [first, first + count) (consecutive in the list): dW[:N][:256] (+)= the sum of
@@ -351,7 +592,13 @@ static int wgrad_r6_setup() {
             hipSuccess ||
         hipFuncSetAttribute((const void*)wgrad_r6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
             hipSuccess ||
-        hipFuncSetAttribute((const void*)wgrad_r6_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+        hipFuncSetAttribute((const void*)wgrad_r6_group_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+            hipSuccess ||
+        hipFuncSetAttribute((const void*)wgrad_r6_group_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+            hipSuccess ||
+        hipFuncSetAttribute((const void*)wgrad_h3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+            hipSuccess ||
+        hipFuncSetAttribute((const void*)wgrad_h3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
             hipSuccess)
       return 0;
     attr_set = true;
@@ -392,13 +639,32 @@ int hold_wgrad_r6_partials(const float* R, int ldr, const float* X, int ldx, lon
   return hipGetLastError() == hipSuccess ? (int)G : HOLD_E_LAUNCH;
 }
 
+// the f16x3 twin of hold_wgrad_r6_partials; n_valid = the columns of R that are the caller's data (the scale sample reads
+// only those)
+int hold_wgrad_h3_partials(const float* R, int ldr, const float* X, int ldx, long P, int n_valid, int max_splits, float* part,
+                           float* part_b, hipStream_t s) {
+  const int n_cu = wgrad_r6_setup();
+  if (n_cu <= 0) return HOLD_E_LAUNCH;
+  WArgs a;
+  a.R = R; a.ldr = ldr; a.X = X; a.ldx = ldx; a.nsteps = P / 16; a.part = part; a.part_b = part_b;
+  long G = n_cu < max_splits ? n_cu : max_splits;
+  if (G > a.nsteps) G = a.nsteps;
+  a.spw = (int)((a.nsteps + G - 1) / G);
+  G = (a.nsteps + a.spw - 1) / a.spw;
+  if (part_b)
+    hipLaunchKernelGGL((wgrad_h3_kernel<true>), dim3((unsigned)G), dim3(256), LDS_BYTES, s, a, n_valid);
+  else
+    hipLaunchKernelGGL((wgrad_h3_kernel<false>), dim3((unsigned)G), dim3(256), LDS_BYTES, s, a, n_valid);
+  return hipGetLastError() == hipSuccess ? (int)G : HOLD_E_LAUNCH;
+}
+
 extern "C" int64_t hold_wgrad_group_workspace_floats(void) {
   const int n_cu = wgrad_r6_setup();
   return n_cu > 0 ? (int64_t)(n_cu > WG_MAX_ITEMS ? n_cu : WG_MAX_ITEMS) * (65536 + 256) : -1;
 }
 
-extern "C" int hold_wgrad_group_x6(const hold_wgrad_item* items, int32_t n_items, int64_t P, float* workspace,
-                                   hold_stream_t stream) {
+static int wgrad_group_impl(const hold_wgrad_item* items, int32_t n_items, int64_t P, float* workspace, hold_stream_t stream,
+                            bool h3) {
   if (!items || n_items <= 0 || n_items > WG_MAX_ITEMS || !workspace || P < 16 || (P % 16)) return HOLD_E_ARG;
   const int n_cu = wgrad_r6_setup();
   if (n_cu <= 0) return HOLD_E_LAUNCH;
@@ -411,7 +677,7 @@ extern "C" int hold_wgrad_group_x6(const hold_wgrad_item* items, int32_t n_items
         (it.ldr & 3) || (it.ldx & 3) || (it.lddw & 3) || ((uintptr_t)it.R & 15) || ((uintptr_t)it.X & 15) ||
         ((uintptr_t)it.dW & 15))
       return HOLD_E_ARG;
-    a.it[i] = WPair{it.R, it.X, it.ldr, it.ldx};
+    a.it[i] = WPair{it.R, it.X, it.ldr, it.ldx, it.N};
     if (nd > 0 && r.d[nd - 1].dW == it.dW) {  // same destination as the previous pair: one reduction over both
       WDst& d = r.d[nd - 1];
       if (d.N != it.N || d.lddw != it.lddw || (it.db && d.db && it.db != d.db)) return HOLD_E_ARG;
@@ -435,7 +701,21 @@ extern "C" int hold_wgrad_group_x6(const hold_wgrad_item* items, int32_t n_items
   a.part_b = workspace + (long)n_items * gper * 65536;
   r.gper = a.gper; r.part = a.part; r.part_b = a.part_b;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(wgrad_r6_group_kernel, dim3((unsigned)(n_items * gper)), dim3(256), LDS_BYTES, s, a);
+  if (h3)
+    hipLaunchKernelGGL(wgrad_r6_group_kernel<true>, dim3((unsigned)(n_items * gper)), dim3(256), LDS_BYTES, s, a);
+  else
+    hipLaunchKernelGGL(wgrad_r6_group_kernel<false>, dim3((unsigned)(n_items * gper)), dim3(256), LDS_BYTES, s, a);
   hipLaunchKernelGGL(wgrad_group_reduce_kernel, dim3(1025, nd), dim3(256), 0, s, r);
   return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+}
+
+extern "C" int hold_wgrad_group_x6(const hold_wgrad_item* items, int32_t n_items, int64_t P, float* workspace,
+                                   hold_stream_t stream) {
+  return wgrad_group_impl(items, n_items, P, workspace, stream, false);
+}
+
+// the same grouped launch in the two-limb fp16 arithmetic (wgrad_h3_body: per-workgroup operand scales)
+extern "C" int hold_wgrad_group_h3(const hold_wgrad_item* items, int32_t n_items, int64_t P, float* workspace,
+                                   hold_stream_t stream) {
+  return wgrad_group_impl(items, n_items, P, workspace, stream, true);
 }

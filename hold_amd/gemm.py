@@ -123,7 +123,7 @@ def wgrad(R, X, dW, db=None, *, N=None, K=None, accumulate=False, splits=None):
     L = _lib.lib()
     ws = _workspace(L.hold_wgrad_workspace_floats(N, K, splits), R.device)
     e0 = _prof_begin()
-    fn = L.hold_wgrad_x6 if config.x6() else L.hold_wgrad
+    fn = (L.hold_wgrad_h3 if (config.h3() and USE_H3_WGRAD) else L.hold_wgrad_x6) if config.x6() else L.hold_wgrad
     check(fn(ptr(R), _ld(R), ptr(X), _ld(X), P, N, K, ptr(dW), _ld(dW), ptr(db), 1 if accumulate else 0,
              splits, ptr(ws), stream_ptr()), "hold_wgrad")
     _prof_end(e0, 2.0 * P * N * K, "wgrad_kernel", 4.0 * P * (N + K))
@@ -131,6 +131,7 @@ def wgrad(R, X, dW, db=None, *, N=None, K=None, accumulate=False, splits=None):
 
 
 USE_NARROW = os.environ.get("HOLD_NARROW", "1") != "0"
+USE_H3_WGRAD = os.environ.get("HOLD_H3_WGRAD", "1") != "0"  # mode f16x3: the whole-dW weight gradients too (A/B switch)
 
 
 def gemm_narrow(A, W, C, *, N=None, accumulate=False):
@@ -205,7 +206,8 @@ class WgradGroup:
         L = _lib.lib()
         ws = _workspace(L.hold_wgrad_group_workspace_floats(), items[0][0].device)
         e0 = _prof_begin()
-        check(L.hold_wgrad_group_x6(arr, len(items), P, ptr(ws), stream_ptr()), "hold_wgrad_group_x6")
+        fn = L.hold_wgrad_group_h3 if (config.h3() and USE_H3_WGRAD) else L.hold_wgrad_group_x6
+        check(fn(arr, len(items), P, ptr(ws), stream_ptr()), "hold_wgrad_group")
         _prof_end(e0, 2.0 * P * 256 * sum(it[4] for it in items), "wgrad_kernel", 4.0 * P * 512 * len(items))
 
 

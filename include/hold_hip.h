@@ -90,6 +90,15 @@ int hold_wgrad(const float* R, int32_t ldr, const float* X, int32_t ldx, int32_t
 int hold_wgrad_x6(const float* R, int32_t ldr, const float* X, int32_t ldx, int32_t P, int32_t N, int32_t K,
                   float* dW, int32_t lddw, float* db, int32_t accumulate, int32_t splits, float* workspace,
                   hold_stream_t stream);
+/* same contract; the shapes the whole-dW workgroups take (N in 129..256, K in 256..320, P a multiple of 16 >= 4 096, rows of R
+ * and X at least 256 floats wide) in the TWO-LIMB fp16 arithmetic "f16x3" (hold_amd/csrc/wgrad_r6.hip: wgrad_h3_body): both
+ * operands, scaled by powers of two, as hi = RN_f16(s x), lo = RN_f16(s x - hi), the products hi hi + hi lo + lo hi on
+ * v_mfma_f32_32x32x16_f16 with fp32 accumulation.  Every workgroup derives its two scales from a sample of its own rows
+ * (sampled maximum -> [2^6, 2^7), 2^9 of headroom; a value beyond fp16's range gives inf / NaN in dW, never a silently wrong
+ * number) and un-scales its partial tile exactly before the fp32 reduction.  Every other shape: hold_wgrad_x6. */
+int hold_wgrad_h3(const float* R, int32_t ldr, const float* X, int32_t ldx, int32_t P, int32_t N, int32_t K,
+                  float* dW, int32_t lddw, float* db, int32_t accumulate, int32_t splits, float* workspace,
+                  hold_stream_t stream);
 
 /* Narrow layer, split-precision arithmetic of hold_gemm_nt_x6:  C[p][n] (+)= sum_k A[p][k] W[n][k],  K = 256, N <= 64
  * (hold_amd/csrc/rnarrow.hip).  For the GEMMs of the path whose output is a few dozen columns wide -- d sdf / d embedding
@@ -118,6 +127,9 @@ typedef struct hold_wgrad_item {
 } hold_wgrad_item;
 int64_t hold_wgrad_group_workspace_floats(void);
 int hold_wgrad_group_x6(const hold_wgrad_item* items, int32_t n_items, int64_t P, float* workspace,
+                        hold_stream_t stream);
+/* the same launch in the two-limb fp16 arithmetic of hold_wgrad_h3 (scales per workgroup = per (item, share of the points)) */
+int hold_wgrad_group_h3(const hold_wgrad_item* items, int32_t n_items, int64_t P, float* workspace,
                         hold_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

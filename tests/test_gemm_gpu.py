@@ -20,6 +20,17 @@ def arith(request):
     hold_amd.set_precision(prev)
 
 
+@pytest.fixture(params=["f16x3", "f32x6"])
+def split_arith(request):
+    """the two split-precision modes: in f16x3 the whole-dW weight gradients run the two-limb fp16 kernel (hold_wgrad_h3 /
+    hold_wgrad_group_h3), everything else the three-limb bf16 kernels of f32x6 -- same tests, same tolerances"""
+    import hold_amd
+    prev = hold_amd.precision()
+    hold_amd.set_precision(request.param)
+    yield request.param
+    hold_amd.set_precision(prev)
+
+
 def _softplus_ref(y):
     return torch.nn.functional.softplus(y, beta=100)
 
@@ -104,13 +115,11 @@ def test_wgrad(P, N, K):
 
 @pytest.mark.parametrize("P,ldr,ldx,bias", [(4096, 256, 256, True), (4144, 256, 256, False), (200000, 256, 256, True),
                                             (65536 + 16, 304, 272, True)])
-def test_wgrad_256x256_whole_layer_workgroups(P, ldr, ldx, bias):
+def test_wgrad_256x256_whole_layer_workgroups(P, ldr, ldx, bias, split_arith):
     """the register-resident 256 x 256 weight gradient (csrc/wgrad_r6.hip: taken by hold_wgrad_x6 for N = K = 256 and P a
     multiple of 16 >= 4096) against fp64 -- row strides wider than the matrix, with / without the bias sums, accumulate"""
     import hold_amd
     from hold_amd import gemm
-    if hold_amd.precision() != "f32x6":
-        pytest.skip("split-precision path")
     dev = _dev()
     torch.manual_seed(P)
     Rb = torch.randn(P, ldr, device=dev)
@@ -137,15 +146,13 @@ def test_wgrad_256x256_whole_layer_workgroups(P, ldr, ldx, bias):
 
 @pytest.mark.parametrize("P,N,K,ldr,ldx", [(4096 * 3 + 16, 217, 256, 256, 256), (65536, 217, 256, 256, 256), (8192, 256, 272, 256, 272),
                                            (20000 * 16, 256, 304, 256, 304), (4096, 130, 256, 260, 256), (4096, 256, 320, 256, 320)])
-def test_wgrad_whole_layer_workgroups_other_shapes(P, N, K, ldr, ldx):
+def test_wgrad_whole_layer_workgroups_other_shapes(P, N, K, ldr, ldx, split_arith):
     """the whole-dW weight gradient for the trunk's 217-row layer (N < 256: the kernel reads 256 columns of R and the rows
     >= N of its partial tiles are never reduced) and the rendering net's first layer (K = 272 / 304: 256 columns this way, the
     tail by the tile kernel) against fp64 -- with the columns N..255 of R POISONED (NaN / Inf: round 3's 0 x NaN in the
     branch-free bias sums), sentinels around dW / db, accumulate on and off"""
     import hold_amd
     from hold_amd import gemm
-    if hold_amd.precision() != "f32x6":
-        pytest.skip("split-precision path")
     dev = _dev()
     torch.manual_seed(P + N + K)
     Rb = torch.randn(P, ldr, device=dev)
@@ -175,15 +182,13 @@ def test_wgrad_whole_layer_workgroups_other_shapes(P, N, K, ldr, ldx):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("P", [4096, 20000, 131072 + 48])
-def test_wgrad_group_matches_fp64_and_single_launches(P):
+def test_wgrad_group_matches_fp64_and_single_launches(P, split_arith):
     """hold_wgrad_group_x6: several (R, X) pairs over the same points in one launch -- two pairs sharing a destination (one
     with a bias, one without; the 217-row layer with its columns 217..255 poisoned), single pairs with and without bias,
     accumulate on and off -- against fp64 (the grouped kernel splits the points differently from hold_wgrad_x6, so the
     comparison with a single launch is at 1e-5 too, not bit for bit), with sentinels around every destination."""
     import hold_amd
     from hold_amd import gemm
-    if hold_amd.precision() != "f32x6":
-        pytest.skip("split-precision path")
     dev = _dev()
     torch.manual_seed(P)
     mk = lambda ld=256: torch.randn(P, ld, device=dev)
@@ -238,7 +243,7 @@ def test_wgrad_group_matches_fp64_and_single_launches(P):
 @pytest.mark.parametrize("P,N,where,acc", [(4096 + 17, 39, "t3", True), (8192, 39, "t3", False), (5000, 40, "own", True),
                                           (4099, 16, "rin", False), (131072 + 5, 48, "rin", False), (4128, 64, "own", True),
                                           (4096, 1, "own", False), (70001, 33, "own", True)])
-def test_narrow_gemm_matches_fp64_and_the_tile_kernel(P, N, where, acc):
+def test_narrow_gemm_matches_fp64_and_the_tile_kernel(P, N, where, acc, split_arith):
     """hold_gemm_narrow_x6 (csrc/rnarrow.hip): C[:, :N] (+)= A[:, :256] W[:N, :256]^T for the shapes of the path -- N = 39 into
     the 4-byte-aligned columns 217.. of a 256-wide buffer (d sdf / d embedding in place in t_3), N = 16 / 48 into the columns
     256.. of the colour net's input gradient, N = 40 into a buffer of its own, the edge widths 1 / 33 / 64 -- with a partial last
@@ -246,8 +251,6 @@ def test_narrow_gemm_matches_fp64_and_the_tile_kernel(P, N, where, acc):
     against hold_gemm_nt_x6"""
     import hold_amd
     from hold_amd import gemm
-    if hold_amd.precision() != "f32x6":
-        pytest.skip("split-precision path")
     dev = _dev()
     torch.manual_seed(P + N)
     A = torch.randn(P, 260, device=dev)[:, :256] if N % 2 else torch.randn(P, 256, device=dev)
@@ -383,7 +386,7 @@ def test_fused_sdf_x6_matches_fp32_fused():
         assert err < 5e-6 * max(1.0, float(ref.abs().max())), (kind, err)
 
 
-@pytest.mark.parametrize("mode", ["f32x6", "f32"])
+@pytest.mark.parametrize("mode", ["f16x3", "f32x6", "f32"])
 @pytest.mark.parametrize("P,N,K", [(4096, 256, 256), (5000, 217, 256), (777, 256, 40), (130, 3, 256), (70000, 257, 256)])
 def test_wgrad_matches_fp64_in_both_precisions(P, N, K, mode):
     """hold_wgrad (fp32 MFMA) and hold_wgrad_x6 (3-limb split, fp32 accumulate) against fp64, same tolerance"""
@@ -474,13 +477,11 @@ def test_colour_head_kernels(P, K):
 
 @pytest.mark.parametrize("P,K,lda,ldc,epi", [(128 * 3, 256, 256, 256, "none"), (1000, 256, 256, 304, "relu"), (40000, 304, 304, 256, "relu"),
                                              (70000, 256, 256, 256, "mask"), (33, 272, 272, 256, "none"), (300000, 256, 256, 256, "relu")])
-def test_gemm_r6_matches_fp64(P, K, lda, ldc, epi):
+def test_gemm_r6_matches_fp64(P, K, lda, ldc, epi, split_arith):
     """hold_gemm_r6 (csrc/rgemm.hip: one 256-wide layer, register-resident) against fp64: K = 256 and the padded K = 272 / 304,
     row strides wider than the matrices, ragged P, several blocks per workgroup, the three epilogues"""
     import hold_amd
     from hold_amd import field as F, gemm
-    if hold_amd.precision() != "f32x6":
-        pytest.skip("split-precision path")
     dev = _dev()
     torch.manual_seed(P + K)
     A = torch.randn(P, lda, device=dev)
@@ -500,3 +501,41 @@ def test_gemm_r6_matches_fp64(P, K, lda, ldc, epi):
     assert float((out[:, :256].double() - y).abs().max()) < 3e-5 * max(1.0, float(y.abs().max()))
     if ldc > 256:
         assert float((out[:, 256:] + 7.0).abs().max()) == 0.0  # columns beyond the 256 outputs are not touched
+
+
+@pytest.mark.parametrize("rscale,xscale", [(1e-9, 1.0), (3e-7, 40.0), (1e4, 1e-5), (1.0, 1.0)])
+def test_wgrad_h3_scales_follow_the_operands(rscale, xscale):
+    """the two-limb fp16 weight gradient picks power-of-two operand scales per workgroup from a sample of its rows: loss
+    cotangents of 1e-9, activations of tens, and operands whose magnitude CHANGES along the points (every workgroup has its
+    own scales) must come out at the relative accuracy of the unit-scale case; rows the sample did not see may exceed the
+    sampled maximum by up to 2^9 without overflow (here: an isolated 200 x outlier)."""
+    import hold_amd
+    from hold_amd import gemm
+    dev = _dev()
+    prev = hold_amd.precision()
+    hold_amd.set_precision("f16x3")
+    try:
+        P = 16 * 65536  # 256 workgroups x 4 096 rows: the scale sample reads rows 0..3 of every 64
+        torch.manual_seed(7)
+        ramp = torch.logspace(0, 3, P, device=dev).view(P, 1)  # magnitudes grow 1000 x along the points
+        R = torch.randn(P, 256, device=dev) * rscale * ramp
+        X = torch.randn(P, 256, device=dev) * xscale / ramp.flip(0)
+        # an outlier no sample row contains (row 12345 = row 57 of its workgroup's rows 12288..16383; 57 % 64 >= 4): 200 x the
+        # largest value of that workgroup's rows
+        R[12345, 17] = 200.0 * float(R[12288:16384].abs().max())
+        dW = torch.zeros(256, 256, device=dev)
+        db = torch.zeros(256, device=dev)
+        gemm.wgrad(R, X, dW, db)
+        ref = R.double().t() @ X.double()
+        assert torch.isfinite(dW).all()
+        assert ((dW.double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
+        # the same bound row by row of dW (a row = one column of R: the outlier's row has a far larger norm than the rest)
+        rel = (dW.double() - ref).abs().max(1).values / ref.abs().max(1).values
+        assert rel.max().item() < 3e-5, rel.max().item()
+        refb = R.double().sum(0)
+        assert ((db.double() - refb).abs().max() / refb.abs().max()).item() < 1e-5
+        # all-zero operands: scale 1, result exactly zero
+        gemm.wgrad(torch.zeros_like(R), X, dW, None)
+        assert float(dW.abs().max()) == 0.0
+    finally:
+        hold_amd.set_precision(prev)
