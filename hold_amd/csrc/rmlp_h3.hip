@@ -44,9 +44,10 @@ constexpr int BPTS = 32 * NW;         // points per workgroup pass
 constexpr int PIECE = 1024;           // one MFMA A fragment for a wave: 64 lanes x 16 B
 constexpr int NPC = 16;               // pieces per k step: [8 n-tiles][2 limbs]
 constexpr int SLOT = NPC * PIECE;
-constexpr int RING = 5;               // LDS slots; NSTEP % RING == 0 keeps slot = step % RING across blocks
-constexpr int L0S = 3, LKS = 16;      // k steps of layer 0 (K = 48, 39 used) and of the 256-wide layers
-constexpr int NSTEP = L0S + 7 * LKS;  // 115 k steps per block of points
+constexpr int RING = 4;               // LDS slots; L0S % RING == LKS % RING == 0: the slot of a k step is a compile-time constant
+constexpr int L0S = 4, LKS = 16;      // k steps of layer 0 (K = 64: 39 used, the last step's weights are zero) and of the 256-wide layers
+constexpr int NSTEP = L0S + 7 * LKS;  // 116 k steps per block of points
+constexpr int AHEAD = RING - 1;       // the rows of k step t + AHEAD are requested during k step t
 constexpr int NE = 39, EMB_STR = 52, SKIP_OUT = 217;
 constexpr int NGAP = 24;              // MFMAs per k step
 constexpr int OFF_BIAS = RING * SLOT;               // [8][256] fp32, pre-scaled by s_w[l] SA on the host
@@ -54,7 +55,7 @@ constexpr int OFF_W8 = OFF_BIAS + 8 * 256 * 4;      // [256] fp32
 constexpr int OFF_EMB = OFF_W8 + 256 * 4;           // [4 waves][32 points][EMB_STR] fp32 (wave-private), scaled by SA
 constexpr int OFF_BARF = OFF_EMB + NW * 32 * EMB_STR * 4;  // [64] fp32: SA x BARF weights of the 39 embedding columns
 constexpr int LDS_BYTES = OFF_BARF + 64 * 4;
-static_assert(NSTEP % RING == 0, "slot index must not depend on the block iteration");
+static_assert(L0S % RING == 0 && LKS % RING == 0, "the ring slot of a k step must not depend on the layer");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 constexpr float SA = 64.0f;                            // activation scale (a power of two)
@@ -63,7 +64,7 @@ constexpr float CL = 0.0069314718056f * SA;            // ln2 / 100, scaled
 
 struct H3Args {
   const float* xc; int ldx; long P;
-  const char* wpack;    // hold_trunk_h3_pack_bytes() bytes, [NSTEP][16 pieces][64 lanes][8 f16]
+  const char* wpack;    // hold_trunk_h3_pack_bytes() bytes, [NSTEP = 116][16 pieces][64 lanes][8 f16]
   const float* bias;    // [8][256], bias_l s_w[l] SA
   const float* c3;      // [8] 1 / s_w[l]
   const float* w8;      // [256] sdf row of lin8 (HEAD)
@@ -131,36 +132,30 @@ __device__ __forceinline__ float resid(uint32_t hi, float x) {
   return r;
 }
 
-// LDS-DMA of wave `wave`'s four 1 KiB pieces of k step `step` into ring slot `slot` (inline assembly: see rmlp.hip --
-// hipcc models the builtin as a FLAT access and would wait lgkmcnt(0) at every later ds_read; completion counted by hand)
-__device__ __forceinline__ void dma_step(const char* wpack, uint32_t lane16, int step, int slot, int wave) {
-  const char* src = wpack + (long)step * SLOT + wave * (4 * PIECE);  // wave-uniform
-  const uint32_t dst = (uint32_t)(slot * SLOT + wave * (4 * PIECE));  // dynamic LDS starts at byte 0 of the allocation
-  uint32_t keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %3\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2\n\t"
-      "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-      "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-      "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(lane16), "s"(src), "s"(dst)
-      : "memory");
-}
-
-// one 1 KiB piece (wave-uniform source, lane offset lane16) to LDS byte `dst`; M0 is not saved (nothing else uses it)
-__device__ __forceinline__ void dma_piece(const char* src, uint32_t lane16, uint32_t dst) {
+// LDS-DMA (inline assembly: hipcc models the builtin as a FLAT access that may touch LDS and would wait lgkmcnt(0) at every
+// later ds_read; completion is counted by hand): TWO consecutive 1 KiB pieces (wave-uniform source, lane offset lane16) to
+// LDS bytes dst, dst + 1 KiB -- the instruction offset advances both the global and the LDS address (M0 = LDS base).  M0 is
+// not saved: nothing else in this kernel uses it.
+__device__ __forceinline__ void dma_pair(const char* src, uint32_t lane16, uint32_t dst) {
   asm volatile(
       "s_mov_b32 m0, %2\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %0, %1"
+      "global_load_lds_dwordx4 %0, %1\n\t"
+      "global_load_lds_dwordx4 %0, %1 offset:1024"
       :
       : "v"(lane16), "s"(src), "s"(dst)
       : "memory");
 }
+// transcendentals as opaque volatile instructions: they stay where the schedule puts them without a pin behind them (an
+// empty asm right behind a builtin v_exp / v_log made the hazard recogniser pad a wait state -- 9 s_nop per k step); their
+// consumers are LAT_TRANS instruction slots away by construction of the schedule (tests/test_r6_pack_cpu.py checks the table)
+// packed fp32 arithmetic (two values per instruction) as volatile instructions as well: written as <2 x float> C
+// arithmetic the instruction selector scalarises most of it again (operands assembled from separately computed halves)
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { f32x2 r; asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 r; asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { f32x2 r; asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float exp2_v(float x) { float r; asm volatile("v_exp_f32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ __forceinline__ float log2_v(float x) { float r; asm volatile("v_log_f32 %0, %1" : "=v"(r) : "v"(x)); return r; }
 
 // Placement of a k step's micro-operations behind its 24 MFMAs: gap G issues the operations op(k), begin(G) <= k < end(G).
 struct SchedNone {
@@ -192,6 +187,7 @@ struct SchedEpi {
 };
 
 #define H3_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define H3_WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xC07F)  // lgkmcnt(0): a real s_waitcnt, which the compiler's own wait insertion sees
 
 template <bool HEAD, bool STORE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rmlp_h3_kernel(H3Args a) {
@@ -204,13 +200,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const char* ring_lane = smem + lane * 16;
   const float b8 = HEAD ? *a.b8 : 0.f;  // read on the device: a host copy of a trained parameter costs a stream drain
 
-  // ---- once per workgroup: biases (+ the sdf row) into LDS, the first four k steps into the ring ----
+  // ---- once per workgroup: biases (+ the sdf row) into LDS, the first AHEAD k steps into the ring ----
   for (int i = tid; i < 8 * 256; i += 256) reinterpret_cast<float*>(smem + OFF_BIAS)[i] = a.bias[i];
   if (HEAD) reinterpret_cast<float*>(smem + OFF_W8)[tid] = a.w8[tid];
   if (tid < 64) reinterpret_cast<float*>(smem + OFF_BARF)[tid] = SA * ((a.barf && tid < NE) ? a.barf[tid] : 1.0f);
   __syncthreads();
+  const char* wsrc0 = a.wpack + wave * (4 * PIECE);                 // this wave's four pieces of k step 0
+  const uint32_t wdst0 = (uint32_t)(wave * (4 * PIECE));            // ... and their place in ring slot 0
 #pragma unroll
-  for (int s = 0; s < 4; ++s) dma_step(a.wpack, lane16, s, s, wave);
+  for (int s = 0; s < AHEAD; ++s)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) dma_pair(wsrc0 + (long)s * SLOT + h * (2 * PIECE), lane16, wdst0 + s * SLOT + h * (2 * PIECE));
 
   f32x16 P[8], Q[8];
   u32x4 A[2][4];  // weight fragments of two n-tiles x two limbs, double-buffered
@@ -266,30 +266,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (hh) er[NE + i] = 0.f;
     }
     if (first) {  // step 0 of the very first block: everybody's pieces landed
-      H3_WAIT_VM(12);
+      H3_WAIT_VM(4 * (AHEAD - 1));
       __builtin_amdgcn_s_barrier();
       read_pair(0, 0, A[0]);
       first = 0;
     }
 
-    // One k step of the layer being accumulated into Q (`t` = step index in the block's stream, ring slot t % RING) with an
-    // EXPLICIT schedule: 4 groups (pairs of n-tiles) x 6 MFMAs; behind every MFMA stands a fixed slice of everything else --
-    // one fragment read for the next group (gaps 0..3 of a group), one DMA piece (gaps 1 and 4 of the two groups behind the
-    // rendezvous), and the micro-operations nops G / 24 .. nops (G + 1) / 24 - 1 of the NEXT step's epilogue (G = the gap's
-    // index in the step) -- closed by a full scheduling barrier: with one wave per SIMD the wave must be back at the next
-    // MFMA within the 32 cycles the current one runs.
-    auto kstep = [&](int t, auto sch, auto&& mop) {
+    // One k step of the layer being accumulated into Q.  `ts` = the step's index in its layer (compile time; ring slot
+    // ts % RING), `src` = this wave's four pieces of the step AHEAD steps later in the stream.  EXPLICIT schedule: 4 groups
+    // (pairs of n-tiles) x 6 MFMAs; behind every MFMA stands a fixed slice of everything else -- one fragment read for the next
+    // group (gaps 0..3 of a group), the LDS wait for this group's fragments (gap 0), one DMA pair (gap 1 of the two groups
+    // behind the rendezvous) and the micro-operations the schedule S gives the gap -- closed by a full scheduling barrier.
+    auto kstep = [&](int ts, const char* src, auto sch, auto&& mop) {
       using S = decltype(sch);
-      const int slot = t % RING;
+      const int slot = ts % RING;
 #pragma unroll
       for (int pair = 0; pair < 4; ++pair) {
-        if (pair == 2) {  // mid-step rendezvous: step t + 1 complete in LDS, slot of step t - 1 free
-          H3_WAIT_VM(8);
+        if (pair == 2) {  // mid-step rendezvous: the next step complete in LDS, the previous step's slot free
+          H3_WAIT_VM(4 * (AHEAD - 2));
           __builtin_amdgcn_s_barrier();
         }
-        const char* rd = ring_lane + (pair < 3 ? slot * SLOT + (pair + 1) * (4 * PIECE) : ((t + 1) % RING) * SLOT);
-        const char* src = a.wpack + (long)((t + 4) % NSTEP) * SLOT + wave * (4 * PIECE) + (pair & 1) * (2 * PIECE);
-        const uint32_t dst = (uint32_t)(((t + 4) % RING) * SLOT + wave * (4 * PIECE) + (pair & 1) * (2 * PIECE));
+        const char* rd = ring_lane + (pair < 3 ? slot * SLOT + (pair + 1) * (4 * PIECE) : ((ts + 1) % RING) * SLOT);
 #pragma unroll
         for (int m = 0; m < 6; ++m) {
           const int pr = m >> 1, tl = m & 1;           // (w limb, act limb): hi hi, hi lo, lo hi
@@ -298,13 +295,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                                    __builtin_bit_cast(f16x8, Bc.l[al]), Q[2 * pair + tl],
                                                                    0, 0, 0);
           if (m < 4) A[(pair + 1) & 1][m] = *reinterpret_cast<const u32x4*>(rd + m * PIECE);
-          if (pair >= 2 && (m == 1 || m == 4)) dma_piece(src + (m >> 2) * PIECE, lane16, dst + (m >> 2) * PIECE);
+          if (pair >= 2 && m == 1)
+            dma_pair(src + (pair & 1) * (2 * PIECE), lane16,
+                     wdst0 + (uint32_t)(((ts + AHEAD) % RING) * SLOT + (pair & 1) * (2 * PIECE)));
           const int G = 6 * pair + m;
 #pragma unroll
           for (int u = 0; u < 12; ++u) {  // constant trip count (the slice bounds fold once pair and m are unrolled)
             const int k = S::begin(G) + u;
             if (k < S::end(G)) mop(S::op(k));
           }
+          // ONE LDS wait per group, at the end of the gap in front of it (inside this scheduling region, so that the next
+          // group's first MFMA cannot be hoisted above it and get a wait of its own): the four fragments of the next group,
+          // read behind the first four MFMAs of this one.  A real s_waitcnt: the compiler's wait insertion accounts for it.
+          if (m == 5) H3_WAIT_LDS();
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -312,8 +315,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     auto no_mop = [](int) {};
 
-    // limb split of dword d from two (scaled) values, as four micro-operations (op = 0..3); results pinned: pure VALU code
-    // has no side effects, so without the pin LLVM sinks the whole next-step epilogue to its first use
+    // limb split of dword d from two (scaled) values, as four micro-operations (op = 0..3); results pinned (empty volatile
+    // asm): the instruction selector's list scheduler is free to place pure VALU code anywhere between its operands and its
+    // first user, and without the pins it collects the whole epilogue in front of the first volatile instruction
     struct SplitState { uint32_t hi[4]; float ra[4], rb[4]; };
     auto split_op = [&](int op, int d, float x0, float x1, Limbs& out, SplitState& ss) {
       if (op == 0) {
@@ -331,7 +335,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     };
 
-    // ---- layer 0: B limbs straight from the (scaled) embedding (natural k order 16 j + 8 hh + e) ----
+    // ---- layer 0: B limbs straight from the (scaled) embedding (natural k order 16 j + 8 hh + e; the fourth k step is
+    // padding: its weights are zero, its B limbs whatever finite numbers follow the embedding in LDS) ----
     SplitState ss;
     auto emb_mop = [&](int j, int k, Limbs& out) {  // k = 0..15: round-major over the four dwords
       const int op = k >> 2, d = k & 3;
@@ -343,10 +348,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int k = 0; k < 16; ++k) emb_mop(0, k, Bc);
 #pragma unroll
     for (int j = 0; j < L0S; ++j) {
+      const char* src = wsrc0 + (long)(j + AHEAD) * SLOT;
       if (j + 1 < L0S)
-        kstep(j, SchedUniform<16>(), [&](int k) { emb_mop(j + 1, k, Bn); });
+        kstep(j, src, SchedUniform<16>(), [&](int k) { emb_mop(j + 1, k, Bn); });
       else
-        kstep(j, SchedNone(), no_mop);
+        kstep(j, src, SchedNone(), no_mop);
     }
 
     // ---- layers 1..7: input = SA x softplus(c3 x the previous layer's accumulators) ----
@@ -356,63 +362,84 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const uint32_t hbytes = (uint32_t)(a.P * a.ldh * 4);
     const uint32_t hvoff = (uint32_t)(((p0 + li) * a.ldh + 4 * hh) * 4);
     // Epilogue of k step j = (nt, q) of the finished layer: its 8 values P[nt][8 q + i] (features 32 nt + 16 q + 8 (i / 4) +
-    // 4 hh + i % 4) as a flat list of micro-operations in ROUND-MAJOR order (micro-operation k of the softplus part = round
-    // k / 8 on value k % 8), so consecutive micro-operations are independent and a dependent pair is eight apart.
-    //   sampler query (8 rounds): y, ys = c3 y, KE |ys|, exp2, 1 + e, log2, max(ys, 0), CL log2 + max  [skip override]
-    //   training (16 rounds): y, ys, KE |ys|, exp2, 1 + e, series x 4, log2, CL log2, select, max, +, threshold [override],
-    //                         1 / SA (the stored value)
-    //   then the limb split of the four dwords (16 micro-operations, round-major) and, training, the two 16-byte stores
-    struct EpiState { float y[8], u[8], e[8], ser[8], r[8], o[8]; };
-    constexpr int NR = HEAD ? 8 : 16;
-    constexpr int NOPS = 8 * NR + 16 + (STORE ? 2 : 0);
+    // 4 hh + i % 4) as a flat list of micro-operations, ROUND-MAJOR: a round works on the 8 values (one instruction each) or, where
+    // a packed fp32 instruction exists, on the 4 value PAIRS (2 i, 2 i + 1) -- consecutive micro-operations are independent.
+    //   sampler query: y (8), ys = c3 y (4, v_pk_mul_f32), KE |ys| (8), exp2 (8), 1 + e (4, v_pk_add_f32), log2 (8),
+    //                  max(ys, 0) (8), CL log2 + max (4, v_pk_fma_f32) [skip override]                         = 52
+    //   training:      y (8), ys (4), KE |ys| (8), exp2 (8), 1 + e (4), series (4 + 4 + 4 + 4), log2 (8), CL log2 (4), select (8),
+    //                  max (8), + (4), [skip override] (8; the reference's `y > 0.2 -> y` branch needs no instruction: softplus(y) - y
+    //                  <= 2.1e-11 there, far below half an ulp of y, so the sum IS y), 1 / SA = the stored value (4)   = 92
+    //   then the limb split of the four dwords (16, round-major) and, training, the two 16-byte stores
+    struct EpiState { f32x2 y[4], e[4], u[4], ser[4], r[4], o[4]; };
+    constexpr int NSP = HEAD ? 52 : 92;
+    constexpr int NOPS = NSP + 16 + (STORE ? 2 : 0);
     static_assert(NOPS == SchedEpi<HEAD>::N, "regenerate rmlp_h3_sched.h");
-    auto epi_mop = [&](int layer, float c3, int j, int k, Limbs& out, EpiState& st) {
-      const int nt = j >> 1, q = j & 1;
-      if (k < 8 * NR) {
-        const int rd = k >> 3, i = k & 7;
-        auto skip = [&](float r) {  // skip connection: columns 217.. of layer 3's output are the embedding (shape_net.py:122-123)
-          if (j >= 13) {
-            const int m = 32 * nt + 16 * q + 8 * (i >> 2) + 4 * hh + (i & 3) - SKIP_OUT;
-            const float ev = embw[li * EMB_STR + (m < 0 ? 0 : m)];
-            r = (layer == 4 && m >= 0) ? ev : r;
-          }
-          return r;
-        };
-        // every result is pinned (empty volatile asm): the instruction selector's list scheduler is free to place pure VALU code
-        // anywhere between its operands and its first user, and without the pins it collects the whole epilogue in
-        // front of the limb split (the first volatile user) instead of leaving each slice behind its MFMA
 #define H3_PIN(x) asm volatile("" : "+v"(x))
-        if (rd == 0) { st.y[i] = P[nt][8 * q + i]; H3_PIN(st.y[i]); }
-        else if (rd == 1) { st.y[i] = c3 * st.y[i]; H3_PIN(st.y[i]); }
-        else if (rd == 2) { st.e[i] = KE * fabsf(st.y[i]); H3_PIN(st.e[i]); }
-        else if (rd == 3) { st.e[i] = __builtin_amdgcn_exp2f(st.e[i]); H3_PIN(st.e[i]); }
-        else if (rd == 4) { st.u[i] = 1.0f + st.e[i]; H3_PIN(st.u[i]); }
-        else if (HEAD) {
-          if (rd == 5) { st.u[i] = __builtin_amdgcn_logf(st.u[i]); H3_PIN(st.u[i]); }
-          else if (rd == 6) { st.r[i] = relu1(st.y[i]); H3_PIN(st.r[i]); }
-          else { st.r[i] = skip(fmaf(CL, st.u[i], st.r[i])); H3_PIN(st.r[i]); }
-        } else {
-          if (rd == 5) { st.ser[i] = fmaf(st.e[i], 0.33333334f, -0.5f); H3_PIN(st.ser[i]); }
-          else if (rd == 6) { st.ser[i] = fmaf(st.e[i], st.ser[i], 1.0f); H3_PIN(st.ser[i]); }
-          else if (rd == 7) { st.e[i] = (0.01f * SA) * st.e[i]; H3_PIN(st.e[i]); }
-          else if (rd == 8) { st.ser[i] = st.e[i] * st.ser[i]; H3_PIN(st.ser[i]); }
-          else if (rd == 9) { st.u[i] = __builtin_amdgcn_logf(st.u[i]); H3_PIN(st.u[i]); }
-          else if (rd == 10) { st.u[i] = CL * st.u[i]; H3_PIN(st.u[i]); }
-          else if (rd == 11) { st.u[i] = (st.e[i] > 1e-5f * SA) ? st.u[i] : st.ser[i]; H3_PIN(st.u[i]); }  // e > 1e-3: log(1 + e) accurate
-          else if (rd == 12) { st.r[i] = relu1(st.y[i]); H3_PIN(st.r[i]); }
-          else if (rd == 13) { st.r[i] = st.r[i] + st.u[i]; H3_PIN(st.r[i]); }
-          else if (rd == 14) { st.r[i] = skip((st.y[i] > 0.2f * SA) ? st.y[i] : st.r[i]); H3_PIN(st.r[i]); }
-          else { st.o[i] = (1.0f / SA) * st.r[i]; H3_PIN(st.o[i]); }
+#define H3_PINP(x)  // (no pin behind a transcendental: see exp2_v)
+    // constants of the packed instructions as OPAQUE register pairs: with an inline constant or an SGPR operand the
+    // instruction selector scalarises a <2 x float> operation into two v_*_f32 (packed fp32 takes no literal per half)
+    f32x2 ONE2 = {1.0f, 1.0f}, CL2 = {CL, CL};
+    H3_PIN(ONE2);
+    H3_PIN(CL2);
+    f32x2 THIRD2 = {0.33333334f, 0.33333334f}, MHALF2 = {-0.5f, -0.5f}, E001_2 = {0.01f * SA, 0.01f * SA}, ISA2 = {1.0f / SA, 1.0f / SA};
+    if (!HEAD) { H3_PIN(THIRD2); H3_PIN(MHALF2); H3_PIN(E001_2); H3_PIN(ISA2); }
+    auto epi_mop = [&](int layer, f32x2 c3, int j, int k, Limbs& out, EpiState& st) {
+      const int nt = j >> 1, q = j & 1;
+      // round boundaries (compile-time): operations of 8 (per value) or 4 (per pair)
+      constexpr int bH[9] = {0, 8, 12, 20, 28, 32, 40, 48, 52};
+      constexpr int bS[17] = {0, 8, 12, 20, 28, 32, 36, 40, 44, 48, 56, 60, 68, 76, 80, 88, 92};
+      auto skip = [&](float r, int i) {  // skip connection: columns 217.. of layer 3's output are the embedding (shape_net.py:122-123)
+        if (j >= 13) {
+          const int m = 32 * nt + 16 * q + 8 * (i >> 2) + 4 * hh + (i & 3) - SKIP_OUT;
+          const float ev = embw[li * EMB_STR + (m < 0 ? 0 : m)];
+          r = (layer == 4 && m >= 0) ? ev : r;
         }
-      } else if (k < 8 * NR + 16) {
-        const int s = k - 8 * NR, op = s >> 2, d = s & 3;
-        split_op(op, d, st.r[2 * d], st.r[2 * d + 1], out, ss);
+        return r;
+      };
+      if (k < NSP) {
+        // round and position within it (plain arithmetic on k: a search loop over the table is not folded for 16 rounds and
+        // the state arrays would be indexed dynamically, i.e. live in scratch)
+        const int rd = HEAD ? (k >= 8) + (k >= 12) + (k >= 20) + (k >= 28) + (k >= 32) + (k >= 40) + (k >= 48)
+                            : (k >= 8) + (k >= 12) + (k >= 20) + (k >= 28) + (k >= 32) + (k >= 36) + (k >= 40) + (k >= 44) +
+                                  (k >= 48) + (k >= 56) + (k >= 60) + (k >= 68) + (k >= 76) + (k >= 80) + (k >= 88);
+        const int i = k - (HEAD ? bH[rd] : bS[rd]);  // value 0..7 or pair 0..3 within the round
+        const int p = i >> 1, c = i & 1;             // (per-value rounds) pair and component of value i
+        if (rd == 0) { st.y[p][c] = P[nt][8 * q + i]; H3_PIN(st.y[p]); }
+        else if (rd == 1) { st.y[i] = pk_mul(st.y[i], c3); }
+        else if (rd == 2) { st.e[p][c] = KE * fabsf(st.y[p][c]); H3_PIN(st.e[p]); }
+        else if (rd == 3) { st.e[p][c] = exp2_v(st.e[p][c]); H3_PINP(st.e[p]); }
+        else if (rd == 4) { st.u[i] = pk_add(st.e[i], ONE2); }
+        else if (HEAD) {
+          if (rd == 5) { st.u[p][c] = log2_v(st.u[p][c]); H3_PINP(st.u[p]); }
+          else if (rd == 6) { st.r[p][c] = relu1(st.y[p][c]); H3_PIN(st.r[p]); }
+          else {
+            f32x2 r = pk_fma(st.u[i], CL2, st.r[i]);
+            if (j >= 13) { r[0] = skip(r[0], 2 * i); r[1] = skip(r[1], 2 * i + 1); H3_PIN(r); }
+            st.r[i] = r;
+          }
+        } else {
+          if (rd == 5) { st.ser[i] = pk_fma(st.e[i], THIRD2, MHALF2); }
+          else if (rd == 6) { st.ser[i] = pk_fma(st.e[i], st.ser[i], ONE2); }
+          else if (rd == 7) { st.e[i] = pk_mul(st.e[i], E001_2); }
+          else if (rd == 8) { st.ser[i] = pk_mul(st.e[i], st.ser[i]); }
+          else if (rd == 9) { st.u[p][c] = log2_v(st.u[p][c]); H3_PINP(st.u[p]); }
+          else if (rd == 10) { st.u[i] = pk_mul(st.u[i], CL2); }
+          else if (rd == 11) { st.u[p][c] = (st.e[p][c] > 1e-5f * SA) ? st.u[p][c] : st.ser[p][c]; H3_PIN(st.u[p]); }  // e > 1e-3: log(1 + e) accurate
+          else if (rd == 12) { st.r[p][c] = relu1(st.y[p][c]); H3_PIN(st.r[p]); }
+          else if (rd == 13) { st.r[i] = pk_add(st.r[i], st.u[i]); }
+          else if (rd == 14) { if (j >= 13) { st.r[p][c] = skip(st.r[p][c], i); H3_PIN(st.r[p]); } }
+          else { st.o[i] = pk_mul(st.r[i], ISA2); }
+        }
+      } else if (k < NSP + 16) {
+        const int s = k - NSP, op = s >> 2, d = s & 3;
+        split_op(op, d, st.r[d][0], st.r[d][1], out, ss);
       } else {  // STORE: the four consecutive features of half h2
-        const int h2 = k - (8 * NR + 16);
-        const f32x4 v = {st.o[4 * h2], st.o[4 * h2 + 1], st.o[4 * h2 + 2], st.o[4 * h2 + 3]};
+        const int h2 = k - (NSP + 16);
+        const f32x4 v = {st.o[2 * h2][0], st.o[2 * h2][1], st.o[2 * h2 + 1][0], st.o[2 * h2 + 1][1]};
         store4(v, hrs, hvoff + (32 * nt + 16 * q + 8 * h2) * 4);
       }
     };
+    const char* lsrc = wsrc0 + (long)(L0S + AHEAD) * SLOT;  // this wave's pieces of the step AHEAD behind the layer's first
     for (int layer = 1; layer < 8; ++layer) {
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
@@ -422,19 +449,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int r = 0; r < 16; ++r) asm volatile("" : "+a"(P[nt][r]));
       }
       init_bias(layer);
-      const float c3 = a.c3[layer - 1];
-      const int t0 = L0S + (layer - 1) * LKS;
+      const float c3s = a.c3[layer - 1];
+      f32x2 c3 = {c3s, c3s};
+      H3_PIN(c3);
       EpiState st;
       if (STORE) hrs = make_rsrc(a.h[layer - 1], hbytes);
 #pragma unroll
       for (int k = 0; k < NOPS; ++k) epi_mop(layer, c3, 0, k, Bc, st);
 #pragma unroll
       for (int j = 0; j < LKS; ++j) {
+        // the stream wraps into the NEXT block's first steps behind the last layer
+        const char* src = (j + AHEAD >= LKS && layer == 7) ? wsrc0 + (long)(j + AHEAD - LKS) * SLOT : lsrc + (long)j * SLOT;
         if (j + 1 < LKS)
-          kstep(t0 + j, SchedEpi<HEAD>(), [&](int k) { epi_mop(layer, c3, j + 1, k, Bn, st); });
+          kstep(j, src, SchedEpi<HEAD>(), [&](int k) { epi_mop(layer, c3, j + 1, k, Bn, st); });
         else
-          kstep(t0 + j, SchedNone(), no_mop);
+          kstep(j, src, SchedNone(), no_mop);
       }
+      lsrc += (long)LKS * SLOT;
     }
     // ---- output of layer 7 ----
     {

@@ -36,6 +36,7 @@ namespace {
 constexpr int NST = 4;            // ring slots
 constexpr int STAGE = 32 * 1024;  // one step: R rows [16][256] fp32, then X rows [16][256]
 constexpr int LDS_BYTES = NST * STAGE;
+constexpr int LDS_BYTES_H3 = LDS_BYTES + 64;  // + the scale sample's reduction
 
 struct WArgs {
   const float* R; int ldr;
@@ -262,7 +263,7 @@ __device__ __forceinline__ void wgrad_r6_body(const float* R, int ldr, const flo
 // 16-point step instead of 96, a limb split of 5 instructions per two values (v_pk_mul_f32 by the scale, v_cvt_pk_f16_f32,
 // 2 x v_fma_mix_f32, v_cvt_pk_f16_f32) instead of 9 + 2 pins, and the fragment's 8 rows read as 4 ds_read2st64_b32.
 // SCALES.  The operands are activations (O(1)) and loss cotangents (1e-9 .. 1e-3 and anything else): every WORKGROUP picks
-// its own pair of scales from a sample of ITS rows (every rows / 64-th row, all 256 -- for R: the first n_valid -- columns)
+// its own pair of scales from a sample of ITS rows (16 groups of four rows, evenly spread; all 256 -- for R: the first n_valid -- columns)
 // so that the sampled maximum lands in [2^6, 2^7): 2^9 of headroom below fp16's largest value for rows the sample did
 // not see (an overflow gives +-inf and a NaN gradient: loud, never silently wrong), full 22-23-bit precision for every value
 // within 2^-8 of the sampled maximum and an absolute 2^-31 of it below.  Workgroups need not agree: a partial tile is
@@ -344,12 +345,20 @@ __device__ __forceinline__ void wgrad_h3_body(const float* R, int ldr, const flo
   float inv = 1.0f;
 
   if (s0 < s1) {
-    // ---- this workgroup's scales: a sample of its rows (4 rows per pass: a row = 64 threads x 16 bytes) ----
+    // the first DIST steps' rows are requested FIRST: the scale sample below runs while they travel
+#pragma unroll
+    for (int u = 0; u < DIST; ++u) {
+      const char* p = step_src(s0 + u);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dma_piece(p + i * rowb, dvoff, (uint32_t)((int)((s0 + u) % NST) * STAGE) + dst0 + i * 1024);
+    }
+    // ---- this workgroup's scales: a sample of its rows -- at most 16 passes of four consecutive rows (a row = 64 threads x
+    // 16 bytes), evenly spread; the reduction uses 32 bytes of LDS behind the ring ----
     float sR, sX;
     {
       const long r0 = s0 * 16, nrows = (s1 - s0) * 16;
-      long stride = nrows / 64;
-      stride = stride < 4 ? 4 : stride & ~3L;  // passes of four consecutive rows, `stride` rows apart
+      long stride = (nrows / 16 + 3) & ~3L;
+      stride = stride < 4 ? 4 : stride;
       const int c4 = (tid & 63) * 4, sub = tid >> 6;
       float amR = 0.f, amX = 0.f;
       for (long r = 0; r + 4 <= nrows; r += stride) {
@@ -366,22 +375,15 @@ __device__ __forceinline__ void wgrad_h3_body(const float* R, int ldr, const flo
         amR = fmaxf(amR, __shfl_xor(amR, o));
         amX = fmaxf(amX, __shfl_xor(amX, o));
       }
-      float* red = reinterpret_cast<float*>(smem);
+      float* red = reinterpret_cast<float*>(smem + LDS_BYTES);
       if (lane == 0) { red[wave] = amR; red[4 + wave] = amX; }
       __syncthreads();
       amR = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
       amX = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
-      __syncthreads();  // the ring's first slot is about to be overwritten by the LDS-DMA
       const int kR = __builtin_amdgcn_readfirstlane(scale_exp(amR)), kX = __builtin_amdgcn_readfirstlane(scale_exp(amX));
       sR = bitsf((uint32_t)(127 + kR) << 23);
       sX = bitsf((uint32_t)(127 + kX) << 23);
       inv = bitsf((uint32_t)(127 - kR - kX) << 23);
-    }
-#pragma unroll
-    for (int u = 0; u < DIST; ++u) {
-      const char* p = step_src(s0 + u);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) dma_piece(p + i * rowb, dvoff, (uint32_t)((int)((s0 + u) % NST) * STAGE) + dst0 + i * 1024);
     }
     const char* dptr = step_src(s0 + DIST);
     WG_WAIT_VM(8 * (DIST - 1));
@@ -439,7 +441,20 @@ __device__ __forceinline__ void wgrad_h3_body(const float* R, int ldr, const flo
           }
           const int w0 = wsh(f), w1 = wsh(f + 1), len = w1 - w0;
           if (m >= w0 && m < w1) {
-            if (m == w0) bias_add(f, fs[f & 1]);
+            if (m == w0) {
+              // ONE wait for the fragment's four reads (a real s_waitcnt, which the compiler's own wait insertion takes into
+              // account: it otherwise puts a wait in front of every first use, 33 per step): LDS reads return in order, so
+              // only the reads of fragment f + 1 issued in the meantime may stay outstanding
+              constexpr int nx = 0;
+              const int after = f < 7 ? (w0 - rsh(f + 1) < 0 ? 0 : (w0 - rsh(f + 1) > 4 ? 4 : w0 - rsh(f + 1))) : 0;
+              if (after == 0) __builtin_amdgcn_s_waitcnt(0xC07F);
+              else if (after == 1) __builtin_amdgcn_s_waitcnt(0xC17F);
+              else if (after == 2) __builtin_amdgcn_s_waitcnt(0xC27F);
+              else if (after == 3) __builtin_amdgcn_s_waitcnt(0xC37F);
+              else __builtin_amdgcn_s_waitcnt(0xC47F);
+              (void)nx;
+              bias_add(f, fs[f & 1]);
+            }
 #pragma unroll
             for (int u = 0; u < 5; ++u) {
               const int k = 20 * (m - w0) / len + u;
@@ -594,11 +609,11 @@ static int wgrad_r6_setup() {
             hipSuccess ||
         hipFuncSetAttribute((const void*)wgrad_r6_group_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
             hipSuccess ||
-        hipFuncSetAttribute((const void*)wgrad_r6_group_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+        hipFuncSetAttribute((const void*)wgrad_r6_group_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_H3) !=
             hipSuccess ||
-        hipFuncSetAttribute((const void*)wgrad_h3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+        hipFuncSetAttribute((const void*)wgrad_h3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_H3) !=
             hipSuccess ||
-        hipFuncSetAttribute((const void*)wgrad_h3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+        hipFuncSetAttribute((const void*)wgrad_h3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_H3) !=
             hipSuccess)
       return 0;
     attr_set = true;
@@ -652,9 +667,9 @@ int hold_wgrad_h3_partials(const float* R, int ldr, const float* X, int ldx, lon
   a.spw = (int)((a.nsteps + G - 1) / G);
   G = (a.nsteps + a.spw - 1) / a.spw;
   if (part_b)
-    hipLaunchKernelGGL((wgrad_h3_kernel<true>), dim3((unsigned)G), dim3(256), LDS_BYTES, s, a, n_valid);
+    hipLaunchKernelGGL((wgrad_h3_kernel<true>), dim3((unsigned)G), dim3(256), LDS_BYTES_H3, s, a, n_valid);
   else
-    hipLaunchKernelGGL((wgrad_h3_kernel<false>), dim3((unsigned)G), dim3(256), LDS_BYTES, s, a, n_valid);
+    hipLaunchKernelGGL((wgrad_h3_kernel<false>), dim3((unsigned)G), dim3(256), LDS_BYTES_H3, s, a, n_valid);
   return hipGetLastError() == hipSuccess ? (int)G : HOLD_E_LAUNCH;
 }
 
@@ -702,7 +717,7 @@ static int wgrad_group_impl(const hold_wgrad_item* items, int32_t n_items, int64
   r.gper = a.gper; r.part = a.part; r.part_b = a.part_b;
   hipStream_t s = (hipStream_t)stream;
   if (h3)
-    hipLaunchKernelGGL(wgrad_r6_group_kernel<true>, dim3((unsigned)(n_items * gper)), dim3(256), LDS_BYTES, s, a);
+    hipLaunchKernelGGL(wgrad_r6_group_kernel<true>, dim3((unsigned)(n_items * gper)), dim3(256), LDS_BYTES_H3, s, a);
   else
     hipLaunchKernelGGL(wgrad_r6_group_kernel<false>, dim3((unsigned)(n_items * gper)), dim3(256), LDS_BYTES, s, a);
   hipLaunchKernelGGL(wgrad_group_reduce_kernel, dim3(1025, nd), dim3(256), 0, s, r);

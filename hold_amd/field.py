@@ -146,8 +146,8 @@ def _lay_x6_stack(l3):
 
 
 def _lay_r6_0(l3):
-    T = l3.shape[0]  # limbs: 3 (bf16, hold_trunk_r6) or 2 (fp16, hold_trunk_h3)
-    return l3.reshape(T, 8, 32, 3, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(-1)
+    T, K = l3.shape[0], l3.shape[2]  # limbs: 3 (bf16, hold_trunk_r6: K = 48) or 2 (fp16, hold_trunk_h3: K = 64)
+    return l3.reshape(T, 8, 32, K // 16, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(-1)
 
 
 def _lay_r6_stack(l3):
@@ -200,6 +200,7 @@ def pack_r6(w0, S):
     return torch.cat([p0, _lay_r6_stack(torch.stack(split_limbs(S)))]).contiguous()
 
 
+H3_K0 = 64  # layer 0's K in the f16x3 stream (39 embedding columns, zero-padded to four 16-wide k steps)
 H3_ACT_SCALE = 64.0  # SA of csrc/rmlp_h3.hip (checked against hold_trunk_h3_act_scale() by kernels.fused_sdf_h3)
 
 
@@ -219,10 +220,11 @@ def split_limbs_h(ws):
 
 def pack_h3(w0, S):
     """limb pack of hold_fused_sdf_h3 / hold_trunk_h3 (include/hold_hip.h): the k order and tiling of pack_r6 with TWO fp16
-    limbs of the scaled weights -> (fp16 [115 steps][8 nt][2 t][2 h][32 i][8 e], s_w [8])"""
+    limbs of the scaled weights and layer 0 padded to K = 64 (four k steps: the ring slot of a k step is then a compile-time
+    constant in every layer) -> (fp16 [116 steps][8 nt][2 t][2 h][32 i][8 e], s_w [8])"""
     dev = S.device
     sw = h3_scales(w0, S)
-    m0 = torch.zeros(256, 48, device=dev)
+    m0 = torch.zeros(256, H3_K0, device=dev)
     m0[:, :w0.shape[1]] = w0
     p0 = _lay_r6_0(torch.stack(split_limbs_h(m0 * sw[0])))
     ps = _lay_r6_stack(torch.stack(split_limbs_h(S * sw[1:].view(7, 1, 1))))
@@ -297,9 +299,6 @@ def pack_plan(K0, device):
         l3 = lambda I: torch.stack([I + t * N for t in range(3)])
         l2 = lambda I: torch.stack([I + t * N for t in range(2)])
         i32 = lambda t: t.to(torch.int32).contiguous()
-        seg = torch.cat([torch.zeros(n0, dtype=torch.long, device=device),
-                         1 + torch.arange(7, device=device).repeat_interleave(65536),
-                         torch.full((65536,), 8, dtype=torch.long, device=device)])  # matrix index of every source element
         frag0 = I0[:, :K0].reshape(8, 32, K0 // 8, 2, 4).permute(2, 0, 3, 1, 4).reshape(-1)
         _PLANS[key] = dict(
             N=N,
@@ -307,11 +306,22 @@ def pack_plan(K0, device):
             chain_bwd=i32(frag_pack_stack(ISTf)),
             fused_x6=i32(torch.cat([_lay_x6(l3(I0), 48), _lay_x6_stack(l3(IS))])),
             trunk_r6=i32(torch.cat([_lay_r6_0(l3(I0)), _lay_r6_stack(l3(IS))])),
-            trunk_h3=i32(torch.cat([_lay_r6_0(l2(I0)), _lay_r6_stack(l2(IS))])), seg=seg,
+            h3=_h3_plan(device),
             chain_bwd_x6=i32(_lay_x6_stack(l3(ISTf))),
             chain_bwd_r6=i32(_lay_r6_stack(l3(ISTf))),
             w8_feat_r6=i32(_lay_gemm_r6(l3(I8), 16)))
     return _PLANS[key]
+
+
+def _h3_plan(device):
+    """gather of the f16x3 trunk stream from ITS flat source [w0 zero-padded to [256, 64] | S [7, 256, 256]] (two limbs)"""
+    n0, ns = 256 * H3_K0, 7 * 65536
+    N = n0 + ns
+    I0 = torch.arange(n0, device=device).view(256, H3_K0)
+    IS = n0 + torch.arange(ns, device=device).view(7, 256, 256)
+    l2 = lambda I: torch.stack([I + t * N for t in range(2)])
+    seg = torch.cat([torch.zeros(n0, dtype=torch.long, device=device), 1 + torch.arange(7, device=device).repeat_interleave(65536)])
+    return dict(idx=torch.cat([_lay_r6_0(l2(I0)), _lay_r6_stack(l2(IS))]).to(torch.int32).contiguous(), seg=seg)
 
 
 def frag_pack_stack(S):
@@ -369,8 +379,8 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool, trunk=None):
         pk["w8_feat_r6"] = limbs.index_select(0, plan["w8_feat_r6"])  # hold_gemm_r6 pack of lin8's feature rows
     if config.h3():  # two-limb fp16 stream of the forward trunk (csrc/rmlp_h3.hip) + its scales, all on the device
         sw = h3_scales(w0, S)
-        sw9 = torch.cat([sw, torch.ones(1, device=dev)])
-        pk["trunk_h3"] = torch.stack(split_limbs_h(src * sw9[plan["seg"]])).reshape(-1).index_select(0, plan["trunk_h3"])
+        src3 = torch.cat([torch.nn.functional.pad(w0, (0, H3_K0 - spec.K0)).reshape(-1), S.reshape(-1)])
+        pk["trunk_h3"] = torch.stack(split_limbs_h(src3 * sw[plan["h3"]["seg"]])).reshape(-1).index_select(0, plan["h3"]["idx"])
         pk["bias8_h3"] = (bias8 * (sw * H3_ACT_SCALE).view(8, 1)).contiguous()
         pk["c3_h3"] = (1.0 / sw).contiguous()
     if rw is None:  # implicit net only (ImplicitNet.forward / gradient)
