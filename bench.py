@@ -324,8 +324,9 @@ def main():
     else:
         split_rays = args.split == "rays" and world > 1
         if split_rays:  # one frame for the whole job; rank r owns rays [r, r + 1) * W * H / world of it
-            from hold_amd.parallel import ray_tile
+            from hold_amd.parallel import ray_tile, tile_chunks
             lo, hi = ray_tile(W * H, rank, world)
+            n_chunks = tile_chunks(W * H, world, args.chunk)  # every rank runs the same number of forwards (collectives inside)
             b = syn.make_batch(sc, [0], uv[lo:hi], W, H)
             for node in net.nodes.values():
                 node.ray_sampler.sync_group = True
@@ -336,9 +337,11 @@ def main():
         inp = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
         rays_per_step = inp["uv"].shape[1]
         frame_rays = W * H if split_rays else None  # loss normalisation: the whole frame, so that the tiles' gradients add up
+        if not split_rays:
+            n_chunks = None
     def step(i):
         if args.mode in ("render", "c5"):
-            render_frame(net, inp, args.chunk)
+            render_frame(net, inp, args.chunk, n_chunks=n_chunks if args.mode == "render" else None)
             return 0.0
         opt.zero_grad()
         if args.mode == "c3":
@@ -352,7 +355,7 @@ def main():
                 loss.backward()
                 lv = loss.detach()
         else:
-            lv, _ = train_step(net, inp, args.chunk, step=i + 1, epoch=0, loss_fn=loss_fn, n_total=frame_rays)
+            lv, _ = train_step(net, inp, args.chunk, step=i + 1, epoch=0, loss_fn=loss_fn, n_total=frame_rays, n_chunks=n_chunks)
         # ray tiles: the all-reduce must SUM the tiles' gradients (FlatAdam averages over ranks: undo it)
         opt.step(grad_mul=float(world) if (args.mode not in ("c3",) and frame_rays is not None) else 1.0)
         if frozen is not None:  # same weights (hence the same SDF, sampler rounds and FLOP per ray) at every step

@@ -189,7 +189,9 @@ struct SchedEpi {
 #define H3_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define H3_WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xC07F)  // lgkmcnt(0): a real s_waitcnt, which the compiler's own wait insertion sees
 
-template <bool HEAD, bool STORE>
+// ABL (developer builds only, results garbage): bit 0 = v_exp_f32 replaced by a v_mul_f32, bit 1 = v_log_f32 likewise --
+// what the transcendentals cost the k step beyond an ordinary VALU instruction in their place
+template <bool HEAD, bool STORE, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rmlp_h3_kernel(H3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -407,10 +409,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (rd == 0) { st.y[p][c] = P[nt][8 * q + i]; H3_PIN(st.y[p]); }
         else if (rd == 1) { st.y[i] = pk_mul(st.y[i], c3); }
         else if (rd == 2) { st.e[p][c] = KE * fabsf(st.y[p][c]); H3_PIN(st.e[p]); }
-        else if (rd == 3) { st.e[p][c] = exp2_v(st.e[p][c]); H3_PINP(st.e[p]); }
+        else if (rd == 3) {
+          if (ABL & 1) { float t = st.e[p][c] * 1e-3f; H3_PIN(t); st.e[p][c] = t; }
+          else { st.e[p][c] = exp2_v(st.e[p][c]); H3_PINP(st.e[p]); }
+        }
         else if (rd == 4) { st.u[i] = pk_add(st.e[i], ONE2); }
         else if (HEAD) {
-          if (rd == 5) { st.u[p][c] = log2_v(st.u[p][c]); H3_PINP(st.u[p]); }
+          if (rd == 5) {
+            if (ABL & 2) { float t = st.u[p][c] * 0.5f; H3_PIN(t); st.u[p][c] = t; }
+            else { st.u[p][c] = log2_v(st.u[p][c]); H3_PINP(st.u[p]); }
+          }
           else if (rd == 6) { st.r[p][c] = relu1(st.y[p][c]); H3_PIN(st.r[p]); }
           else {
             f32x2 r = pk_fma(st.u[i], CL2, st.r[i]);
@@ -519,6 +527,17 @@ static int rmlp_h3_launch(const H3Args& a, bool head, hipStream_t s) {
   }
   const long blocks = (a.P + BPTS - 1) / BPTS;
   const dim3 grid((unsigned)(blocks < n_cu ? blocks : n_cu));
+#ifdef HOLD_DEV
+  if (const char* v = getenv("HOLD_H3_ABL")) {
+    const int abl = atoi(v);
+    if (head && abl >= 1 && abl <= 3) {
+      auto k = abl == 1 ? rmlp_h3_kernel<true, false, 1> : abl == 2 ? rmlp_h3_kernel<true, false, 2> : rmlp_h3_kernel<true, false, 3>;
+      if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return HOLD_E_LAUNCH;
+      hipLaunchKernelGGL(k, grid, dim3(256), LDS_BYTES, s, a);
+      return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+    }
+  }
+#endif
   if (head)
     hipLaunchKernelGGL((rmlp_h3_kernel<true, false>), grid, dim3(256), LDS_BYTES, s, a);
   else

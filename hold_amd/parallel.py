@@ -52,3 +52,21 @@ def ray_tile(n_rays, rank, world):
     """[lo, hi) of the contiguous ray tile rank `rank` of `world` owns of one frame (bench.py --split rays): balanced -- sizes
     differ by at most one ray, no rank is left without rays while n_rays >= world -- and exhaustive."""
     return n_rays * rank // world, n_rays * (rank + 1) // world
+
+
+def tile_chunks(n_rays, world, chunk_rays):
+    """number of ray chunks EVERY rank runs per step when one frame of n_rays is tiled over `world` ranks (ray_tile) and a
+    rank processes at most chunk_rays rays per forward: ceil(largest tile / chunk_rays).  With the sampler's per-round
+    exchange (ErrorBoundSampler.sync_round) and the Loss's per-step count exchange every forward is a sequence of
+    collectives, so ranks must agree on the NUMBER of forwards: tiles differ by one ray, and ceil(tile / chunk) of each
+    rank's own tile differs across ranks whenever a tile size straddles a multiple of chunk_rays (98 305 rays on 3 ranks in
+    16 384-ray chunks: 2, 2 and 3 forwards) -- the third forward of the last rank would then wait for collectives nobody
+    else issues.  Every rank derives the same number from (n_rays, world, chunk_rays) without communication."""
+    largest = max(hi - lo for lo, hi in (ray_tile(n_rays, r, world) for r in range(world)))
+    return max(1, -(-largest // chunk_rays))
+
+
+def chunk_bounds(n, n_chunks):
+    """[(lo, hi)] of n_chunks balanced, contiguous chunks of n rays (sizes differ by at most one; none empty while
+    n >= n_chunks; an empty tail chunk (lo == hi) otherwise -- callers skip the forward but not the collectives)."""
+    return [(n * c // n_chunks, n * (c + 1) // n_chunks) for c in range(n_chunks)]

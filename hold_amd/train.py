@@ -60,22 +60,32 @@ def training_step(net, loss_fn, batch, epoch=0, step=0):
     return ld["loss"], ld, out
 
 
-def train_step(net, inp, chunk_rays, step=0, epoch=0, loss_fn=None, n_total=None):
+def train_step(net, inp, chunk_rays, step=0, epoch=0, loss_fn=None, n_total=None, n_chunks=None):
     """fwd + loss + bwd over all rays of `inp` (uv [B,P,2]) in chunks of chunk_rays per frame; gradients accumulate in
     .grad.  Per-frame (not per-ray) loss terms -- eikonal, MANO-canonical -- are evaluated with the first chunk only;
     the BARF counter steps once per call (the reference steps it once per training_step).
     ``n_total``: the ray count the ray-wise loss terms are normalised by (default: the rays of ``inp``; a rank that owns a
     ray tile of a frame passes the frame's total so that the ranks' gradients ADD UP to the whole-frame gradient -- the
     opacity-sparsity denominator and the per-frame terms are scaled by the tile's share of the frame, hold_amd.loss.Loss).
+    ``n_chunks``: run exactly this many forwards, over balanced chunks (parallel.chunk_bounds) -- ranks that own ray tiles of
+    one frame pass parallel.tile_chunks(frame rays, world, chunk_rays) so that every rank issues the same sequence of
+    collectives (sampler rounds, loss counts) even when the tiles' own ceil(P / chunk_rays) differ.
     Returns (loss -- a device scalar, read it once per step at most --, rays processed)."""
     B, P = inp["uv"].shape[:2]
     n_total = B * P if n_total is None else int(n_total)
     total = None
     auto = net.auto_step_embedding
     net.auto_step_embedding = False
+    if n_chunks is None:
+        bounds = [(lo, min(P, lo + chunk_rays)) for lo in range(0, P, chunk_rays)]
+    else:
+        from .parallel import chunk_bounds
+        bounds = chunk_bounds(P, int(n_chunks))
+        if any(hi - lo > chunk_rays for lo, hi in bounds) or any(hi == lo for lo, hi in bounds):
+            raise ValueError(f"train_step: {n_chunks} chunks of {P} rays do not fit chunk_rays = {chunk_rays} (or leave a "
+                             "chunk empty): pass parallel.tile_chunks(frame rays, world, chunk_rays)")
     try:
-        for ci, lo in enumerate(range(0, P, chunk_rays)):
-            hi = min(P, lo + chunk_rays)
+        for ci, (lo, hi) in enumerate(bounds):
             c = with_params(net, chunked_input(inp, lo, hi), epoch, step)  # pose-table lookups: one graph per chunk
             c["hold_amd.frame_terms"] = ci == 0
             c["hold_amd.n_total"] = n_total
@@ -95,12 +105,19 @@ def train_step(net, inp, chunk_rays, step=0, epoch=0, loss_fn=None, n_total=None
 
 
 @torch.no_grad()
-def render_frame(net, inp, chunk_rays, keys=("rgb", "normal", "mask_prob", "depth", "instance_map")):
-    """chunked rendering that stays on the device (no per-chunk D2H)."""
+def render_frame(net, inp, chunk_rays, keys=("rgb", "normal", "mask_prob", "depth", "instance_map"), n_chunks=None):
+    """chunked rendering that stays on the device (no per-chunk D2H); ``n_chunks`` as in train_step (ray tiles over ranks)."""
     B, P = inp["uv"].shape[:2]
     outs = {k: [] for k in keys}
-    for lo in range(0, P, chunk_rays):
-        c = chunked_input(inp, lo, min(P, lo + chunk_rays))
+    if n_chunks is None:
+        bounds = [(lo, min(P, lo + chunk_rays)) for lo in range(0, P, chunk_rays)]
+    else:
+        from .parallel import chunk_bounds
+        bounds = chunk_bounds(P, int(n_chunks))
+        if any(hi - lo > chunk_rays or hi == lo for lo, hi in bounds):
+            raise ValueError(f"render_frame: {n_chunks} chunks of {P} rays do not fit chunk_rays = {chunk_rays}")
+    for lo, hi in bounds:
+        c = chunked_input(inp, lo, hi)
         for node in net.nodes.values():
             c.update(node.params(c["idx"]))
         o = net(c)

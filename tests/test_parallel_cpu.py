@@ -272,3 +272,64 @@ def test_ray_tiles_world4_uneven_tiles_run_the_unsharded_rounds(tmp_path):
     parts = [torch.load(out + str(r)) for r in range(4)]
     assert all(p["it"] == it_full for p in parts)
     assert torch.equal(torch.cat([p["z"] for p in parts]), z_full)
+
+
+# ------------------------------------------------------------------------------------------ same number of forwards on every rank
+def test_tile_chunks_give_every_rank_the_same_number_of_forwards():
+    """every forward of a ray tile is a sequence of collectives (sampler rounds, loss counts); with
+    tiles that differ by one ray, ceil(tile / chunk) of each rank's OWN tile can differ across ranks when a tile size
+    straddles a multiple of the chunk (world 3 / 5 / 7, tile ~ k chunk).  parallel.tile_chunks + chunk_bounds: the same
+    count on every rank, balanced non-empty chunks that fit chunk_rays and cover the tile."""
+    from hold_amd.parallel import chunk_bounds, ray_tile, tile_chunks
+    hit = 0
+    for world in (1, 2, 3, 4, 5, 7, 8):
+        for chunk in (16, 100, 16384):
+            for k in (1, 2, 3):
+                for d in (-3, -1, 0, 1, 2, world - 1, world, world + 1):
+                    n = world * k * chunk + d
+                    if n < world:
+                        continue
+                    tiles = [hi - lo for lo, hi in (ray_tile(n, r, world) for r in range(world))]
+                    own = {-(-t // chunk) for t in tiles}
+                    hit += len(own) > 1  # the situation that deadlocked: ranks disagree on ceil(own tile / chunk)
+                    nc = tile_chunks(n, world, chunk)
+                    assert nc == max(own)
+                    for t in tiles:
+                        b = chunk_bounds(t, nc)
+                        assert len(b) == nc and b[0][0] == 0 and b[-1][1] == t
+                        assert all(b[i][1] == b[i + 1][0] for i in range(nc - 1))
+                        assert all(0 < hi - lo <= chunk for lo, hi in b)
+    assert hit > 20  # the cases above do contain the disagreement
+    assert tile_chunks(98305, 3, 16384) == 3 and [-(-(hi - lo) // 16384) for lo, hi in (ray_tile(98305, r, 3) for r in range(3))] == [2, 2, 3]
+
+
+def _chunked_tile_worker(rank, world, port, n, chunk, out):
+    from hold_amd.parallel import chunk_bounds, ray_tile, tile_chunks
+    from hold_amd.sampler import ErrorBoundSampler
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dirs, cam = _rays(n)
+    lo, hi = ray_tile(n, rank, world)
+    smp = ErrorBoundSampler(3.0)
+    smp.sync_group = True
+    calls, rounds = 0, []
+    for a, b in chunk_bounds(hi - lo, tile_chunks(n, world, chunk)):  # one sampler call (a run of per-round collectives) per chunk
+        z, it = _sample(dirs[lo + a:lo + b], cam[lo + a:lo + b], sync=lambda m: smp.sync_round(m, False)[0])
+        calls += 1
+        rounds.append(it)
+    t = torch.tensor([float(calls)])
+    dist.all_reduce(t)  # the step's gradient all-reduce: reached by every rank after the SAME number of sampler calls
+    torch.save(dict(calls=calls, rounds=rounds, total=float(t)), out + str(rank))
+    dist.destroy_process_group()
+
+
+def test_ray_tiles_world3_tiles_straddling_a_chunk_multiple_do_not_deadlock(tmp_path):
+    """3 ranks, 97 rays in chunks of 16: tiles of 32 / 32 / 33 rays -- ceil(own tile / 16) = 2, 2, 3.  With the common chunk
+    count every rank makes 3 sampler calls (each a run of per-round MAX exchanges), agrees on the rounds of every call, and
+    reaches the final all-reduce."""
+    out = str(tmp_path / "c")
+    mp.spawn(_chunked_tile_worker, args=(3, _free_port(), 97, 16, out), nprocs=3, join=True)
+    parts = [torch.load(out + str(r)) for r in range(3)]
+    assert [p["calls"] for p in parts] == [3, 3, 3] and all(p["total"] == 9.0 for p in parts)
+    assert parts[0]["rounds"] == parts[1]["rounds"] == parts[2]["rounds"]

@@ -67,3 +67,39 @@ def test_two_rank_flat_adam_step_equals_single_rank_on_averaged_gradients(tmp_pa
         opt.step()
     ref = opt.flat.cpu()
     assert (p0 - ref).abs().max().item() <= 1e-7 + 1e-6 * ref.abs().max().item()
+
+
+def _rccl_worker(rank, world, port, out):
+    """the collectives of a data-parallel step on the RCCL backend itself (backend "nccl" IS RCCL on ROCm), one rank: the flat
+    gradient all-reduce inside FlatAdam.step, the sampler's per-round MAX exchange on a device tensor, a barrier"""
+    from hold_amd.sampler import ErrorBoundSampler
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    net, opt = _net_opt()
+    before = opt.flat.clone()
+    opt.zero_grad()
+    for p, g in zip(opt.params, _grads(opt, 0)):
+        p.grad.add_(g.cuda())
+    gsum = float(opt.grad.double().sum())
+    scale = opt.allreduce(average=True)  # one RCCL all-reduce of the bucket: identity with one rank
+    assert scale == 1.0 and abs(float(opt.grad.double().sum()) - gsum) <= 1e-9 * abs(gsum)
+    opt.step()
+    smp = ErrorBoundSampler(3.0)
+    smp.sync_group = True
+    mb, err = smp.sync_round(0.375, False, dev="cuda:0")
+    dist.barrier()
+    torch.cuda.synchronize()
+    torch.save(dict(moved=float((opt.flat - before).abs().max()), mb=mb, err=err), out)
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_single_rank_step_and_sampler_exchange(tmp_path):
+    """the RCCL code path is exercised by the driver's GPU suite every round (the 8-GPU run itself is the
+    driver's): process group "nccl" with one rank on the box's GPU -- FlatAdam.step through its all-reduce, the sampler's
+    2-float MAX exchange on the device, barrier, teardown."""
+    out = str(tmp_path / "rccl")
+    mp.spawn(_rccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    r = torch.load(out)
+    assert r["moved"] > 0 and r["mb"] == 0.375 and r["err"] is False

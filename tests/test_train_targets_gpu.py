@@ -528,3 +528,95 @@ def test_ray_tile_losses_of_two_ranks_add_up_to_the_unsharded_loss():
         assert part[k] == pytest.approx(full[k], rel=2e-5), (k, part[k], full[k])
     for k in g_full:
         assert float((g_part[k] - g_full[k]).abs().max()) <= 2e-5 * float(g_full[k].abs().max()), k
+
+
+def test_five_step_trajectory_matches_oracle_with_torch_adam(ctx):
+    """every other training parity test is ONE step; this one carries the cross-step state --
+    the BARF counter (4000 .. 4004), the spawned canonical MANO (forced at the first step, step % 200 == 0), the per-node
+    activation pools and their generation counters, FlatAdam's moments and step count, the weight-pack invalidation after a
+    HIP-side parameter update, the speculative sampler's round prediction -- through FIVE optimiser steps: HOLDNet.forward
+    (HIP sampler in the loop, speculation on) + hold_amd.loss.Loss + backward + FlatAdam.step(clip 0.5) against five oracle
+    steps (oracle forward on the HIP path's z_vals and sample points, the oracle's Loss restatement, torch autograd,
+    clip_grad_norm_(0.5), torch.optim.Adam with the reference's parameter groups: code/src/hold/hold.py:79-101,
+    code/train.py:30), fresh random draws every step.  Held: the loss curve (1e-5 relative per step), the sampler's round
+    counts against the ORACLE's own sampler at the oracle's weights of that step, and after step 5 every parameter tensor
+    within 1e-4 of its norm -- and, the sharper statement, every tensor's five-step UPDATE within 2e-2 of the update's norm
+    (Adam divides by sqrt(v): elements whose gradient is below eps = 1e-8 move by amounts that depend on their last bits)."""
+    from hold_amd.loss import Loss
+    from hold_amd.optim import FlatAdam
+    from oracle import targets_oracle as to
+    sc, sd, osc = ctx["sc"], ctx["sd"], ctx["osc"]
+    sdg = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+    W, frames, epoch = 6, [0, 2], 25
+    N = len(frames) * W * W
+    net = hip_net(sc, ctx["sd_np"], train=True)
+    net.nodes["object"].update_cano(_sphere_mesh(0.08))
+    opt = FlatAdam(net, lr=5e-4, clip_norm=0.5)
+    names = [n for n, p in net.named_parameters() if p.requires_grad and p.numel() and n in sdg]
+    assert len(names) >= 100
+    node_names = [n for n in names if ".params." in n]
+    topt = torch.optim.Adam([{"params": [sdg[n] for n in node_names], "lr": 5e-5},
+                             {"params": [sdg[n] for n in names if n not in node_names], "lr": 5e-4}], lr=5e-4, eps=1e-8)
+    p0 = {n: sdg[n].detach().clone() for n in names}
+    hand, obj = net.nodes["right"], net.nodes["object"]
+    B = len(frames)
+    batch_o = None
+    losses = []
+    for k in range(5):
+        step = 400 + k  # k = 0: step % 200 == 0 -> spawn_cano_mano at the first step
+        rng = _rng(sc, N, seed=11 + k)
+        b, oinp = oracle_input(sc, sdg, frames, W, W)
+        batch_o = {"gt.rgb": torch.from_numpy(b["gt.rgb"]), "gt.mask": torch.from_numpy(b["gt.mask"])}
+        # ---- HIP step
+        inp = hip_input(b, net, epoch=epoch, step=step)
+        opt.zero_grad()
+        out = net(inp, rng=_cuda_rng(rng))
+        assert int(obj.implicit_network.embedder_obj.alpha_iter) == 4001 + k  # the BARF counter steps once per training forward
+        rounds = {n: net.nodes[n].ray_sampler.last_iters for n in sc["entities"]}
+        lh = Loss()(inp, out)
+        lh["loss"].backward()
+        # ---- the oracle's own sampler at the oracle's weights of this step: same number of rounds
+        ex_s = {}
+        with torch.no_grad():
+            ho.holdnet_forward(osc, {kk: (v.detach() if torch.is_tensor(v) else v) for kk, v in sdg.items()},
+                               {kk: (v.detach() if torch.is_tensor(v) else v) for kk, v in oinp.items()}, True, rng=rng,
+                               current_epoch=epoch, barf_alpha_iter=4000 + k, extras=ex_s)
+        for n in sc["entities"]:
+            assert ex_s[n]["iters"] == rounds[n], (k, n, ex_s[n]["iters"], rounds[n])
+        # ---- oracle step on the HIP path's z_vals and drawn sample points
+        zo = {n: out[n + ".z_vals"].detach().cpu() for n in sc["entities"]}
+        ex = {}
+        oo = ho.holdnet_forward(osc, sdg, oinp, True, rng=rng, z_override=zo, current_epoch=epoch, barf_alpha_iter=4000 + k,
+                                extras=ex, stable_merge=True)
+        oo["step"], oo["epoch"] = step, epoch
+        bw = ho.barf_weights(4000 + k, 6, 3)
+        tg = to.loss_targets_hand(sdg, "right", hand.mesh_v_cano_div.cpu(), hand.mesh_f_cano_div.cpu(),
+                                  ex["right"]["x_c"].detach().view(B, -1, 3), hand._last_targets["mano_cano_samples"].cpu(),
+                                  hand._last_targets["eikonal_samples"].cpu(), N)
+        tg.update(to.loss_targets_object(sdg, "object", obj.mesh_vo_cano[0].cpu(), obj.mesh_fo_cano.cpu(),
+                                         ex["object"]["x_c"].detach().view(B, -1, 3), obj._last_targets["eikonal_samples"].cpu(),
+                                         N, embed_w=bw))
+        oo.update(tg)
+        for nid in ("right", "object"):  # borderline rays of the off-surface test: the same index set for both losses
+            oo[f"{nid}.index_off_surface"] = out[f"{nid}.index_off_surface"].cpu()
+        lo = to.loss_forward(batch_o, oo)
+        losses.append((float(lo["loss"]), float(lh["loss"])))
+        assert float(lh["loss"]) == pytest.approx(float(lo["loss"]), rel=1e-5), (k, losses)
+        topt.zero_grad()
+        lo["loss"].backward()
+        torch.nn.utils.clip_grad_norm_([sdg[n] for n in names], 0.5)
+        topt.step()
+        opt.step()
+    assert opt.step_count == 5
+    worst_p, worst_d = ("", 0.0), ("", 0.0)
+    pn = dict(net.named_parameters())
+    for n in names:
+        ph, po = pn[n].detach().cpu().double(), sdg[n].detach().double()
+        rp = float((ph - po).norm() / (po.norm() + 1e-30))
+        dh, do = ph - p0[n].double(), po - p0[n].double()
+        rd = float((dh - do).norm() / (do.norm() + 1e-30)) if float(do.norm()) > 0 else 0.0
+        worst_p = max(worst_p, (n, rp), key=lambda t: t[1])
+        worst_d = max(worst_d, (n, rd), key=lambda t: t[1])
+    print(f"five-step trajectory: losses {losses}; worst parameter error {worst_p}; worst update error {worst_d}")
+    assert worst_p[1] < 1e-4, worst_p
+    assert worst_d[1] < 2e-2, worst_d
