@@ -42,8 +42,12 @@ __global__ void face_setup_kernel(const float* __restrict__ v3d, int V, const in
   o.ymin = fminf(fminf(y[0], y[1]), y[2]) - r;
   o.ymax = fmaxf(fmaxf(y[0], y[1]), y[2]) + r;
   const float area = (x[1] - x[0]) * (y[2] - y[0]) - (y[1] - y[0]) * (x[2] - x[0]);
-  o.valid = (fabsf(area) > 1e-8f && fminf(fminf(z[0], z[1]), z[2]) > 0.f) ? 1.f : 0.f;
-  o.pad = 0.f;
+  const float zmin = fminf(fminf(z[0], z[1]), z[2]), zmax = fmaxf(fmaxf(z[0], z[1]), z[2]);
+  o.valid = (fabsf(area) > 1e-8f && zmin > 0.f) ? 1.f : 0.f;
+  // a face that STRADDLES the image plane (some vertices behind the camera, some in front): pytorch3d drops it per pixel
+  // (interpolated depth < 0, rasterize_meshes.cu), this kernel as a whole -- the two agree only while no such face exists;
+  // hold_silhouette_max_faces reports them (pad = 1) so that the caller can refuse the configuration
+  o.pad = (zmin <= 0.f && zmax > 0.f && fabsf(area) > 1e-8f) ? 1.f : 0.f;
   fs[i] = o;
 }
 
@@ -75,6 +79,7 @@ __device__ __forceinline__ bool face_dist(const FaceSetup& f, float px, float py
 }
 
 constexpr int TILE = 16, LIST = 1024;
+constexpr int HOLD_SILHOUETTE_STRADDLE = 1 << 30;  // hold_silhouette_max_faces: "a face straddles the image plane"
 
 template <bool BWD>
 __global__ __launch_bounds__(256) void silhouette_kernel(const FaceSetup* __restrict__ fs, const int* __restrict__ faces,
@@ -270,10 +275,11 @@ __global__ __launch_bounds__(256) void silhouette_count_kernel(const FaceSetup* 
     const FaceSetup* fb = fs + (long)b * F;
     for (int f = 0; f < F; ++f) {
       const FaceSetup cur = fb[f];
+      if (cur.pad != 0.f) cnt = HOLD_SILHOUETTE_STRADDLE;  // see face_setup_kernel
       if (cur.valid == 0.f || cur.xmax < px || cur.xmin > px || cur.ymax < py || cur.ymin > py) continue;
       float d, t;
       int e;
-      if (face_dist(cur, px, py, blur, d, e, t)) ++cnt;
+      if (face_dist(cur, px, py, blur, d, e, t) && cnt < HOLD_SILHOUETTE_STRADDLE) ++cnt;
     }
   }
 #pragma unroll

@@ -80,6 +80,10 @@ def max_faces_per_pixel(v3d_c, faces, fx, fy, cx, cy, H, W, blur=BLUR):
 def check_faces_per_pixel(v3d_c, faces, fx, fy, cx, cy, H, W, blur=BLUR):
     """raise if pytorch3d's K = 100 nearest-faces cap would be active (then the uncapped product differs from it)."""
     k = max_faces_per_pixel(v3d_c, faces, fx, fy, cx, cy, H, W, blur)
+    if k >= (1 << 30):
+        raise NotImplementedError("a face straddles the image plane (vertices behind AND in front of the camera): the reference "
+                                  "rasteriser drops such a face per pixel on the interpolated depth (pytorch3d rasterize_meshes), "
+                                  "hold_silhouette_fwd drops it as a whole -- the two agree only for meshes in front of the camera")
     if k > FACES_PER_PIXEL:
         raise NotImplementedError(f"{k} faces overlap one pixel: the reference rasteriser keeps only the {FACES_PER_PIXEL} "
                                   "nearest (fitting/utils.py:107); hold_silhouette_fwd multiplies over all of them")

@@ -60,10 +60,16 @@ def _seg_d2(p, a, b):
     return ((p - q) ** 2).sum(-1)
 
 
-def soft_silhouette(v3d_c, faces, fx, fy, cx, cy, H, W, sigma=SIGMA, blur=BLUR, chunk=2048, return_count=False):
+def soft_silhouette(v3d_c, faces, fx, fy, cx, cy, H, W, sigma=SIGMA, blur=BLUR, chunk=2048, return_count=False, cull="pixel"):
     """v3d_c [B,V,3] camera-space vertices, faces [F,3] -> alpha [B,H,W] (and, with return_count, the number of faces
     contributing to each pixel [B,H,W]: the rasteriser of the reference keeps at most faces_per_pixel = 100 of them,
-    fitting/utils.py:107 -- the product over all faces below equals it while that count stays <= 100)."""
+    fitting/utils.py:107 -- the product over all faces below equals it while that count stays <= 100).
+    cull: "pixel" (default) = pytorch3d's rule as published (rasterize_meshes.cu, CheckPixelInsideFace / the naive kernel): a
+    face whose largest vertex depth is < 0 is skipped, and a (pixel, face) pair is skipped when the depth interpolated with
+    the perspective-corrected, clipped barycentric coordinates of the pixel is < 0 (perspective_correct and
+    clip_barycentric_coords both default to True for a perspective camera with blur_radius > 0); "face" = the HIP kernel's
+    rule (skip a face unless ALL its vertices are in front of the camera).  The two agree for meshes in front of the camera
+    (tests/test_host_cpu.py); hold_amd.fitting.check_faces_per_pixel refuses the configurations where they do not."""
     B = v3d_c.shape[0]
     ndc = to_ndc(v3d_c, fx, fy, cx, cy, H, W)  # [B,V,2]
     z = v3d_c[..., 2]
@@ -88,7 +94,19 @@ def soft_silhouette(v3d_c, faces, fx, fy, cx, cy, H, W, sigma=SIGMA, blur=BLUR, 
             area = (bb[..., 0] - a[..., 0]) * (cc[..., 1] - a[..., 1]) - (bb[..., 1] - a[..., 1]) * (cc[..., 0] - a[..., 0])
             d2 = torch.minimum(torch.minimum(_seg_d2(p, a, bb), _seg_d2(p, bb, cc)), _seg_d2(p, cc, a))
             d = torch.where(inside, -d2, d2)
-            valid = (inside | (d2 < blur)) & (area.abs() > 1e-8) & (zf.min(-1).values[None] > 0)
+            valid = (inside | (d2 < blur)) & (area.abs() > 1e-8)
+            if cull == "face":
+                valid = valid & (zf.min(-1).values[None] > 0)
+            else:
+                z0, z1, z2 = zf[None, :, 0], zf[None, :, 1], zf[None, :, 2]
+                sa = torch.where(area.abs() > 1e-8, area, torch.ones_like(area))
+                w0, w1, w2 = e1 / sa, e2 / sa, e0 / sa  # barycentric weights of a, b, c (unclipped)
+                t0, t1, t2 = w0 * z1 * z2, z0 * w1 * z2, z0 * z1 * w2  # BarycentricPerspectiveCorrectionForward
+                den = torch.clamp(t0 + t1 + t2, min=1e-8)
+                q0, q1, q2 = (torch.clamp(t / den, min=0.0) for t in (t0, t1, t2))  # BarycentricClipForward (lower bound only)
+                qs = torch.clamp(q0 + q1 + q2, min=1e-5)
+                pz = (q0 * z0 + q1 * z1 + q2 * z2) / qs
+                valid = valid & (zf.max(-1).values[None] >= 0) & (pz >= 0)
             # 1 - prob = sigmoid(d / sigma)
             l1mp = torch.nn.functional.logsigmoid(d / sigma)
             logacc[c0:c0 + chunk] = torch.where(valid, l1mp, torch.zeros_like(l1mp)).sum(-1)

@@ -481,3 +481,39 @@ def test_flat_adam_state_interchange_with_torch_adam_and_rehome_errors():
     opt.flat = torch.empty(opt.n, device="meta")  # (no second real device here: the bucket "lives elsewhere")
     with pytest.raises(RuntimeError):
         opt.rehome()
+
+
+def test_silhouette_oracle_per_pixel_depth_cull_follows_pytorch3d():
+    """the rasteriser oracle culled a face when ANY vertex lay behind the camera; pytorch3d
+    (rasterize_meshes.cu) skips a face only when ALL do (zmax < 0) and otherwise drops (pixel, face) pairs whose interpolated
+    depth -- perspective-corrected, clipped barycentric weights -- is negative.  The oracle now restates that rule
+    (cull="pixel", its default); for meshes in front of the camera -- the only configuration hold_amd.fitting accepts, see
+    check_faces_per_pixel -- it equals the whole-face rule of the HIP kernel (cull="face") bit for bit, and for a triangle
+    that straddles the image plane the two differ, which is what the check refuses."""
+    import sys
+    import numpy as np
+    import torch
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle import fitting_oracle as fo
+    g = torch.Generator().manual_seed(0)
+    v = torch.randn(2, 30, 3, generator=g) * 0.03
+    v[..., 2] += 0.5
+    f = torch.randint(0, 30, (40, 3), generator=g)
+    sig = 1e-4
+    blur = float(np.log(1 / 1e-4 - 1) * sig)
+    args = (300.0, 300.0, 32.0, 32.0, 64, 64, sig, blur)
+    a = fo.soft_silhouette(v, f, *args)
+    b = fo.soft_silhouette(v, f, *args, cull="face")
+    assert 0.02 < float(a.mean()) < 0.9 and torch.equal(a, b)
+    # one large triangle with one vertex behind the camera: dropped as a whole by the face rule, kept by pytorch3d's where the
+    # interpolated depth is >= 0
+    tri = torch.tensor([[[-0.05, -0.05, 0.5], [0.05, -0.05, 0.5], [0.0, 0.4, -0.1]]])
+    ft = torch.tensor([[0, 1, 2]])
+    a = fo.soft_silhouette(tri, ft, *args)
+    b = fo.soft_silhouette(tri, ft, *args, cull="face")
+    assert float(b.abs().max()) == 0.0 and float(a.max()) > 0.01
+    # all vertices behind the camera: nothing is drawn under either rule
+    behind = tri.clone()
+    behind[..., 2] = -behind[..., 2].abs()
+    assert float(fo.soft_silhouette(behind, ft, *args).abs().max()) == 0.0
