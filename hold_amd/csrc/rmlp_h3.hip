@@ -189,8 +189,9 @@ struct SchedEpi {
 #define H3_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define H3_WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xC07F)  // lgkmcnt(0): a real s_waitcnt, which the compiler's own wait insertion sees
 
-// ABL (developer builds only, results garbage): bit 0 = v_exp_f32 replaced by a v_mul_f32, bit 1 = v_log_f32 likewise --
-// what the transcendentals cost the k step beyond an ordinary VALU instruction in their place
+// ABL (developer builds only, results garbage): bit 0 = v_exp_f32 replaced by a v_mul_f32, bit 1 = v_log_f32 likewise (what the
+// transcendentals cost the k step beyond an ordinary VALU instruction in their place: nothing, GPU call 6); bit 2 = no LDS-DMA
+// in the k steps, bit 3 = no fragment reads (the first step's fragments are reused), bit 4 = no rendezvous barrier
 template <bool HEAD, bool STORE, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rmlp_h3_kernel(H3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -284,7 +285,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const int slot = ts % RING;
 #pragma unroll
       for (int pair = 0; pair < 4; ++pair) {
-        if (pair == 2) {  // mid-step rendezvous: the next step complete in LDS, the previous step's slot free
+        if (pair == 2 && !(ABL & 16)) {  // mid-step rendezvous: the next step complete in LDS, the previous step's slot free
+          if (ABL & 4) H3_WAIT_VM(0); else
           H3_WAIT_VM(4 * (AHEAD - 2));
           __builtin_amdgcn_s_barrier();
         }
@@ -296,8 +298,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           Q[2 * pair + tl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[pair & 1][2 * tl + wl]),
                                                                    __builtin_bit_cast(f16x8, Bc.l[al]), Q[2 * pair + tl],
                                                                    0, 0, 0);
-          if (m < 4) A[(pair + 1) & 1][m] = *reinterpret_cast<const u32x4*>(rd + m * PIECE);
-          if (pair >= 2 && m == 1)
+          if (m < 4 && !(ABL & 8)) A[(pair + 1) & 1][m] = *reinterpret_cast<const u32x4*>(rd + m * PIECE);
+          if (pair >= 2 && m == 1 && !(ABL & 4))
             dma_pair(src + (pair & 1) * (2 * PIECE), lane16,
                      wdst0 + (uint32_t)(((ts + AHEAD) % RING) * SLOT + (pair & 1) * (2 * PIECE)));
           const int G = 6 * pair + m;
@@ -338,12 +340,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
 
     // ---- layer 0: B limbs straight from the (scaled) embedding (natural k order 16 j + 8 hh + e; the fourth k step is
-    // padding: its weights are zero, its B limbs whatever finite numbers follow the embedding in LDS) ----
+    // padding: zero weights, zero B limbs) ----
     SplitState ss;
     auto emb_mop = [&](int j, int k, Limbs& out) {  // k = 0..15: round-major over the four dwords
       const int op = k >> 2, d = k & 3;
       const float* er = embw + li * EMB_STR + 16 * j + 8 * hh + 2 * d;
-      split_op(op, d, er[0], er[1], out, ss);
+      // the padding k step (j = 3, columns 48..63) gets ZERO limbs, not what lies behind the embedding in LDS: columns 48..51 of
+      // a point's row are never written, and a stale bit pattern there that converts to an fp16 inf / NaN times a zero weight is
+      // a NaN in every accumulator (call 4 / 5 of round 5: wrong sdf -> a sampler window out of range -> a memory fault two
+      // kernels later; the unit tests, which start from a quiet LDS, passed)
+      const bool pad = 16 * j >= 48;
+      split_op(op, d, pad ? 0.f : er[0], pad ? 0.f : er[1], out, ss);
     };
     init_bias(0);
 #pragma unroll
@@ -501,6 +508,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
   }
+  H3_WAIT_VM(0);  // the stream runs AHEAD steps past the last block: no LDS-DMA may be in flight when the workgroup's LDS is released
 }
 
 }  // namespace
@@ -530,8 +538,10 @@ static int rmlp_h3_launch(const H3Args& a, bool head, hipStream_t s) {
 #ifdef HOLD_DEV
   if (const char* v = getenv("HOLD_H3_ABL")) {
     const int abl = atoi(v);
-    if (head && abl >= 1 && abl <= 3) {
-      auto k = abl == 1 ? rmlp_h3_kernel<true, false, 1> : abl == 2 ? rmlp_h3_kernel<true, false, 2> : rmlp_h3_kernel<true, false, 3>;
+    if (head && abl >= 1) {
+      auto k = abl == 3 ? rmlp_h3_kernel<true, false, 3> : abl == 4 ? rmlp_h3_kernel<true, false, 4> : abl == 8 ? rmlp_h3_kernel<true, false, 8>
+             : abl == 12 ? rmlp_h3_kernel<true, false, 12> : abl == 16 ? rmlp_h3_kernel<true, false, 16> : abl == 28 ? rmlp_h3_kernel<true, false, 28>
+             : rmlp_h3_kernel<true, false, 31>;
       if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return HOLD_E_LAUNCH;
       hipLaunchKernelGGL(k, grid, dim3(256), LDS_BYTES, s, a);
       return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;

@@ -207,3 +207,44 @@ def test_h3_error_against_fp64_is_within_one_and_a_half_of_r6_on_half_a_million_
               f"h3 max {e3.max().item():.3e} rms {e3.pow(2).mean().sqrt().item():.3e}")
         assert e3.max().item() <= 1.5 * e6.max().item(), (seed, e3.max().item(), e6.max().item())
         assert e3.pow(2).mean().sqrt().item() <= 1.5 * e6.pow(2).mean().sqrt().item()
+
+
+def test_h3_kernels_do_not_depend_on_stale_lds():
+    """round 5, GPU calls 4 / 5: the padded fourth k step of layer 0 read LDS bytes no one had written; zero weights times a
+    stale inf / NaN bit pattern made every accumulator NaN -- invisible to the tests above, which start from a quiet LDS.
+    Here every compute unit's LDS is filled with NaN first (the whole-dW weight gradient stages its operand rows in a
+    128 KiB ring: all-NaN operands on 256 workgroups), then the h3 kernels must return bit for bit what they return
+    after a zero fill."""
+    import hold_amd
+    from hold_amd import gemm, kernels as K
+    dev = _dev()
+    P = 128 * 256 * 2
+    w0, S, bias, w8, bw = _net(3, dev, True)
+    g = torch.Generator().manual_seed(9)
+    xc = torch.zeros(P, 4)
+    xc[:, :3] = torch.rand(P, 3, generator=g) * 1.6 - 0.8
+    xc = xc.to(dev)
+    pk, bs, c3 = _h3_pack(w0, S, bias)
+    b8 = torch.full((1,), 0.25, device=dev)
+    prev = hold_amd.precision()
+    hold_amd.set_precision("f32x6")
+    try:
+        res = []
+        for fill in (0.0, float("nan"), float("inf")):
+            R = torch.full((16 * 4096, 256), fill, device=dev)
+            dW = torch.empty(256, 256, device=dev)
+            gemm.wgrad(R, R, dW, None)  # 256 workgroups x a 128 KiB LDS ring of `fill`
+            out = torch.empty(P, 1, device=dev)
+            K.fused_sdf_h3(xc, P, pk, bs, c3, w8, b8, bw, out)
+            gemm.wgrad(R, R, dW, None)
+            h = [torch.empty(P, 256, device=dev) for _ in range(8)]
+            K.trunk_h3(xc, P, pk, bs, c3, bw, h)
+            torch.cuda.synchronize()
+            res.append((out, h))
+        for out, h in res[1:]:
+            assert torch.isfinite(out).all()
+            assert torch.equal(out, res[0][0])
+            for a, b in zip(h, res[0][1]):
+                assert torch.equal(a, b)
+    finally:
+        hold_amd.set_precision(prev)
