@@ -66,6 +66,76 @@ def test_silhouette_backward():
     assert rel < 2e-2, rel
 
 
+def _perturbed(verts, rel, seed):
+    g = torch.Generator().manual_seed(seed)
+    return verts * (1.0 + rel * (2.0 * torch.rand(verts.shape, generator=g, dtype=verts.dtype) - 1.0))
+
+
+def test_silhouette_at_the_reference_sigma_under_a_conditioning_aware_bound():
+    """at the reference's sigma = 1e-6 (fitting/utils.py:101-118) the silhouette is a step function of the
+    signed squared NDC distance d: alpha moves from 0 to 1 while d crosses a band 1e-5 wide, so the fp32 rounding of the NDC
+    arithmetic (relative 1e-7 of coordinates of order 1, i.e. 1e-7 in d) decides alpha at the pixels whose centre lies within
+    that band of an edge -- for ANY fp32 implementation, pytorch3d's included.  As for the sampler's inverse CDF
+    (oracle.inv_cdf_conditioning), the test therefore measures how far the fp64 oracle's alpha moves at each pixel when the
+    vertices move by fp32-sized noise (relative 2e-7, eight draws) and holds the HIP kernel, forward AND backward, to
+        |alpha_hip - alpha_fp64| <= 1e-4 + 4 x spread(pixel)
+    -- 1e-4 at every well-conditioned pixel (spread < 1e-5: all but the edge band) -- and the vertex gradient of a weighted sum
+    of alpha to 1e-3 of its norm + 4 x the spread of the fp64 gradient under the same noise."""
+    from hold_amd import fitting as ft
+    net, verts, faces = _scene_verts(1)
+    H = W = 64
+    fx = fy = 300.0
+    cx = cy = 32.0
+    sigma = 1e-6
+    blur = np.log(1.0 / 1e-4 - 1.0) * sigma
+    g = torch.Generator().manual_seed(0)
+    wgt = torch.rand(1, H, W, generator=g, dtype=torch.float64)
+    v = verts.clone().requires_grad_(True)
+    vs, fs = ft.seal_mano_mesh(v, faces, True)
+    m = ft.soft_silhouette(vs, fs, fx, fy, cx, cy, H, W, sigma, blur)
+    (m * wgt.float().cuda()).sum().backward()
+    m = m.detach().cpu().double()
+    gh = v.grad.cpu().double()
+
+    def oracle(vin):
+        vc = vin.clone().requires_grad_(True)
+        vo, fo_ = fo.seal_mano_mesh(vc, faces.cpu(), True)
+        a = fo.soft_silhouette(vo, fo_, fx, fy, cx, cy, H, W, sigma, blur)
+        (a * wgt).sum().backward()
+        return a.detach(), vc.grad.detach()
+
+    v64 = verts.cpu().double()
+    ref, gref = oracle(v64)
+    assert 0.03 < float(ref.mean()) < 0.9
+    spread = torch.zeros_like(ref)
+    gspread = 0.0
+    for k in range(8):
+        a, gk = oracle(_perturbed(v64, 2e-7, k))
+        spread = torch.maximum(spread, (a - ref).abs())
+        gspread = max(gspread, float((gk - gref).norm()))
+    err = (m - ref).abs()
+    well = spread < 1e-5
+    print(f"sigma 1e-6: {float((~well).double().mean()) * 100:.2f} % of the pixels are edge-band pixels; max err well-conditioned "
+          f"{float(err[well].max()):.2e}, edge band {float(err[~well].max()) if (~well).any() else 0.0:.2e} (spread up to {float(spread.max()):.2e}); "
+          f"gradient: |g_hip - g_64| / |g_64| = {float((gh - gref).norm() / gref.norm()):.2e}, fp64 spread / |g_64| = {gspread / float(gref.norm()):.2e}")
+    assert float(well.double().mean()) > 0.9
+    assert bool((err <= 1e-4 + 4.0 * spread).all()), float((err - 4.0 * spread).max())
+    assert float((gh - gref).norm()) <= 1e-3 * float(gref.norm()) + 4.0 * gspread
+
+
+def test_faces_straddling_the_image_plane_are_refused():
+    """hold_silhouette_fwd drops a face with a vertex behind the camera as a whole, pytorch3d per pixel (oracle cull='pixel'):
+    check_faces_per_pixel -- the guard Model.forward calls once per fit -- must refuse such a configuration"""
+    from hold_amd import fitting as ft
+    tri = torch.tensor([[[-0.05, -0.05, 0.5], [0.05, -0.05, 0.5], [0.0, 0.4, -0.1]]], device="cuda")
+    faces = torch.tensor([[0, 1, 2]], device="cuda")
+    with pytest.raises(NotImplementedError, match="straddles"):
+        ft.check_faces_per_pixel(tri, faces, 300.0, 300.0, 32.0, 32.0, 64, 64)
+    front = tri.clone()
+    front[..., 2] = 0.5
+    assert ft.check_faces_per_pixel(front, faces, 300.0, 300.0, 32.0, 32.0, 64, 64) >= 1
+
+
 def test_knn1():
     from hold_amd import fitting as ft
     g = torch.Generator().manual_seed(1)

@@ -576,11 +576,10 @@ def test_five_step_trajectory_matches_oracle_with_torch_adam(ctx):
         lh = Loss()(inp, out)
         lh["loss"].backward()
         # ---- the oracle's own sampler at the oracle's weights of this step: same number of rounds
-        ex_s = {}
-        with torch.no_grad():
-            ho.holdnet_forward(osc, {kk: (v.detach() if torch.is_tensor(v) else v) for kk, v in sdg.items()},
-                               {kk: (v.detach() if torch.is_tensor(v) else v) for kk, v in oinp.items()}, True, rng=rng,
-                               current_epoch=epoch, barf_alpha_iter=4000 + k, extras=ex_s)
+        ex_s = {}  # (detached copies: no graph; the oracle's normal path needs autograd enabled for d sdf / d x)
+        ho.holdnet_forward(osc, {kk: (v.detach() if torch.is_tensor(v) else v) for kk, v in sdg.items()},
+                           {kk: (v.detach() if torch.is_tensor(v) else v) for kk, v in oinp.items()}, True, rng=rng,
+                           current_epoch=epoch, barf_alpha_iter=4000 + k, extras=ex_s)
         for n in sc["entities"]:
             assert ex_s[n]["iters"] == rounds[n], (k, n, ex_s[n]["iters"], rounds[n])
         # ---- oracle step on the HIP path's z_vals and drawn sample points
