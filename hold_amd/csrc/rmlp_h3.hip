@@ -187,7 +187,7 @@ struct SchedEpi {
 };
 
 #define H3_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-#define H3_WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xC07F)  // lgkmcnt(0): a real s_waitcnt, which the compiler's own wait insertion sees
+#define H3_WAIT_LDS3() __builtin_amdgcn_s_waitcnt(0xC37F)  // lgkmcnt(3): a real s_waitcnt, which the compiler's own wait insertion sees
 
 // ABL (developer builds only, results garbage): bit 0 = v_exp_f32 replaced by a v_mul_f32, bit 1 = v_log_f32 likewise (what the
 // transcendentals cost the k step beyond an ordinary VALU instruction in their place: nothing, GPU call 6); bit 2 = no LDS-DMA
@@ -272,6 +272,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       H3_WAIT_VM(4 * (AHEAD - 1));
       __builtin_amdgcn_s_barrier();
       read_pair(0, 0, A[0]);
+      A[1][0] = *reinterpret_cast<const u32x4*>(ring_lane + 4 * PIECE);  // group 1's fragments 0, 2, 1 (its 3 follows behind MFMA 0)
+      A[1][2] = *reinterpret_cast<const u32x4*>(ring_lane + 6 * PIECE);
+      A[1][1] = *reinterpret_cast<const u32x4*>(ring_lane + 5 * PIECE);
       first = 0;
     }
 
@@ -290,7 +293,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           H3_WAIT_VM(4 * (AHEAD - 2));
           __builtin_amdgcn_s_barrier();
         }
-        const char* rd = ring_lane + (pair < 3 ? slot * SLOT + (pair + 1) * (4 * PIECE) : ((ts + 1) % RING) * SLOT);
+        // fragment f (0 = tile 0 hi, 1 = tile 0 lo, 2 = tile 1 hi, 3 = tile 1 lo) of group tp of this step (tp >= 4: group
+        // tp - 4 of the next step, complete in LDS behind the rendezvous)
+        auto frag = [&](int tp, int f) {
+          return *reinterpret_cast<const u32x4*>(ring_lane + (tp < 4 ? slot : (ts + 1) % RING) * SLOT + (tp & 3) * (4 * PIECE) + f * PIECE);
+        };
 #pragma unroll
         for (int m = 0; m < 6; ++m) {
           const int pr = m >> 1, tl = m & 1;           // (w limb, act limb): hi hi, hi lo, lo hi
@@ -298,7 +305,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           Q[2 * pair + tl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[pair & 1][2 * tl + wl]),
                                                                    __builtin_bit_cast(f16x8, Bc.l[al]), Q[2 * pair + tl],
                                                                    0, 0, 0);
-          if (m < 4 && !(ABL & 8)) A[(pair + 1) & 1][m] = *reinterpret_cast<const u32x4*>(rd + m * PIECE);
+          // Fragment reads, each into the register quad its last MFMA has just left (the MFMAs of a group use the fragments in
+          // the order 0 2 0 2 1 3): fragments 0, 2, 1 of the group AFTER NEXT behind the MFMAs 3, 4, 5, fragment 3 of the next
+          // group behind MFMA 0 -- a read is 5 to 9 MFMAs ahead of its wait instead of 2 to 5 (the fragment reads, not the
+          // matrix pipe, bounded the first version: without them the k step ran in 541 instead of 717 ns, GPU call 8)
+          if (!(ABL & 8)) {
+            if (m == 0) A[(pair + 1) & 1][3] = frag(pair + 1, 3);
+            if (m == 3) A[pair & 1][0] = frag(pair + 2, 0);
+            if (m == 4) A[pair & 1][2] = frag(pair + 2, 2);
+            if (m == 5) A[pair & 1][1] = frag(pair + 2, 1);
+          }
           if (pair >= 2 && m == 1 && !(ABL & 4))
             dma_pair(src + (pair & 1) * (2 * PIECE), lane16,
                      wdst0 + (uint32_t)(((ts + AHEAD) % RING) * SLOT + (pair & 1) * (2 * PIECE)));
@@ -309,9 +325,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (k < S::end(G)) mop(S::op(k));
           }
           // ONE LDS wait per group, at the end of the gap in front of it (inside this scheduling region, so that the next
-          // group's first MFMA cannot be hoisted above it and get a wait of its own): the four fragments of the next group,
-          // read behind the first four MFMAs of this one.  A real s_waitcnt: the compiler's wait insertion accounts for it.
-          if (m == 5) H3_WAIT_LDS();
+          // group's first MFMA cannot be hoisted above it and get a wait of its own): everything but the three most recent
+          // reads (the group after next's) has landed, i.e. the next group's four fragments.  A real s_waitcnt: the compiler's
+          // wait insertion accounts for it.
+          if (m == 5) H3_WAIT_LDS3();
           __builtin_amdgcn_sched_barrier(0);
         }
       }
