@@ -57,6 +57,12 @@ def parse():
     ap.add_argument("--loss", default="full", choices=["pixel", "full"])
     ap.add_argument("--two-hands", action="store_true", help="ARCTIC-style scene (right + left + object), config C4")
     ap.add_argument("--fp32-mfma", action="store_true", help="true-fp32 MFMA everywhere (no split-precision kernels)")
+    ap.add_argument("--beta", type=float, default=None,
+                    help="Laplace density beta of the foreground nodes (default: the synthetic scene's 0.1, the reference's "
+                         "INITIAL value, density.py:21-30; a trained HOLD model has beta ~ 0.005: sdf -> density is then an exact "
+                         "fp32 zero half a scene unit off the surface and exact sample compaction has something to drop)")
+    ap.add_argument("--no-compact", action="store_true",
+                    help="A/B: run every sample through every stage (hold_amd.field.COMPACT = False)")
     ap.add_argument("--precision", default=None, choices=["f32", "f32x6", "f16x3"],
                     help="arithmetic of the MFMA kernels (hold_amd/config.py); default: the package default")
     ap.add_argument("--no-profile", action="store_true")
@@ -284,6 +290,13 @@ def main():
     n_frames = max(16, world) if args.mode == "c3" else max(8, world)
     sc = syn.make_scene(n_frames=n_frames, two_hands=args.two_hands)
     sd_np = syn.make_state_dict(sc, barf_iter=3999)
+    if args.beta is not None:
+        for k in sd_np:
+            if k.startswith("nodes.") and k.endswith(".density.beta"):
+                sd_np[k] = np.float32(args.beta - 1e-4)  # get_beta() = |beta| + beta_min (1e-4)
+    if args.no_compact:
+        from hold_amd import field as _fld
+        _fld.COMPACT = False
     sampler_opt = dict(DEFAULT_SAMPLER, N_samples=128) if args.mode == "c5" else None
     net = hold_amd.build_from_scene(sc, sd_np, device=dev, sampler_opt=sampler_opt)
     for node in net.nodes.values():
@@ -520,6 +533,13 @@ def main():
                        "which the query kernels rightly do not compute (0.918 vs 1.049 MFLOP per point): roofline.end_to_end."
                        "executed_tflops_end_to_end counts the FLOP the MFMA kernels execute",
                        "weights_frozen": frozen is not None,
+                       "density_beta": {nid: node.density.beta_host() for nid, node in net.nodes.items()},
+                       "sample_compaction": {"enabled": bool(__import__("hold_amd.field", fromlist=["COMPACT"]).COMPACT),
+                                             "live_samples_last_call": {nid: getattr(node.field, "last_live", None)
+                                                                        for nid, node in net.nodes.items()},
+                                             "note": "exact: a sample is dropped behind the sdf only when its Laplace density AND "
+                                                     "exp(-|sdf|/beta) are fp32 zeros (hold_amd/csrc/compact.hip); None = every "
+                                                     "sample of the last call was live"},
                        "loss_terms": args.loss if training else None,
                        "parallelism": (f"dp{world} (ONE frame, ray tiles per rank, sampler rounds synchronised by a 2-float MAX "
                                        "all-reduce, one RCCL all-reduce (sum) of the flat gradient bucket)"

@@ -173,6 +173,8 @@ SIGNATURES = {
     "hold_fused_sdf_x6": [_P, _I, _L, _P, _P, _P, _F, _P, _P, _I, _P],
     "hold_fused_sdf_r6": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _I, _P],
     "hold_trunk_r6": [_P, _I, _L, _P, _P, _P, C.POINTER(C.c_void_p), _I, _P],
+    "hold_alive_count": [_P, _I, _L, _F, _P, _P],
+    "hold_alive_index": [_P, _I, _L, _F, _P, _P, _P],
     "hold_fused_sdf_h3": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "hold_trunk_h3": [_P, _I, _L, _P, _P, _P, _P, C.POINTER(C.c_void_p), _I, _P],
     "hold_mano_lbs_fwd": [C.POINTER(ManoModel), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
@@ -191,6 +193,8 @@ def _declare(L):
     L.hold_fused_sdf_x6_pack_bytes.restype = C.c_int64
     L.hold_trunk_r6_pack_bytes.restype = C.c_int64
     L.hold_trunk_h3_pack_bytes.restype = C.c_int64
+    L.hold_alive_blocks.restype = C.c_int64
+    L.hold_alive_blocks.argtypes = [C.c_int64]
     L.hold_trunk_h3_act_scale.restype = C.c_float
     L.hold_gemm_r6_pack_bytes.restype = C.c_int64
     L.hold_gemm_r6_pack_bytes.argtypes = [C.c_int32]

@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 #include "../../include/hold_hip.h"
+#include "laplace.h"
 
 namespace {
 
@@ -61,10 +62,7 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
   return v;
 }
-__device__ __forceinline__ float laplace(float s, float beta) {
-  const float sg = (s > 0.f) ? 1.f : ((s < 0.f) ? -1.f : 0.f);
-  return (1.0f / beta) * (0.5f + 0.5f * sg * expm1f(-fabsf(s) / beta));
-}
+__device__ __forceinline__ float laplace(float s, float beta) { return hold_laplace_density(s, beta); }
 
 struct Lds {
   float z[MAXK + 8], dens[MAXK + 8];   // per node, node-major [n*S + s]
@@ -314,7 +312,7 @@ __global__ __launch_bounds__(64 * WAVES) void composite_bwd_kernel(CompArgs a) {
     for (int s = lane; s < S; s += 64) {
       const float sd = a.sdf[n][ray * S + s];
       const float g = dd[n * S + s];
-      const float e = expf(-fabsf(sd) / beta);
+      const float e = hold_laplace_exp(sd, beta);
       const float ib = 1.0f / beta;
       float dsig_ds = -e * 0.5f * ib * ib;
       if (sd == 0.f) dsig_ds = 0.f;

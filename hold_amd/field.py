@@ -34,6 +34,7 @@ USE_CHAIN = os.environ.get("HOLD_CHAIN", "1") != "0"
 # register-resident trunk (csrc/rmlp.hip) for the sampler queries and the training forward trunk (f32x6 arithmetic only)
 USE_R6 = os.environ.get("HOLD_R6", "1") != "0"
 USE_H3_TRUNK = os.environ.get("HOLD_H3_TRUNK", "1") != "0"  # mode f16x3: the training forward trunk too (A/B switch)
+COMPACT = os.environ.get("HOLD_COMPACT", "1") != "0"  # exact sample compaction behind the sdf (csrc/compact.hip); A/B switch
 USE_R6_BWD = os.environ.get("HOLD_R6_BWD", "1") != "0"  # ... and for the descending sweeps (csrc/rchain.hip)
 # the 256 x 256 weight gradients of a backward as one grouped launch (gemm.WgradGroup / hold_wgrad_group_x6)
 USE_WGRAD_GROUP = os.environ.get("HOLD_WGRAD_GROUP", "1") != "0"
@@ -518,20 +519,56 @@ class NodeField:
         K.rowdot(h[7], pk["w8_sdf"], 256, pk["b8_sdf"], P, out_sdf)
 
     # ------------------------------------------------------------------ full forward
-    def forward(self, pk, x, P, ppf, dfm, barf_w, pose_embed, time_code, training):
-        """-> dict(sdf [P,1], rgb [P,4], normal = rin[:, RIN_N:+3], xc, feat = rin[:, :256])."""
+    def forward(self, pk, x, P, ppf, dfm, barf_w, pose_embed, time_code, training, beta=None):
+        """-> dict(sdf [P,1], rgb [P,4], normal [P,3], xc, feat, grad).
+        ``beta`` (the node's Laplace density beta, as the compositor will receive it): enables EXACT SAMPLE COMPACTION
+        (csrc/compact.hip) for single-frame calls -- after the trunk and the sdf row, the samples whose density and whose
+        density derivatives are exact fp32 zeros are dropped: the reverse sweep, the normal, the colour net and the whole
+        backward run on the compacted rows, the dropped rows of rgb / normal are zeros (the compositor multiplies them by a
+        weight of exactly 0).  Outputs are bit-identical to the uncompacted path; nothing changes when every sample is live."""
         sp, pool = self.spec, self.pool
         self.gen += 1
         xc, w_def = self._deform(x, P, ppf, dfm, want_w=training)
         in0, h = self._trunk(pk, xc, P, barf_w, keep_all=True, need_in0=training)
-        rin = pool.get("rin", P, sp.Kr)
         sdf = pool.get("sdf", P, 1)
+        K.rowdot(h[7], pk["w8_sdf"], 256, pk["b8_sdf"], P, sdf)
+        cidx = K.alive_index(sdf, P, beta) if (COMPACT and beta is not None and ppf == P and P > 0) else None
+        if cidx is None:
+            self.last_live = None
+            out = self._forward_tail(pk, xc, w_def, in0, h, P, ppf, dfm, barf_w, pose_embed, time_code, training)
+            self.saved.update(sdf=sdf, cidx=None, P_full=P)
+            out.update(sdf=sdf, xc=xc)
+            return out
+        # ---- compacted tail ----
+        Pa = int(cidx.numel())
+        self.last_live = (Pa, P)
+        rgb_f, nrm_f = pool.get("rgb_full", P, 4), pool.get("n_full", P, 4)
+        rgb_f.zero_()
+        nrm_f.zero_()
+        if Pa == 0:  # nothing along these rays: no colour, no normal, no gradient
+            self.saved = dict(P=0, P_full=P, cidx=cidx, pk=pk, sdf=sdf)
+            return dict(sdf=sdf, rgb=rgb_f, normal=nrm_f[:, :3], xc=xc, feat=None, grad=None)
+        gather = lambda src, name, cols: torch.index_select(src, 0, cidx, out=pool.get(name, Pa, cols))
+        xc_c = gather(xc, "c_xc", 4)
+        h_c = [gather(h[l], f"c_h{l}", 256) for l in range(8)]
+        in0_c = gather(in0, "c_in0", sp.K0) if training else in0
+        w_c = None if w_def is None else gather(w_def, "c_wdef", w_def.shape[1])
+        out = self._forward_tail(pk, xc_c, w_c, in0_c, h_c, Pa, Pa, dfm, barf_w, pose_embed, time_code, training)
+        rgb_f.index_copy_(0, cidx, out["rgb"])
+        nrm_f[:, :3].index_copy_(0, cidx, out["normal"])
+        self.saved.update(sdf=sdf, cidx=cidx, P_full=P)
+        return dict(sdf=sdf, rgb=rgb_f, normal=nrm_f[:, :3], xc=xc, feat=out["feat"], grad=out["grad"])
+
+    def _forward_tail(self, pk, xc, w_def, in0, h, P, ppf, dfm, barf_w, pose_embed, time_code, training):
+        """everything behind the trunk and the sdf row, on P rows (all samples, or the compacted live ones): lin8's feature
+        rows, the reverse sweep and the canonical normal, the rendering net; fills self.saved for backward()."""
+        sp, pool = self.spec, self.pool
+        rin = pool.get("rin", P, sp.Kr)
         # lin8 = 256 feature rows as a full-tile GEMM + the sdf row as a row dot (N = 257 would add a 256-wide tile for it)
         if USE_R6_GEMM and "w8_feat_r6" in pk:
             G.gemm_r6(h[7], pk["w8_feat_r6"], rin[:, RIN_FEAT:RIN_FEAT + FEAT], K=256, bias=pk["b8_feat"])
         else:
             G.gemm_nt(h[7], pk["W8_feat"], rin[:, RIN_FEAT:RIN_FEAT + FEAT], bias=pk["b8_feat"], N=256)
-        K.rowdot(h[7], pk["w8_sdf"], 256, pk["b8_sdf"], P, sdf)
         # ---- reverse sweep: t_l = d sdf / d a_l, ge = d sdf / d embed, g = d sdf / d xc ----
         WT = pk["WT"]
         # t[3] always has its own buffer: its columns 217..219 are K-padding of the next GEMM and must stay zero
@@ -566,9 +603,8 @@ class NodeField:
         rgb = pool.get("rgb", P, 4)
         G.head3_fwd(r[3], R[4], rb[4], rgb)  # 3-output head: a streaming kernel, not a 3/256-full GEMM tile
         self.saved = dict(P=P, ppf=ppf, xc=xc, w_def=w_def, w_c=w_c, in0=in0, h=h, t=t, ge=ge, g=g, rin=rin, r=r,
-                          rgb=rgb, sdf=sdf, dfm=dfm, barf_w=barf_w, pk=pk)
-        return dict(sdf=sdf, rgb=rgb, normal=rin[:, RIN_N:RIN_N + 3], xc=xc, feat=rin[:, RIN_FEAT:RIN_FEAT + FEAT],
-                    grad=g)
+                          rgb=rgb, dfm=dfm, barf_w=barf_w, pk=pk)
+        return dict(rgb=rgb, normal=rin[:, RIN_N:RIN_N + 3], feat=rin[:, RIN_FEAT:RIN_FEAT + FEAT], grad=g)
 
     # ------------------------------------------------------------------ shared backward sweeps
     def _second_order_sweep(self, pk, h, t, gebar, dW, P, grp=None, side_in_t3=False):
@@ -753,11 +789,24 @@ class NodeField:
         tfs [B,nb,16], pose_embed [B,8], time_code [B,32] (object)."""
         sp, pool = self.spec, self.bpool
         sv = self.saved
-        P, ppf, pk = sv["P"], sv["ppf"], sv["pk"]
-        h, t, rin, r, rgb, xc = sv["h"], sv["t"], sv["rin"], sv["r"], sv["rgb"], sv["xc"]
+        pk = sv["pk"]
         dev = self.device
         W, WT, R, RT = pk["W"], pk["WT"], pk["R"], pk["RT"]
         dR, dRb, dW, dWb = zeros_like_many(R, pk["rb"], W, pk["b"])
+        if sv.get("cidx") is not None:  # compacted forward: the cotangents of the dropped samples are exact zeros (csrc/compact.hip)
+            cidx = sv["cidx"]
+            if sv["P"] == 0:  # no live sample: every gradient is zero
+                g0 = torch.zeros(256, sp.rin_dim, device=dev)
+                d0 = torch.zeros(256, pk["iw0_cols"], device=dev)
+                return dict(iw=[d0] + dW[1:8] + [torch.zeros(257, 256, device=dev)], ib=dWb[:8] + [torch.zeros(257, device=dev)],
+                            rw=[g0, dR[1], dR[2], dR[3], dR[4]], rb=dRb, tfs=torch.zeros(n_frames, sp.n_bones, 16, device=dev),
+                            pose_embed=torch.zeros(n_frames, 8, device=dev),
+                            time_code=torch.zeros(n_frames, sp.time, device=dev) if sp.time else None)
+            d_sdf = d_sdf.reshape(-1).index_select(0, cidx)
+            d_rgb = d_rgb.index_select(0, cidx)
+            d_normal = None if d_normal is None else d_normal.index_select(0, cidx)
+        P, ppf = sv["P"], sv["ppf"]
+        h, t, rin, r, rgb, xc = sv["h"], sv["t"], sv["rin"], sv["r"], sv["rgb"], sv["xc"]
         # ---------- rendering net ----------
         dy = pool.get("dy4", P, 4)
         sg = rgb[:, :3]

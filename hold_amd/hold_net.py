@@ -418,7 +418,8 @@ class _FieldFn(torch.autograd.Function):
         dfm = dict(dfm_const)
         dfm["tfs"] = tfs.detach().reshape(-1, nb, 16).contiguous()
         out = node.field.forward(pk, x, P, ppf, dfm, barf_w, pose_embed.detach().contiguous(),
-                                 None if time_code is None else time_code.detach().contiguous(), training=training)
+                                 None if time_code is None else time_code.detach().contiguous(), training=training,
+                                 beta=node.density.beta_host())
         ctx.node, ctx.gen = node, node.field.gen
         ctx.B = tfs.shape[0]
         ctx.tfs_shape = tfs.shape
@@ -434,7 +435,7 @@ class _FieldFn(torch.autograd.Function):
     def backward(ctx, d_sdf, d_rgb, d_normal, d_xc_unused):
         node = ctx.node
         _check_gen(node.field, ctx.gen, f"HOLDNet node '{node.node_id}'")
-        P = node.field.saved["P"]
+        P = node.field.saved["P_full"]  # (the field itself may hold the compacted live samples only)
         dev = node.field.device
         d_sdf = torch.zeros(P, device=dev) if d_sdf is None else d_sdf.contiguous()
         d_rgb = torch.zeros(P, 3, device=dev) if d_rgb is None else d_rgb.contiguous()

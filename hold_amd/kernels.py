@@ -136,6 +136,26 @@ def fused_sdf_r6(xc, P, wpack_r6, bias8, w8, b8, barf_w, out_sdf):
     _g._prof_end(e0, 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256), "fused_sdf_kernel", 20.0 * P)
 
 
+def alive_index(sdf, P, beta):
+    """ordered indices (int64, device) of the samples that can contribute anything -- to a pixel or to a gradient -- given the
+    node's density beta (csrc/compact.hip: Laplace density != 0 or exp(-|sdf| / beta) != 0, the compositor's expressions); None
+    when every sample is live.  ONE host read (the live count sizes the launches that follow)."""
+    L = _lib.lib()
+    nb = int(L.hold_alive_blocks(P))
+    counts = torch.empty(nb, dtype=torch.int32, device=sdf.device)
+    ld = sdf.stride(0) if sdf.dim() > 1 else 1
+    call("hold_alive_count", ptr(sdf), ld, P, float(beta), ptr(counts))
+    off = torch.zeros(nb + 1, dtype=torch.int64, device=sdf.device)
+    torch.cumsum(counts, 0, out=off[1:])
+    n_live = int(off[-1])  # host read
+    if n_live == P:
+        return None
+    idx = torch.empty(n_live, dtype=torch.int64, device=sdf.device)
+    if n_live:
+        call("hold_alive_index", ptr(sdf), ld, P, float(beta), ptr(off), ptr(idx))
+    return idx
+
+
 def fused_sdf_h3(xc, P, wpack_h3, bias8_scaled, c3, w8, b8, barf_w, out_sdf):
     """the sampler's SDF query in the two-limb fp16 arithmetic (csrc/rmlp_h3.hip): wpack_h3 / bias8_scaled / c3 from
     field.pack_weights in mode f16x3 (field.pack_h3); otherwise the contract of fused_sdf_r6"""

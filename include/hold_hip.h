@@ -133,6 +133,20 @@ int hold_wgrad_group_h3(const hold_wgrad_item* items, int32_t n_items, int64_t P
                         hold_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Exact sample compaction (hold_amd/csrc/compact.hip; reference semantics preserved: code/src/engine/volsdf_utils.py:220-251,
+ * code/src/engine/density.py:21-26 -- the reference integrates every sample).  A sample is DEAD when the Laplace density of its
+ * sdf and the exponential exp(-|sdf| / beta) of the density's derivatives are both exact fp32 zeros, evaluated with the
+ * compositor's own expressions: its compositing weight and every gradient that would flow through it are then exactly zero.
+ * hold_alive_count: block_counts[b] = live samples among sdf[b * 1024 .. +1024) (hold_alive_blocks(P) blocks);
+ * hold_alive_index: idx[block_offsets[b] + rank] = p for the live samples of block b in ascending order (block_offsets = the
+ * exclusive prefix sum of the counts) -- wave ballots + popcount ranks, deterministic.  sdf: [P] with stride ld floats.
+ * ---------------------------------------------------------------------------------------- */
+int64_t hold_alive_blocks(int64_t P);
+int hold_alive_count(const float* sdf, int32_t ld, int64_t P, float beta, int32_t* block_counts, hold_stream_t stream);
+int hold_alive_index(const float* sdf, int32_t ld, int64_t P, float beta, const int64_t* block_offsets, int64_t* idx,
+                     hold_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-point kernels (hold_amd/csrc/points.hip)
  * ---------------------------------------------------------------------------------------- */
 
@@ -583,16 +597,6 @@ int hold_knn1_fwd(const float* q, int32_t B, int32_t Nq, const float* t, int32_t
                   hold_stream_t stream);
 int hold_knn1_bwd(const float* q, int32_t B, int32_t Nq, const float* t, int32_t Nt, const int32_t* idx, const float* g,
                   float* dq, float* dt_accum, hold_stream_t stream);
-
-#ifdef HOLD_DEV /* developer build only (HOLD_DEV=1 python -m hold_amd.build): hold_amd/csrc/dev/diag.hip */
-/* diagnostic: pure v_mfma_f32_32x32x2_f32 issue loop (blocks x 256 threads, iters x 64 MFMAs per wave);
- * out needs blocks*256 floats; random_operands != 0 feeds 32 pseudo-random operand values per lane (realistic
- * switching power).  Used only to calibrate the MFMA ceiling at the sustained clock. */
-int hold_diag_mfma_peak(float* out, int32_t blocks, int32_t iters, int32_t random_operands, hold_stream_t stream);
-/* diagnostic: same MFMA count with A operands read from LDS (mode 2) and B streamed from wsrc (mode 3; >= 64 Ki floats);
- * out needs blocks*512 floats */
-int hold_diag_mfma_lds(float* out, const float* wsrc, int32_t blocks, int32_t iters, int32_t mode, hold_stream_t stream);
-#endif
 
 #ifdef __cplusplus
 }

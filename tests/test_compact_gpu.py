@@ -1,0 +1,101 @@
+"""Exact sample compaction (hold_amd/csrc/compact.hip, hold_amd/field.py): the live-sample list against a torch restatement of
+the predicate, and the compacted training step against the uncompacted one on a scene with a trained-model density beta."""
+import numpy as np
+import pytest
+import torch
+
+from parity_common import hip_input, hip_net, oracle_input, setup, syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("P", [1, 63, 1024, 1025, 5000, 3 * 1024 * 7 + 5])
+def test_alive_index_is_the_ordered_list_of_samples_with_a_nonzero_density_or_derivative(P):
+    """dead <=> Laplace density == 0 and exp(-|sdf| / beta) == 0 in fp32 (sdf / beta beyond ~104): only positive sdf far
+    outside the surface; the list is ascending, complete, and None when nothing is dead"""
+    from hold_amd import kernels as K
+    beta = 0.005
+    g = torch.Generator().manual_seed(P)
+    r = torch.rand(P, generator=g)
+    # sdf / beta in {-300..-1} (inside: density 1 / beta), {0..80} (alive), {110..400} (dead); thresholds themselves avoided
+    kind = torch.randint(0, 4, (P,), generator=g)
+    sdf = torch.where(kind == 0, -beta * (1 + 299 * r), torch.where(kind == 1, beta * 80 * r, beta * (110 + 290 * r)))
+    sdf[kind == 3] = 0.0 if P % 2 else float("nan")  # exact zero / NaN: alive (NaN must never be dropped silently)
+    dead = kind == 2
+    buf = torch.full((P, 3), 7.0)
+    buf[:, 1] = sdf
+    view = buf.cuda()[:, 1:2]  # strided [P, 1] view, as the pooled sdf column may be
+    idx = K.alive_index(view, P, beta)
+    want = torch.nonzero(~dead).view(-1)
+    if want.numel() == P:
+        assert idx is None
+    else:
+        assert idx.dtype == torch.int64 and torch.equal(idx.cpu(), want)
+    assert K.alive_index(torch.zeros(P, 1, device="cuda"), P, beta) is None
+
+
+def _sharp_net(beta):
+    sc, sd_np, sd, osc = setup()
+    sd_np = dict(sd_np)
+    for k in sd_np:
+        if k.endswith(".density.beta") and k.startswith("nodes."):
+            sd_np[k] = np.float32(beta - 1e-4)
+    return sc, sd_np, sd
+
+
+def _rng(sc, N):
+    g = torch.Generator().manual_seed(5)
+    rng = {"bg_t": torch.rand(N, 32, generator=g).cuda()}
+    for i, n in enumerate(sc["entities"]):
+        rng[n] = {"t_uniform": torch.rand(N, 128, generator=g).cuda(), "u_final": torch.rand(N, 64, generator=g).cuda(),
+                  "perm": (lambda S, _s=i: torch.randperm(S, generator=torch.Generator().manual_seed(100 + _s)))}
+    return rng
+
+
+def _run(sc, sd_np, sd, compact, W=8):
+    from hold_amd import field as F
+    prev = F.COMPACT
+    F.COMPACT = compact
+    try:
+        net = hip_net(sc, sd_np, train=True)
+        b, _ = oracle_input(sc, sd, [1], W, W)  # ONE frame: the configuration compaction applies to
+        out = net(hip_input(b, net, epoch=25, step=10), rng=_rng(sc, W * W))
+        gt = torch.from_numpy(b["gt.rgb"]).view(-1, 3).cuda()
+        loss = ((out["rgb"] - gt).abs().mean() + 0.1 * (out["semantics"] ** 2).mean() + 0.05 * out["normal"].sum(-1).mean()
+                + 0.02 * out["right.fg_rgb"].sum(-1).mean() + 0.03 * out["object.mask_prob"].mean() + 0.01 * out["depth"].mean())
+        loss.backward()
+        live = {n: getattr(net.nodes[n].field, "last_live", None) for n in sc["entities"]}
+        grads = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+        keys = [k for k in out.keys() if torch.is_tensor(out[k]) and out[k].is_floating_point()]
+        return {k: out[k].detach().clone() for k in keys}, grads, live, float(loss)
+    finally:
+        F.COMPACT = prev
+
+
+def test_compacted_step_equals_the_uncompacted_step_on_a_sharp_beta_scene():
+    """with a trained model's beta (0.005) most samples lie where the density underflows to an exact zero.
+    The compacted path (reverse sweep, colour net and the whole backward on the live samples only) must return EVERY output
+    of the forward bit for bit -- dropped samples carry weight 0 -- and the parameter gradients up to the order of their
+    sums (the dropped terms are exact zeros, but fewer rows are grouped differently into the partial sums of the weight
+    gradients): held to 2e-6 of each tensor's norm, and most tensors to exact equality."""
+    sc, sd_np, sd = _sharp_net(0.005)
+    o1, g1, live1, l1 = _run(sc, sd_np, sd, True)
+    o0, g0, live0, l0 = _run(sc, sd_np, sd, False)
+    assert all(v is None for v in live0.values())
+    assert all(v is not None and v[0] < 0.8 * v[1] for v in live1.values()), live1  # compaction did drop samples
+    assert l1 == l0
+    for k in o0:
+        assert torch.equal(o1[k], o0[k]), k
+    assert set(g1) == set(g0) and len(g0) >= 100
+    exact = 0
+    for n in g0:
+        d = float((g1[n] - g0[n]).norm() / (g0[n].norm() + 1e-30))
+        assert d < 2e-6, (n, d)
+        exact += torch.equal(g1[n], g0[n])
+    print(f"compaction: live samples {live1}; {exact} of {len(g0)} gradient tensors bit-identical")
+
+
+def test_default_scene_has_no_dead_samples_and_takes_the_uncompacted_path():
+    sc, sd_np, sd, _ = setup()
+    o1, g1, live1, l1 = _run(sc, sd_np, sd, True, W=6)
+    assert all(v is None for v in live1.values())

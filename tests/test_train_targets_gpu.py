@@ -540,7 +540,7 @@ def test_five_step_trajectory_matches_oracle_with_torch_adam(ctx):
     clip_grad_norm_(0.5), torch.optim.Adam with the reference's parameter groups: code/src/hold/hold.py:79-101,
     code/train.py:30), fresh random draws every step.  Held: the loss curve (1e-5 relative per step), the sampler's round
     counts against the ORACLE's own sampler at the oracle's weights of that step (equal in >= 4 of 5 steps, see below), and after step 5 every parameter tensor
-    within 1e-4 of its norm -- and, the sharper statement, every tensor's five-step UPDATE within 2e-2 of the update's norm
+    within 1e-4 of its norm (measured 4.5e-5) -- and, the sharper statement, every tensor's five-step UPDATE within 5e-3 of the update's norm
     (Adam divides by sqrt(v): elements whose gradient is below eps = 1e-8 move by amounts that depend on their last bits)."""
     from hold_amd.loss import Loss
     from hold_amd.optim import FlatAdam
@@ -624,4 +624,4 @@ def test_five_step_trajectory_matches_oracle_with_torch_adam(ctx):
     print(f"five-step trajectory: losses {losses}; sampler rounds (oracle, HIP) per step {round_log}; worst parameter error {worst_p}; "
           f"worst update error {worst_d}")
     assert worst_p[1] < 1e-4, worst_p
-    assert worst_d[1] < 2e-2, worst_d
+    assert worst_d[1] < 5e-3, worst_d  # measured 1.3e-3 (round 5, GPU call 9)
