@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../../../include/hold_hip.h"
+#include "hold_hip_dev.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

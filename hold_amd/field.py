@@ -35,6 +35,8 @@ USE_CHAIN = os.environ.get("HOLD_CHAIN", "1") != "0"
 USE_R6 = os.environ.get("HOLD_R6", "1") != "0"
 USE_H3_TRUNK = os.environ.get("HOLD_H3_TRUNK", "1") != "0"  # mode f16x3: the training forward trunk too (A/B switch)
 COMPACT = os.environ.get("HOLD_COMPACT", "1") != "0"  # exact sample compaction behind the sdf (csrc/compact.hip); A/B switch
+COMPACT_ALIGN = 128       # compacted row counts are padded to this (the kernels' fast paths: P % 16 == 0, 128-point blocks)
+COMPACT_MAX_LIVE = 0.85   # compaction moves 9 KiB per live sample: above this live fraction it costs more than it saves
 USE_R6_BWD = os.environ.get("HOLD_R6_BWD", "1") != "0"  # ... and for the descending sweeps (csrc/rchain.hip)
 # the 256 x 256 weight gradients of a backward as one grouped launch (gemm.WgradGroup / hold_wgrad_group_x6)
 USE_WGRAD_GROUP = os.environ.get("HOLD_WGRAD_GROUP", "1") != "0"
@@ -541,6 +543,13 @@ class NodeField:
             return out
         # ---- compacted tail ----
         Pa = int(cidx.numel())
+        Pc = (Pa + COMPACT_ALIGN - 1) // COMPACT_ALIGN * COMPACT_ALIGN  # rows the compacted stages run on
+        if Pc > COMPACT_MAX_LIVE * P:  # too few dead samples to pay for the gathers: every stage on every sample
+            self.last_live = (Pa, P, "not compacted")
+            out = self._forward_tail(pk, xc, w_def, in0, h, P, ppf, dfm, barf_w, pose_embed, time_code, training)
+            self.saved.update(sdf=sdf, cidx=None, P_full=P)
+            out.update(sdf=sdf, xc=xc)
+            return out
         self.last_live = (Pa, P)
         rgb_f, nrm_f = pool.get("rgb_full", P, 4), pool.get("n_full", P, 4)
         rgb_f.zero_()
@@ -548,15 +557,25 @@ class NodeField:
         if Pa == 0:  # nothing along these rays: no colour, no normal, no gradient
             self.saved = dict(P=0, P_full=P, cidx=cidx, pk=pk, sdf=sdf)
             return dict(sdf=sdf, rgb=rgb_f, normal=nrm_f[:, :3], xc=xc, feat=None, grad=None)
-        gather = lambda src, name, cols: torch.index_select(src, 0, cidx, out=pool.get(name, Pa, cols))
+        if Pc > Pa:
+            # the fast kernels want row counts that are multiples of 16 (whole-dW weight gradients) / 128 (point blocks): the list
+            # is padded with copies of ONE DEAD sample -- its cotangents are exact zeros, so the padding rows add exact zeros
+            # to every gradient sum; their forward values are not scattered back
+            live = torch.zeros(P, dtype=torch.int8, device=cidx.device)
+            live[cidx] = 1
+            dead = torch.argmin(live).reshape(1)  # index of the first dead sample (no host read)
+            gidx = torch.cat([cidx, dead.expand(Pc - Pa)])
+        else:
+            gidx = cidx
+        gather = lambda src, name, cols: torch.index_select(src, 0, gidx, out=pool.get(name, Pc, cols))
         xc_c = gather(xc, "c_xc", 4)
         h_c = [gather(h[l], f"c_h{l}", 256) for l in range(8)]
         in0_c = gather(in0, "c_in0", sp.K0) if training else in0
         w_c = None if w_def is None else gather(w_def, "c_wdef", w_def.shape[1])
-        out = self._forward_tail(pk, xc_c, w_c, in0_c, h_c, Pa, Pa, dfm, barf_w, pose_embed, time_code, training)
-        rgb_f.index_copy_(0, cidx, out["rgb"])
-        nrm_f[:, :3].index_copy_(0, cidx, out["normal"])
-        self.saved.update(sdf=sdf, cidx=cidx, P_full=P)
+        out = self._forward_tail(pk, xc_c, w_c, in0_c, h_c, Pc, Pc, dfm, barf_w, pose_embed, time_code, training)
+        rgb_f.index_copy_(0, cidx, out["rgb"][:Pa])
+        nrm_f[:, :3].index_copy_(0, cidx, out["normal"][:Pa])
+        self.saved.update(sdf=sdf, cidx=gidx, P_full=P)
         return dict(sdf=sdf, rgb=rgb_f, normal=nrm_f[:, :3], xc=xc, feat=out["feat"], grad=out["grad"])
 
     def _forward_tail(self, pk, xc, w_def, in0, h, P, ppf, dfm, barf_w, pose_embed, time_code, training):
@@ -754,6 +773,7 @@ class NodeField:
         """gradient of a loss on g = d sdf/d x w.r.t. the effective implicit weights (second-order terms only:
         the points themselves and sdf / features carry no upstream gradient)."""
         sp, pool, sv = self.spec, self.bpool, self.saved
+        self._consume(sv, "grad_points_backward")
         P, pk, h, t, xc = sv["P"], sv["pk"], sv["h"], sv["t"], sv["xc"]
         dev = self.device
         W, WT = pk["W"], pk["WT"]
@@ -782,6 +802,17 @@ class NodeField:
         g_ib = dWb[:8] + [torch.zeros(257, device=dev)]
         return g_iw, g_ib
 
+    @staticmethod
+    def _consume(sv, what):
+        """ONE backward per forward (advisor r4): the second-order backward overwrites saved forward state in place -- d sdf /
+        d embedding lives in t_3's skip columns and hold_embed_bwd2 writes the embedding cotangent over it -- so a second
+        backward over the same saved state (retain_graph, calling backward twice) would read the first one's cotangents as
+        forward values and return wrong second-order terms: refused instead."""
+        if sv.get("consumed"):
+            raise RuntimeError(f"hold_amd: NodeField.{what}() called twice for one forward: the backward consumes the saved "
+                               "activations in place (one-shot contract); run the forward again")
+        sv["consumed"] = True
+
     # ------------------------------------------------------------------ backward
     def backward(self, d_sdf, d_rgb, d_normal, n_frames):
         """d_sdf [P] / [P,1], d_rgb [P,3], d_normal [P,3] (may be None) -> dict of gradients:
@@ -789,6 +820,7 @@ class NodeField:
         tfs [B,nb,16], pose_embed [B,8], time_code [B,32] (object)."""
         sp, pool = self.spec, self.bpool
         sv = self.saved
+        self._consume(sv, "backward")
         pk = sv["pk"]
         dev = self.device
         W, WT, R, RT = pk["W"], pk["WT"], pk["R"], pk["RT"]

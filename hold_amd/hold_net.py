@@ -920,8 +920,13 @@ class Background(nn.Module):
         if config.x6() and _field.USE_R6_BWD:
             # the seven 256-wide layers as ONE register-resident descending sweep (csrc/rchain.hip, skip width 172) instead
             # of seven hold_gemm_nt launches with the MUL_DSP epilogue; every r_l stays for the weight gradients
-            S = torch.stack([F.pad(W[l], (0, 0, 0, 256 - W[l].shape[0])) for l in range(1, 8)])
-            wr6 = _field.pack_r6_stack(S.transpose(1, 2).flip(0).contiguous())  # layer j of the sweep = W_{7-j}^T
+            # (advisor r4: the pack -- limb split + permutation of 7 x 256 x 256 -- was rebuilt on EVERY backward call, i.e. per ray
+            # chunk; the weights change once per optimiser step: cached on the weights epoch and the parameters' versions)
+            wkey = _pack_key([self.bg_implicit_network], True)
+            if getattr(self, "_wr6_cache", (None, None))[0] != wkey:
+                stacked = torch.stack([F.pad(W[l], (0, 0, 0, 256 - W[l].shape[0])) for l in range(1, 8)])
+                self._wr6_cache = (wkey, _field.pack_r6_stack(stacked.transpose(1, 2).flip(0).contiguous()))  # layer j = W_{7-j}^T
+            wr6 = self._wr6_cache[1]
             r = [pool.get(f"rs{l}", P, 256) for l in range(7)] + [cur]
             K.chain(K.CHAIN_DSP, P, cur, None, 7, 32, skip_layer=3, aux1=[h[l - 1] for l in range(7, 0, -1)],
                     out=[r[l - 1] for l in range(7, 0, -1)], wpack_r6=wr6, skip_out=so)
