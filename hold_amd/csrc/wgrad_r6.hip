@@ -36,7 +36,7 @@ namespace {
 constexpr int NST = 4;            // ring slots
 constexpr int STAGE = 32 * 1024;  // one step: R rows [16][256] fp32, then X rows [16][256]
 constexpr int LDS_BYTES = NST * STAGE;
-constexpr int LDS_BYTES_H3 = LDS_BYTES + 64;  // + the scale sample's reduction
+constexpr int LDS_BYTES_H3 = LDS_BYTES + 64;  // + the workgroup reductions of the scale sample and of the exact maxima
 
 struct WArgs {
   const float* R; int ldr;
@@ -265,8 +265,12 @@ __device__ __forceinline__ void wgrad_r6_body(const float* R, int ldr, const flo
 // SCALES.  The operands are activations (O(1)) and loss cotangents (1e-9 .. 1e-3 and anything else): every WORKGROUP picks
 // its own pair of scales from a sample of ITS rows (16 groups of four rows, evenly spread; all 256 -- for R: the first n_valid -- columns)
 // so that the sampled maximum lands in [2^6, 2^7): 2^9 of headroom below fp16's largest value for rows the sample did
-// not see (an overflow gives +-inf and a NaN gradient: loud, never silently wrong), full 22-23-bit precision for every value
-// within 2^-8 of the sampled maximum and an absolute 2^-31 of it below.  Workgroups need not agree: a partial tile is
+// not see, full 22-23-bit precision for every value within 2^-8 of the sampled maximum and an absolute 2^-31 of it below.
+// Loss cotangents are heavy-tailed (compositing weights span thirty orders of magnitude; a sharp density makes it worse), so a
+// row outside the sample CAN exceed that headroom: every pass therefore keeps the exact maximum of the scaled values of each
+// operand (one v_max3_f32 per value pair), and a workgroup that saw one beyond 65504 repeats its share once with that
+// operand's scale taken from the exact maximum -- no overflow ever reaches dW (GPU call 12 of round 5: the first version,
+// without this, returned NaN gradients on the beta = 0.005 scene).  Workgroups need not agree on scales: a partial tile is
 // multiplied by 1 / (s_R s_X) (exact) before it is written, the reduction adds unscaled fp32 tiles as before.
 struct LimbsH { u32x4 l[8][2]; };
 struct FragH { float x[8]; f32x2 xs[4]; uint32_t hi[4]; float ra[4], rb[4]; };
@@ -276,11 +280,14 @@ __device__ __forceinline__ uint32_t cvt_pk_h(float a, float b) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
 }
 // micro-operation k (0..19) of the split of a fragment: operation k / 4 on value pair k % 4
-__device__ __forceinline__ void split_mop_h(FragH& s, u32x4 (&out)[2], int k, float scale) {
+// `mx` collects the EXACT maximum of the scaled magnitudes (one v_max3_f32 per pair): the scales come from a sample, and a row
+// the sample did not see may exceed fp16's range -- the workgroup then knows, and repeats its share with exact scales
+__device__ __forceinline__ void split_mop_h(FragH& s, u32x4 (&out)[2], int k, float scale, float& mx) {
   const int op = k >> 2, j = k & 3;
   if (op == 0) {
     f32x2 v = {s.x[2 * j], s.x[2 * j + 1]};
     v = v * scale;
+    asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mx) : "v"(v[0]), "v"(v[1]));
     asm volatile("" : "+v"(v));
     s.xs[j] = v;
   } else if (op == 1) {
@@ -303,10 +310,11 @@ __device__ __forceinline__ void split_mop_h(FragH& s, u32x4 (&out)[2], int k, fl
 constexpr int rsh(int f) { return 42 * f / 8; }
 constexpr int wsh(int f) { return f >= 8 ? 48 : 6 + 42 * f / 8; }
 
-// power-of-two scale exponent for an operand whose sampled maximum is am: 2^k am in [2^6, 2^7); |k| <= 60
-__device__ __forceinline__ int scale_exp(float am) {
+// power-of-two scale exponent for an operand whose maximum is am: 2^k am in [2^top, 2^(top + 1)); |k| <= 60.  top = 6 for a
+// SAMPLED maximum (2^9 of headroom for the rows not sampled), 13 for an exact one
+__device__ __forceinline__ int scale_exp(float am, int top = 6) {
   const int e = (int)((fbits(am) >> 23) & 0xffu);
-  int k = 133 - e;
+  int k = 127 + top - e;
   k = k > 60 ? 60 : (k < -60 ? -60 : k);
   return am > 0.f ? k : 0;
 }
@@ -335,56 +343,74 @@ __device__ __forceinline__ void wgrad_h3_body(const float* R, int ldr, const flo
   };
 
   f32x16 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float bsum[2] = {0.f, 0.f};
   float inv = 1.0f;
+  float* red = reinterpret_cast<float*>(smem + LDS_BYTES);  // 16 floats behind the ring: workgroup reductions
 
-  if (s0 < s1) {
-    // the first DIST steps' rows are requested FIRST: the scale sample below runs while they travel
+  auto preload = [&]() {
 #pragma unroll
     for (int u = 0; u < DIST; ++u) {
       const char* p = step_src(s0 + u);
 #pragma unroll
       for (int i = 0; i < 8; ++i) dma_piece(p + i * rowb, dvoff, (uint32_t)((int)((s0 + u) % NST) * STAGE) + dst0 + i * 1024);
     }
-    // ---- this workgroup's scales: a sample of its rows -- at most 16 passes of four consecutive rows (a row = 64 threads x
-    // 16 bytes), evenly spread; the reduction uses 32 bytes of LDS behind the ring ----
-    float sR, sX;
-    {
-      const long r0 = s0 * 16, nrows = (s1 - s0) * 16;
-      long stride = (nrows / 16 + 3) & ~3L;
-      stride = stride < 4 ? 4 : stride;
-      const int c4 = (tid & 63) * 4, sub = tid >> 6;
-      float amR = 0.f, amX = 0.f;
-      for (long r = 0; r + 4 <= nrows; r += stride) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(R + (r0 + r + sub) * (long)ldr + c4);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(X + (r0 + r + sub) * (long)ldx + c4);
+  };
+  auto wg_max2 = [&](float& a, float& b) {  // maxima over the workgroup (NaNs are ignored by v_max)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (c4 + e < n_valid) amR = fmaxf(amR, fabsf(a[e]));  // columns >= n_valid of R are not the caller's data
-          amX = fmaxf(amX, fabsf(b[e]));
-        }
-      }
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) {
-        amR = fmaxf(amR, __shfl_xor(amR, o));
-        amX = fmaxf(amX, __shfl_xor(amX, o));
-      }
-      float* red = reinterpret_cast<float*>(smem + LDS_BYTES);
-      if (lane == 0) { red[wave] = amR; red[4 + wave] = amX; }
-      __syncthreads();
-      amR = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-      amX = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
-      const int kR = __builtin_amdgcn_readfirstlane(scale_exp(amR)), kX = __builtin_amdgcn_readfirstlane(scale_exp(amX));
-      sR = bitsf((uint32_t)(127 + kR) << 23);
-      sX = bitsf((uint32_t)(127 + kX) << 23);
-      inv = bitsf((uint32_t)(127 - kR - kX) << 23);
+    for (int o = 32; o >= 1; o >>= 1) {
+      a = fmaxf(a, __shfl_xor(a, o));
+      b = fmaxf(b, __shfl_xor(b, o));
     }
+    __syncthreads();
+    if (lane == 0) { red[wave] = a; red[4 + wave] = b; }
+    __syncthreads();
+    a = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    b = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+  };
+
+  int kR = 0, kX = 0;
+  if (s0 < s1) {
+    preload();  // the first DIST steps' rows are requested FIRST: the scale sample below runs while they travel
+    // ---- this workgroup's scales: a sample of its rows -- at most 16 passes of four consecutive rows (a row = 64 threads x
+    // 16 bytes), evenly spread ----
+    const long r0 = s0 * 16, nrows = (s1 - s0) * 16;
+    long stride = (nrows / 16 + 3) & ~3L;
+    stride = stride < 4 ? 4 : stride;
+    const int c4 = (tid & 63) * 4, sub = tid >> 6;
+    float amR = 0.f, amX = 0.f;
+    for (long r = 0; r + 4 <= nrows; r += stride) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(R + (r0 + r + sub) * (long)ldr + c4);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(X + (r0 + r + sub) * (long)ldx + c4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (c4 + e < n_valid) amR = fmaxf(amR, fabsf(a[e]));  // columns >= n_valid of R are not the caller's data
+        amX = fmaxf(amX, fabsf(b[e]));
+      }
+    }
+    wg_max2(amR, amX);
+    kR = __builtin_amdgcn_readfirstlane(scale_exp(amR));
+    kX = __builtin_amdgcn_readfirstlane(scale_exp(amX));
+  }
+  // A pass over the workgroup's steps with the scales 2^kR, 2^kX.  It keeps the EXACT maxima of the scaled operands; if one
+  // exceeds fp16's largest value (a row the sample did not see: heavy-tailed loss cotangents do that -- compositing weights
+  // span thirty orders of magnitude), the pass is repeated ONCE with that operand's scale taken from its exact maximum.
+  for (int attempt = 0; attempt < 2 && s0 < s1; ++attempt) {
+    const float sR = bitsf((uint32_t)(127 + kR) << 23), sX = bitsf((uint32_t)(127 + kX) << 23);
+    inv = bitsf((uint32_t)(127 - kR - kX) << 23);
+    // R's scale per lane and fragment: 0 for the columns >= n_valid (their content is not the caller's data -- NaN / inf
+    // included: it then neither counts as an overflow nor reaches a row of dW that is reduced)
+    float sRf[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) sRf[f] = (128 * wn + 32 * f + li < n_valid) ? sR : 0.f;
+    float mR = 0.f, mX = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bsum[0] = bsum[1] = 0.f;
+    if (attempt > 0) preload();
     const char* dptr = step_src(s0 + DIST);
     WG_WAIT_VM(8 * (DIST - 1));
     __builtin_amdgcn_s_barrier();
@@ -409,7 +435,7 @@ __device__ __forceinline__ void wgrad_h3_body(const float* R, int ldr, const flo
         for (int e = 0; e < 8; ++e) fs[0].x[e] = *reinterpret_cast<const float*>(p + e * 1024);
         bias_add(f, fs[0]);
 #pragma unroll
-        for (int k = 0; k < 20; ++k) split_mop_h(fs[0], L0.l[f], k, f < 4 ? sR : sX);
+        for (int k = 0; k < 20; ++k) split_mop_h(fs[0], L0.l[f], k, f < 4 ? sRf[f & 3] : sX, f < 4 ? mR : mX);
       }
     }
 
@@ -458,7 +484,7 @@ __device__ __forceinline__ void wgrad_h3_body(const float* R, int ldr, const flo
 #pragma unroll
             for (int u = 0; u < 5; ++u) {
               const int k = 20 * (m - w0) / len + u;
-              if (k < 20 * (m - w0 + 1) / len) split_mop_h(fs[f & 1], N.l[f], k, f < 4 ? sR : sX);
+              if (k < 20 * (m - w0 + 1) / len) split_mop_h(fs[f & 1], N.l[f], k, f < 4 ? sRf[f & 3] : sX, f < 4 ? mR : mX);
             }
           }
         }
@@ -476,7 +502,21 @@ __device__ __forceinline__ void wgrad_h3_body(const float* R, int ldr, const flo
       step(t, L0, L1);
       if (t + 1 < s1) step(t + 1, L1, L0);
     }
-    WG_WAIT_VM(0);
+    WG_WAIT_VM(0);  // no LDS-DMA in flight when the ring is refilled (or released)
+    // ---- did a scaled value leave fp16's range?  (65504 is the largest finite value; a NaN operand is not an overflow) ----
+    wg_max2(mR, mX);
+    const bool ovR = mR > 65504.f, ovX = mX > 65504.f;
+    if (!(ovR || ovX)) break;
+    if (ovR) kR = __builtin_amdgcn_readfirstlane(scale_exp(mR * bitsf((uint32_t)(127 - kR) << 23), 13));
+    if (ovX) kX = __builtin_amdgcn_readfirstlane(scale_exp(mX * bitsf((uint32_t)(127 - kX) << 23), 13));
+  }
+  if (!(s0 < s1)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
 
 #pragma unroll

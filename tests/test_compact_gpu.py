@@ -89,6 +89,9 @@ def test_compacted_step_equals_the_uncompacted_step_on_a_sharp_beta_scene():
     for k in o0:
         assert torch.equal(o1[k], o0[k]), k
     assert set(g1) == set(g0) and len(g0) >= 100
+    bad0 = [n for n in g0 if not torch.isfinite(g0[n]).all()]
+    bad1 = [n for n in g1 if not torch.isfinite(g1[n]).all()]
+    assert not bad0 and not bad1, (bad0[:5], bad1[:5])
     exact = 0
     for n in g0:
         d = float((g1[n] - g0[n]).norm() / (g0[n].norm() + 1e-30))
