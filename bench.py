@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 matrix)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 matrix, same guide
 HBM_PEAK_GBPS = 8000.0  # HBM3E spec (6.3 TB/s achievable by a float4 copy), same guide
-ROUND = "r04"
+ROUND = "r05"
 
 
 def parse():

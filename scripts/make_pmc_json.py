@@ -3,14 +3,15 @@ Unit / correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both
 reports half of wide coalesced reads, so read bytes = 2 * FETCH_SIZE * 1024."""
 import json, os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "prof_r04")
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "prof_r05")
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r05"
 F = json.load(open(os.path.join(src, "FETCH_SIZE.json")))
 W = json.load(open(os.path.join(src, "WRITE_SIZE.json")))
 # bench.py's kernel families -> rocprof kernel names (rmlp_kernel is both the sampler query <HEAD> and the forward trunk
 # <STORE>: the counter CSV keys carry no template arguments, so its traffic is reported under its own entry too)
-groups = {"fused_sdf_kernel": ["rmlp_kernel<true,false,0>", "fused_sdf_x6p_kernel", "fused_sdf_pipe_kernel", "fused_sdf_kernel"],
-          "trunk_r6_kernel": ["rmlp_kernel<false,true,0>"],
+groups = {"fused_sdf_kernel": ["rmlp_h3_kernel<true,false,0>", "rmlp_kernel<true,false,0>", "fused_sdf_x6p_kernel", "fused_sdf_pipe_kernel",
+                               "fused_sdf_kernel"],
+          "trunk_r6_kernel": ["rmlp_h3_kernel<false,true,0>", "rmlp_kernel<false,true,0>"],
           # rsweep_kernel<MODE, A2, DIST, ABL, SKIP_OUT>: the foreground nets' sweeps (skip width 217); the background's descending
           # sweep (skip width 172, a third of the points) is reported under its own name so that it does not dilute the average
           "rchain_kernel": ["rsweep_kernel<1,false,1,0,217>", "rsweep_kernel<1,false,1>"],
@@ -23,7 +24,8 @@ groups = {"fused_sdf_kernel": ["rmlp_kernel<true,false,0>", "fused_sdf_x6p_kerne
           "sampler_beta_kernel": ["sampler_beta_kernel"], "sampler_sample_kernel": ["sampler_sample_kernel"],
           "composite_fwd_kernel": ["composite_fwd_kernel"], "composite_bwd_kernel": ["composite_bwd_kernel"],
           "gemm_nt_kernel": ["gemm_nt_kernel"], "rnarrow_kernel": ["rnarrow_kernel"],
-          "wgrad_kernel": ["wgrad_r6_kernel<true,0,3>", "wgrad_r6_kernel<false,0,3>", "wgrad_r6_kernel<true>", "wgrad_r6_kernel<false>",
+          "wgrad_kernel": ["wgrad_h3_kernel<true>", "wgrad_h3_kernel<false>", "wgrad_r6_group_kernel<true>", "wgrad_r6_group_kernel<false>",
+                           "wgrad_r6_kernel<true,0,3>", "wgrad_r6_kernel<false,0,3>", "wgrad_r6_kernel<true>", "wgrad_r6_kernel<false>",
                            "wgrad_r6_kernel", "wgrad_r6_group_kernel", "wgrad_lds_kernel", "wgrad_kernel"]}
 notes = {
     "fused_sdf_kernel": "sampler queries: 16 B in (xc row) + 4 B out per point; the 2.8 MiB limb pack stays in L2",
@@ -40,7 +42,7 @@ notes = {
     "wgrad_kernel": "dW[N,K] = R^T X over P = 1.61 M points: (N + K) * 4 B per point = 2 KiB (3.3 GB) for the 256x256 layers; "
                     "split-K partials (<= 256 x 256 KiB) are written here and reduced by wgrad_reduce4_kernel"}
 out = {"command": "rocprofv3 --kernel-trace --pmc <C> -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile "
-                  "(one pass per counter; scripts/prof_r04.sh), chunk 16384 rays, default precision (f32x6)",
+                  "(one pass per counter; scripts/lease_logs/r5_call14.sh), chunk 16384 rays, default precision (f16x3: the forward trunk kernels and the whole-dW weight gradients in the two-limb fp16 arithmetic, everything else f32x6)",
        "correction": "gfx950 FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md HBM section): read bytes = "
                      "2*FETCH_SIZE*1024; WRITE_SIZE taken as KiB", "kernels": {}}
 for g, names in groups.items():
