@@ -126,7 +126,11 @@ def wgrad(R, X, dW, db=None, *, N=None, K=None, accumulate=False, splits=None):
     fn = (L.hold_wgrad_h3 if (config.h3() and USE_H3_WGRAD) else L.hold_wgrad_x6) if config.x6() else L.hold_wgrad
     check(fn(ptr(R), _ld(R), ptr(X), _ld(X), P, N, K, ptr(dW), _ld(dW), ptr(db), 1 if accumulate else 0,
              splits, ptr(ws), stream_ptr()), "hold_wgrad")
-    _prof_end(e0, 2.0 * P * N * K, "wgrad_kernel", 4.0 * P * (N + K))
+    # bench.py prices the families by the matrix instructions they issue: the whole-dW shapes in mode f16x3 run wgrad_h3_kernel
+    # (3 limb products per product; for K = 272 / 304 the 16 / 48-column tail runs the bf16 tile kernel: 6 % of the launch's FLOP)
+    h3 = (config.h3() and USE_H3_WGRAD and 128 < N <= 256 and 256 <= K <= 320 and P % 16 == 0 and P >= 4096 and _ld(R) >= 256
+          and _ld(X) >= K)
+    _prof_end(e0, 2.0 * P * N * K, "wgrad_h3_kernel" if h3 else "wgrad_kernel", 4.0 * P * (N + K))
     return dW
 
 
@@ -208,7 +212,8 @@ class WgradGroup:
         e0 = _prof_begin()
         fn = L.hold_wgrad_group_h3 if (config.h3() and USE_H3_WGRAD) else L.hold_wgrad_group_x6
         check(fn(arr, len(items), P, ptr(ws), stream_ptr()), "hold_wgrad_group")
-        _prof_end(e0, 2.0 * P * 256 * sum(it[4] for it in items), "wgrad_kernel", 4.0 * P * 512 * len(items))
+        _prof_end(e0, 2.0 * P * 256 * sum(it[4] for it in items),
+                  "wgrad_h3_kernel" if fn is L.hold_wgrad_group_h3 else "wgrad_kernel", 4.0 * P * 512 * len(items))
 
 
 def wcolsum(X, out, *, weights=None, N=None, accumulate=False):

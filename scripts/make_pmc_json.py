@@ -24,8 +24,8 @@ groups = {"fused_sdf_kernel": ["rmlp_h3_kernel<true,false,0>", "rmlp_kernel<true
           "sampler_beta_kernel": ["sampler_beta_kernel"], "sampler_sample_kernel": ["sampler_sample_kernel"],
           "composite_fwd_kernel": ["composite_fwd_kernel"], "composite_bwd_kernel": ["composite_bwd_kernel"],
           "gemm_nt_kernel": ["gemm_nt_kernel"], "rnarrow_kernel": ["rnarrow_kernel"],
-          "wgrad_kernel": ["wgrad_h3_kernel<true>", "wgrad_h3_kernel<false>", "wgrad_r6_group_kernel<true>", "wgrad_r6_group_kernel<false>",
-                           "wgrad_r6_kernel<true,0,3>", "wgrad_r6_kernel<false,0,3>", "wgrad_r6_kernel<true>", "wgrad_r6_kernel<false>",
+          "wgrad_h3_kernel": ["wgrad_h3_kernel<true>", "wgrad_h3_kernel<false>", "wgrad_r6_group_kernel<true>"],
+          "wgrad_kernel": ["wgrad_r6_group_kernel<false>", "wgrad_r6_kernel<true,0,3>", "wgrad_r6_kernel<false,0,3>", "wgrad_r6_kernel<true>", "wgrad_r6_kernel<false>",
                            "wgrad_r6_kernel", "wgrad_r6_group_kernel", "wgrad_lds_kernel", "wgrad_kernel"]}
 notes = {
     "fused_sdf_kernel": "sampler queries: 16 B in (xc row) + 4 B out per point; the 2.8 MiB limb pack stays in L2",
@@ -39,6 +39,8 @@ notes = {
     "gemm_nt_kernel": "per-layer GEMMs (rendering net fwd+bwd, lin8 features, d/d embedding, background): (K + N) * 4 B per "
                       "point (+ N * 4 B per aux operand of the MUL_DSP / DRELU epilogues)",
     "rnarrow_kernel": "the N <= 64 layers (N = 39 / 16 / 48): 1 KiB in per point (A once) + 4 N B out (+ 4 N B in when accumulating)",
+    "wgrad_h3_kernel": "dW[256,256] = R^T X over P = 1.61 M points in the two-limb fp16 arithmetic: 2 KiB per point (3.3 GB) of operand "
+                       "rows + the scale sample (64 rows per workgroup and operand) + 256 x 256 KiB of partial tiles",
     "wgrad_kernel": "dW[N,K] = R^T X over P = 1.61 M points: (N + K) * 4 B per point = 2 KiB (3.3 GB) for the 256x256 layers; "
                     "split-K partials (<= 256 x 256 KiB) are written here and reduced by wgrad_reduce4_kernel"}
 out = {"command": "rocprofv3 --kernel-trace --pmc <C> -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile "

@@ -79,7 +79,7 @@ def test_compacted_step_equals_the_uncompacted_step_on_a_sharp_beta_scene():
     The compacted path (reverse sweep, colour net and the whole backward on the live samples only) must return EVERY output
     of the forward bit for bit -- dropped samples carry weight 0 -- and the parameter gradients up to the order of their
     sums (the dropped terms are exact zeros, but fewer rows are grouped differently into the partial sums of the weight
-    gradients): held to 1e-5 of each tensor's norm (measured: 2.4e-6 worst), and most tensors to exact equality."""
+    gradients): held to 1e-4 of each tensor's norm (measured: 2.4e-6 .. 2.4e-5 worst), and most tensors to exact equality."""
     sc, sd_np, sd = _sharp_net(0.005)
     o1, g1, live1, l1 = _run(sc, sd_np, sd, True, max_live=0.999)  # (compact whatever has a dead sample: both nodes)
     o0, g0, live0, l0 = _run(sc, sd_np, sd, False)
@@ -95,7 +95,8 @@ def test_compacted_step_equals_the_uncompacted_step_on_a_sharp_beta_scene():
     exact = 0
     for n in g0:
         d = float((g1[n] - g0[n]).norm() / (g0[n].norm() + 1e-30))
-        assert d < 1e-5, (n, d)  # measured 2.4e-6 worst (round 5, GPU call 13); most tensors are bit-identical
+        assert d < 1e-4, (n, d)  # measured 2.4e-6 / 2.4e-5 worst on two boxes (round 5, GPU calls 13 / 14): a weight_g gradient --
+        # a sum over a row of dW with cancellation -- amplifies the reordering of dW's fp32 partial sums; most tensors are bit-identical
         exact += torch.equal(g1[n], g0[n])
     print(f"compaction: live samples {live1}; {exact} of {len(g0)} gradient tensors bit-identical")
 
