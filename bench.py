@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--torch-profile", default=None, metavar="PATH",
                     help="diagnostic: run the timed steps under torch.profiler and write the per-operator call counts / "
                          "host and device times to PATH (the step time of such a run is perturbed; not a bench line)")
+    ap.add_argument("--cprofile", default=None, metavar="PATH",
+                    help="diagnostic: the host's Python time of the timed steps by function (cProfile on the main thread and, "
+                         "through wrapped autograd Function.backward bodies, on the autograd engine's thread) -> PATH")
     ap.add_argument("--no-refine", action="store_true", help="--mode c3: skip the pose-refinement leg")
     ap.add_argument("--no-freeze", action="store_true",
                     help="let Adam move the weights during the run (default: the flat parameter bucket is restored after "
@@ -412,6 +415,26 @@ def main():
         from torch.profiler import ProfilerActivity, profile
         tprof = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True)
         tprof.__enter__()
+    cprof = None
+    if args.cprofile and rank == 0:
+        import cProfile, functools
+        from hold_amd import fitting as _m0, hold_net as _m1, loss as _m2, mano as _m3
+        cprof = [cProfile.Profile(), cProfile.Profile()]  # main thread, autograd engine thread
+
+        def _wrap(f):
+            @functools.wraps(f)
+            def g(*a, **k):
+                cprof[1].enable()
+                try:
+                    return f(*a, **k)
+                finally:
+                    cprof[1].disable()
+            return g
+        for m in (_m0, _m1, _m2, _m3):
+            for v in list(vars(m).values()):
+                if isinstance(v, type) and issubclass(v, torch.autograd.Function) and v is not torch.autograd.Function:
+                    v.backward = staticmethod(_wrap(v.backward))
+        cprof[0].enable()
     t0 = time.perf_counter()
     rays = 0
     loss = 0.0
@@ -419,6 +442,15 @@ def main():
         loss = step(args.warmup + i)
         rays += rays_per_step
     torch.cuda.synchronize()
+    if cprof is not None:
+        import io, pstats
+        cprof[0].disable()
+        with open(args.cprofile, "w") as f:
+            for name, p in zip(("main thread (forward, loss, optimiser; backward() = waiting for the engine)", "autograd engine thread (Function.backward bodies)"), cprof):
+                for key in ("tottime", "cumulative"):
+                    buf = io.StringIO()
+                    pstats.Stats(p, stream=buf).sort_stats(key).print_stats(45)
+                    f.write(f"# {name}: {args.steps} steps, sorted by {key}\n{buf.getvalue()}\n")
     if args.sync_debug and rank == 0:
         torch.cuda.set_sync_debug_mode("default")
         with open(args.sync_debug, "w") as f:
@@ -452,12 +484,15 @@ def main():
                 f.write(f"{sum(c.values()):6d}  {site}  {dict(c.most_common(5))}\n")
     if tprof is not None:
         tprof.__exit__(None, None, None)
+        tprof.export_chrome_trace(args.torch_profile + ".trace.json")  # scripts/gap_report.py attributes the device's idle time
         ka = tprof.key_averages()
         with open(args.torch_profile, "w") as f:
             f.write(f"# {args.steps} steps of --mode {args.mode}; sorted by call count\n")
             f.write(ka.table(sort_by="count", row_limit=120, max_name_column_width=70))
             f.write("\n# sorted by device time\n")
             f.write(ka.table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=70))
+            f.write("\n# sorted by the host time spent in the operator itself\n")
+            f.write(ka.table(sort_by="self_cpu_time_total", row_limit=60, max_name_column_width=70))
             # device-launching aten operators by the hold_amd / bench source line that issued them
             import collections
             sites = collections.defaultdict(lambda: [0, 0.0, collections.Counter()])
