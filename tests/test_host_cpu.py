@@ -36,6 +36,49 @@ def test_library_exports_every_declared_symbol():
     assert "getenv" not in syms
 
 
+def test_header_is_plain_c_and_a_c_program_links_the_library(tmp_path):
+    """the drop-in boundary is a C ABI: include/hold_hip.h compiles as strict C99 and as C++, and a C program that includes it links
+    libholdhip.so, gets the ABI version, the workspace sizes (pure host arithmetic) and HOLD_E_ARG for null pointers -- the calls
+    a cgo / JNI / ctypes binding makes first, none of which needs a GPU."""
+    import shutil
+    import subprocess
+    from hold_amd import _lib, build
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    build.build()
+    src = tmp_path / "consumer.c"
+    src.write_text("""
+#include <stdio.h>
+#include <string.h>
+#include "hold_hip.h"
+int main(void) {
+  hold_gemm_desc d;
+  memset(&d, 0, sizeof d);
+  if (hold_abi_version() != 1) return 1;
+  if (hold_gemm_nt(&d, NULL) != HOLD_E_ARG) return 2;              /* null pointers are refused before any launch */
+  if (hold_wgrad_workspace_floats(256, 256, 8) <= 0) return 3;
+  if (hold_trunk_h3_pack_bytes() != 116 * 16384) return 4;          /* 116 k steps of one 16 KiB slot */
+  if (hold_trunk_h3_act_scale() != 64.0f) return 5;
+  if (hold_alive_blocks(1025) != 2) return 6;                       /* 1 024 samples per block */
+  printf("abi %d\\n", hold_abi_version());
+  return 0;
+}
+""")
+    inc = os.path.join(ROOT, "include")
+    for cc, std in (("gcc", "-std=c99"), ("g++", "-std=c++17")):
+        r = subprocess.run([cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", "-x", "c" if cc == "gcc" else "c++",
+                            str(src)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    exe = tmp_path / "consumer"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-l:" + os.path.basename(_lib.LIB_PATH),
+                        "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "abi 1", (r.returncode, r.stdout, r.stderr)
+
+
 def test_bad_arguments_are_rejected_without_a_gpu():
     import ctypes as C
     from hold_amd import _lib
