@@ -103,3 +103,21 @@ def test_rccl_backend_single_rank_step_and_sampler_exchange(tmp_path):
     mp.spawn(_rccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
     r = torch.load(out)
     assert r["moved"] > 0 and r["mb"] == 0.375 and r["err"] is False
+
+
+def test_launch_stream_follows_torchs_current_stream():
+    """every entry point is launched on `_lib.stream_ptr()`: it must be torch's CURRENT stream of the current device -- also inside a
+    `torch.cuda.stream(side)` block (the overlap of copies / collectives with compute relies on it) -- whichever getter is used."""
+    from hold_amd import _lib, kernels as K
+    assert (_lib.stream_ptr().value or 0) == torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        assert (_lib.stream_ptr().value or 0) == side.cuda_stream
+        # and a kernel launched there is ordered on that stream: it sees the value written just before it on the same stream
+        x = torch.full((4096, 4), 3.0, device="cuda")
+        y = torch.zeros(4096, 8, device="cuda")
+        K.copy_cols(x, y, 4, 4096)
+        ev = torch.cuda.Event(); ev.record()
+    ev.synchronize()
+    assert torch.equal(y[:, :4], x) and float(y[:, 4:].abs().max()) == 0.0
+    assert (_lib.stream_ptr().value or 0) == torch.cuda.current_stream().cuda_stream
