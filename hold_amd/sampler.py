@@ -42,6 +42,13 @@ class UniformSampler:
 
 
 class ErrorBoundSampler:
+    PRED_WINDOW = 4  # calls whose round counts the next call's prediction looks at
+
+    @staticmethod
+    def predict_rounds(recent):
+        """rounds to launch before the first flag read, from the round counts of the last calls: their minimum (0 = no history)"""
+        return min(recent) if recent else 0
+
     def __init__(self, scene_bounding_sphere, near=0.0, N_samples=64, N_samples_eval=128, N_samples_extra=32,
                  eps=0.1, beta_iters=10, max_total_iters=5, inverse_sphere_bg=True, N_samples_inverse_sphere=32,
                  add_tiny=1e-6, rng_device="cpu"):
@@ -69,8 +76,12 @@ class ErrorBoundSampler:
         # rounds continues from where it stands, one that converged EARLIER than predicted is redone round by round (the
         # extra rounds changed the window).  Results are those of the round-by-round loop either way.  Off with sync_group
         # (the data-parallel exchange is per round by definition).
+        # The prediction is the SMALLEST round count of the last PRED_WINDOW calls (round 5): a prediction that is too low costs one
+        # more flag read per missing round, one that is too high costs the whole call again -- with batches that alternate
+        # between 2 and 3 rounds (bench.py --mode c3) "what the last call took" was wrong every time, half of the time too high.
         self.speculate = os.environ.get("HOLD_SAMPLER_SPECULATE", "1") != "0"
         self._pred_rounds = 0
+        self._recent_rounds = []
         self.last_iters = 0
         self.sum_iters = 0  # rounds summed over all calls / number of calls (bench.py: FLOP per ray of a timed region)
         self.n_calls = 0
@@ -214,7 +225,8 @@ class ErrorBoundSampler:
         else:
             round_by_round()
         S, iters = st["S"], st["iters"]
-        self._pred_rounds = iters
+        self._recent_rounds = (self._recent_rounds + [iters])[-self.PRED_WINDOW:]
+        self._pred_rounds = self.predict_rounds(self._recent_rounds)
         ns = self.N_samples
         zs = pool.get("z_samples", N, ns)
         if is_training:

@@ -561,3 +561,15 @@ def test_silhouette_oracle_per_pixel_depth_cull_follows_pytorch3d():
     behind = tri.clone()
     behind[..., 2] = -behind[..., 2].abs()
     assert float(fo.soft_silhouette(behind, ft, *args).abs().max()) == 0.0
+
+
+def test_sampler_round_prediction_is_the_recent_minimum():
+    """hold_amd.sampler (speculative rounds): a low prediction costs one more flag read, a high one the whole call again -- so the
+    next call launches the SMALLEST round count of the last PRED_WINDOW calls before it reads the flags."""
+    from hold_amd.sampler import ErrorBoundSampler as S
+    assert S.predict_rounds([]) == 0 and S.predict_rounds([3]) == 3
+    assert S.predict_rounds([3, 2, 3, 2]) == 2 and S.predict_rounds([5, 5, 5, 5]) == 5
+    s = S(3.0)
+    for it, want in ((3, 3), (2, 2), (3, 2), (3, 2), (3, 2), (3, 3)):  # the 2 leaves the window after PRED_WINDOW = 4 calls
+        s._recent_rounds = (s._recent_rounds + [it])[-S.PRED_WINDOW:]
+        assert S.predict_rounds(s._recent_rounds) == want
