@@ -573,3 +573,32 @@ def test_sampler_round_prediction_is_the_recent_minimum():
     for it, want in ((3, 3), (2, 2), (3, 2), (3, 2), (3, 2), (3, 3)):  # the 2 leaves the window after PRED_WINDOW = 4 calls
         s._recent_rounds = (s._recent_rounds + [it])[-S.PRED_WINDOW:]
         assert S.predict_rounds(s._recent_rounds) == want
+
+
+def test_gap_report_charges_idle_time_to_the_launching_operator(tmp_path):
+    """scripts/gap_report.py (the tool behind profiles/r05_c3_gap_report.txt) on a hand-made trace: three kernels with two idle gaps, the
+    first launched from inside an autograd Function's backward, the second by a bare runtime call."""
+    import json
+    import subprocess
+    import sys
+    ev = [
+        {"ph": "X", "cat": "kernel", "name": "k0", "ts": 100, "dur": 50, "args": {"correlation": 1}},
+        {"ph": "X", "cat": "kernel", "name": "k1", "ts": 180, "dur": 20, "args": {"correlation": 2}},   # 30 us after k0 ended
+        {"ph": "X", "cat": "kernel", "name": "k2", "ts": 500, "dur": 10, "args": {"correlation": 3}},   # 300 us after k1 ended
+        {"ph": "X", "cat": "cuda_runtime", "name": "hipLaunchKernel", "ts": 90, "dur": 4, "tid": 7, "args": {"correlation": 1}},
+        {"ph": "X", "cat": "cuda_runtime", "name": "hipLaunchKernel", "ts": 170, "dur": 4, "tid": 7, "args": {"correlation": 2}},
+        {"ph": "X", "cat": "cuda_runtime", "name": "hipLaunchKernel", "ts": 490, "dur": 4, "tid": 9, "args": {"correlation": 3}},
+        {"ph": "X", "cat": "cpu_op", "name": "_FieldFnBackward", "ts": 80, "dur": 120, "tid": 7},
+        {"ph": "X", "cat": "cpu_op", "name": "aten::mul", "ts": 165, "dur": 12, "tid": 7},
+    ]
+    p = tmp_path / "t.json"
+    p.write_text(json.dumps({"traceEvents": ev}))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gap_report.py"), str(p), "1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    assert "device events 3 (3 per step)" in out and "busy 0.08 ms" in out and "idle 0.33 ms per step" in out
+    rows = [ln.split() for ln in out.splitlines() if ln.startswith("    ")]
+    by = {ln[-1]: float(ln[0]) for ln in rows if len(ln) >= 4}
+    assert abs(by["_FieldFnBackward"] - 0.030) < 1e-9        # the OUTERMOST operator around the launch, not aten::mul
+    assert any("no host operator" in ln and " 0.300 " in ln for ln in out.splitlines())
+    assert "300" in out.split("gaps over 100 us")[1]
