@@ -60,6 +60,10 @@ struct R6Args {
   const float* barf;    // [39] or null
   float* sdf; int lds;  // HEAD output
   float* h[8]; int ldh; // STORE outputs ([P][ldh], columns 0..255)
+  // CONDITIONAL launch (hold_*_r6_if: the fallback of the f16x3 kernels, csrc/rmlp_h3.hip): null = always run.  Otherwise
+  // 4 words of device memory: the kernel exits at once unless [0] != 0; if it ran, the last workgroup to finish counts the
+  // event in [2] and clears [0] and its own arrival counter [1] -- every workgroup has read [0] by then
+  uint32_t* guard;
 };
 
 __device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
@@ -205,6 +209,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const uint32_t lane16 = lane * 16;
   float* embw = reinterpret_cast<float*>(smem + OFF_EMB) + wave * (32 * EMB_STR);
   const char* ring_lane = smem + lane * 16;
+  if (a.guard && __hip_atomic_load(a.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;  // wave-uniform
   const float b8 = HEAD ? *a.b8 : 0.f;  // read on the device: a host copy of a trained parameter costs a stream drain
 
   // ---- once per workgroup: biases (+ the sdf row) into LDS, the first four k steps into the ring ----
@@ -466,6 +471,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
   }
+  if (a.guard) {  // the conditional launch ran: count it once and re-arm the guard
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+      if (atomicAdd(a.guard + 1, 1u) == gridDim.x - 1) {
+        a.guard[1] = 0u;
+        atomicAdd(a.guard + 2, 1u);
+        __threadfence();
+        __hip_atomic_store(a.guard, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
 }
 
 }  // namespace
@@ -526,24 +543,29 @@ static int rmlp_launch(const R6Args& a, bool head, bool store, hipStream_t s) {
 }
 
 // SDF-only query of the sampler (the contract of hold_fused_sdf_x6 with the register-resident trunk).
-extern "C" int hold_fused_sdf_r6(const float* xc, int32_t ldx, int64_t P, const void* wpack_r6, const float* bias,
-                                 const float* w8, const float* b8, const float* barf_w, float* sdf, int32_t ld_sdf,
-                                 hold_stream_t st) {
+extern "C" int hold_fused_sdf_r6_if(const float* xc, int32_t ldx, int64_t P, const void* wpack_r6, const float* bias,
+                                    const float* w8, const float* b8, const float* barf_w, float* sdf, int32_t ld_sdf,
+                                    uint32_t* guard, hold_stream_t st) {
   if (!xc || !wpack_r6 || !bias || !w8 || !b8 || !sdf || ldx < 3 || ld_sdf < 1 || P < 0) return HOLD_E_ARG;
-  if (((uintptr_t)wpack_r6 & 15) || ((uintptr_t)w8 & 15) || ((uintptr_t)bias & 15)) return HOLD_E_ARG;
+  if (((uintptr_t)wpack_r6 & 15) || ((uintptr_t)w8 & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)guard & 3)) return HOLD_E_ARG;
   if (P == 0) return HOLD_OK;
   R6Args a = {};
   a.xc = xc; a.ldx = ldx; a.P = (long)P; a.wpack = (const char*)wpack_r6; a.bias = bias; a.w8 = w8; a.b8 = b8;
-  a.barf = barf_w; a.sdf = sdf; a.lds = ld_sdf;
+  a.barf = barf_w; a.sdf = sdf; a.lds = ld_sdf; a.guard = guard;
   return rmlp_launch(a, true, false, (hipStream_t)st);
+}
+extern "C" int hold_fused_sdf_r6(const float* xc, int32_t ldx, int64_t P, const void* wpack_r6, const float* bias,
+                                 const float* w8, const float* b8, const float* barf_w, float* sdf, int32_t ld_sdf,
+                                 hold_stream_t st) {
+  return hold_fused_sdf_r6_if(xc, ldx, P, wpack_r6, bias, w8, b8, barf_w, sdf, ld_sdf, nullptr, st);
 }
 
 // Training forward trunk: h[l] [P][ldh] (l = 0..7) = softplus outputs of lin0..lin7; columns 217..255 of h[3] receive
 // the embedding (the skip concat of shape_net.py:122-123, 1/sqrt2 folded into the packed lin4).
-extern "C" int hold_trunk_r6(const float* xc, int32_t ldx, int64_t P, const void* wpack_r6, const float* bias,
-                             const float* barf_w, float* const* h, int32_t ldh, hold_stream_t st) {
+extern "C" int hold_trunk_r6_if(const float* xc, int32_t ldx, int64_t P, const void* wpack_r6, const float* bias,
+                                const float* barf_w, float* const* h, int32_t ldh, uint32_t* guard, hold_stream_t st) {
   if (!xc || !wpack_r6 || !bias || !h || ldx < 3 || ldh < 256 || (ldh & 3) || P < 0) return HOLD_E_ARG;
-  if (((uintptr_t)wpack_r6 & 15) || ((uintptr_t)bias & 15)) return HOLD_E_ARG;
+  if (((uintptr_t)wpack_r6 & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)guard & 3)) return HOLD_E_ARG;
   R6Args a = {};
   for (int l = 0; l < 8; ++l) {
     if (!h[l] || ((uintptr_t)h[l] & 15)) return HOLD_E_ARG;
@@ -552,5 +574,10 @@ extern "C" int hold_trunk_r6(const float* xc, int32_t ldx, int64_t P, const void
   if (P == 0) return HOLD_OK;
   if (((uint64_t)P + 128) * (uint64_t)ldh * 4 >= (1ull << 32)) return HOLD_E_ARG;  // 32-bit buffer offsets: split by rows
   a.xc = xc; a.ldx = ldx; a.P = (long)P; a.wpack = (const char*)wpack_r6; a.bias = bias; a.barf = barf_w; a.ldh = ldh;
+  a.guard = guard;
   return rmlp_launch(a, false, true, (hipStream_t)st);
+}
+extern "C" int hold_trunk_r6(const float* xc, int32_t ldx, int64_t P, const void* wpack_r6, const float* bias,
+                             const float* barf_w, float* const* h, int32_t ldh, hold_stream_t st) {
+  return hold_trunk_r6_if(xc, ldx, P, wpack_r6, bias, barf_w, h, ldh, nullptr, st);
 }

@@ -15,7 +15,12 @@
 // are indistinguishable (scripts/split_precision_study.py; tests/test_rmlp_gpu.py holds this kernel to <= 1.5 x the error of
 // hold_fused_sdf_r6 on 524 288 points).  Scales: weights by s_w[l] = 2^k with max |W_l| s_w in [2^13, 2^14) (host, per matrix,
 // at pack time -- hold_amd/field.py:pack_h3); activations by the constant SA = 2^6 (softplus outputs and the embedding:
-// full precision from 2^-8 up, absolute 4.7e-10 below; an activation >= 1023 would overflow fp16 -- to +inf, i.e. loudly).
+// full precision from 2^-8 up, absolute 4.7e-10 below).  OVERFLOW GUARD (round 6): an activation >= 1023.5 would round to an
+// fp16 infinity -- and an infinity is not guaranteed to stay visible (inf x negative weight -> -inf -> softplus -> 0).  Every
+// lane therefore keeps the EXACT maximum of the scaled magnitudes it splits (one v_max3_f32 per value pair, as wgrad_h3_body
+// does) and a lane that saw one beyond fp16's largest finite value sets the caller's guard word; the entry points enqueue the
+// f32x6 kernel (csrc/rmlp.hip) right behind as a CONDITIONAL launch that exits at once unless that word is set, recomputes the
+// whole launch otherwise, counts the event and clears the word: no host read, no silent infinity.
 // The accumulators hold s_w SA a_l; the epilogue multiplies by c3[l] = 1 / s_w[l] (exact) and carries SA through softplus.
 //
 // Per k step: 16 KiB of weight limbs (8 n-tiles x 2 limbs x 1 KiB fragments, 24 KiB in rmlp.hip), 24 MFMAs (48), and a
@@ -72,6 +77,7 @@ struct H3Args {
   const float* barf;    // [39] or null
   float* sdf; int lds;  // HEAD output
   float* h[8]; int ldh; // STORE outputs ([P][ldh], columns 0..255)
+  uint32_t* guard;      // [0] set to 1 when a scaled activation left fp16's range (null: not reported)
 };
 
 __device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
@@ -218,6 +224,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   f32x16 P[8], Q[8];
   u32x4 A[2][4];  // weight fragments of two n-tiles x two limbs, double-buffered
   Limbs Bc, Bn;
+  float mx = 0.f;  // exact maximum of the scaled magnitudes this lane has split (the overflow guard)
 
   auto read_pair = [&](int slot, int pair, u32x4 (&dst)[4]) {
     const char* base = ring_lane + slot * SLOT + pair * (4 * PIECE);
@@ -340,11 +347,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // asm): the instruction selector's list scheduler is free to place pure VALU code anywhere between its operands and its
     // first user, and without the pins it collects the whole epilogue in front of the first volatile instruction
     struct SplitState { uint32_t hi[4]; float ra[4], rb[4]; };
-    auto split_op = [&](int op, int d, float x0, float x1, Limbs& out, SplitState& ss) {
+    auto split_op = [&](int op, int d, float x0, float x1, Limbs& out, SplitState& ss, bool track = true) {
       if (op == 0) {
         ss.hi[d] = cvt_pk(x0, x1);
         asm volatile("" : "+v"(ss.hi[d]));
         out.l[0][d] = ss.hi[d];
+        if (track) asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mx) : "v"(x0), "v"(x1));
       } else if (op == 1) {
         ss.ra[d] = resid<0>(ss.hi[d], x0);
       } else if (op == 2) {
@@ -367,7 +375,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       // a NaN in every accumulator (call 4 / 5 of round 5: wrong sdf -> a sampler window out of range -> a memory fault two
       // kernels later; the unit tests, which start from a quiet LDS, passed)
       const bool pad = 16 * j >= 48;
-      split_op(op, d, pad ? 0.f : er[0], pad ? 0.f : er[1], out, ss);
+      split_op(op, d, pad ? 0.f : er[0], pad ? 0.f : er[1], out, ss, !pad);
     };
     init_bias(0);
 #pragma unroll
@@ -526,6 +534,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
   }
   H3_WAIT_VM(0);  // the stream runs AHEAD steps past the last block: no LDS-DMA may be in flight when the workgroup's LDS is released
+  // 65504 = fp16's largest finite value (RN turns anything from 65520 on into an infinity; the 16 in between are given away)
+  if (a.guard && mx >= 65504.f) __hip_atomic_store(a.guard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace
@@ -573,24 +583,35 @@ static int rmlp_h3_launch(const H3Args& a, bool head, hipStream_t s) {
 }
 
 // SDF-only query of the sampler in the f16x3 arithmetic (the contract of hold_fused_sdf_r6 + the per-layer weight scales).
+// `guard` (4 words of device memory, zero-initialised once, one per stream; may be null: overflow then goes unreported):
+// [0] is set when a scaled activation left fp16's range.  With `wpack_r6` / `bias` (the operands of hold_fused_sdf_r6 for the
+// same weights) the f32x6 kernel follows as a conditional launch (hold_fused_sdf_r6_if) that recomputes the query if and only
+// if that happened, adds 1 to guard[2] and clears guard[0]: the result is then hold_fused_sdf_r6's, bit for bit.
 extern "C" int hold_fused_sdf_h3(const float* xc, int32_t ldx, int64_t P, const void* wpack_h3, const float* bias_scaled,
                                  const float* c3, const float* w8, const float* b8, const float* barf_w, float* sdf,
-                                 int32_t ld_sdf, hold_stream_t st) {
+                                 int32_t ld_sdf, uint32_t* guard, const void* wpack_r6, const float* bias,
+                                 hold_stream_t st) {
   if (!xc || !wpack_h3 || !bias_scaled || !c3 || !w8 || !b8 || !sdf || ldx < 3 || ld_sdf < 1 || P < 0) return HOLD_E_ARG;
-  if (((uintptr_t)wpack_h3 & 15) || ((uintptr_t)w8 & 15) || ((uintptr_t)bias_scaled & 15)) return HOLD_E_ARG;
+  if (((uintptr_t)wpack_h3 & 15) || ((uintptr_t)w8 & 15) || ((uintptr_t)bias_scaled & 15) || ((uintptr_t)guard & 3)) return HOLD_E_ARG;
+  if ((wpack_r6 != nullptr) != (bias != nullptr) || (wpack_r6 && !guard)) return HOLD_E_ARG;
   if (P == 0) return HOLD_OK;
   H3Args a = {};
   a.xc = xc; a.ldx = ldx; a.P = (long)P; a.wpack = (const char*)wpack_h3; a.bias = bias_scaled; a.c3 = c3; a.w8 = w8;
-  a.b8 = b8; a.barf = barf_w; a.sdf = sdf; a.lds = ld_sdf;
-  return rmlp_h3_launch(a, true, (hipStream_t)st);
+  a.b8 = b8; a.barf = barf_w; a.sdf = sdf; a.lds = ld_sdf; a.guard = guard;
+  const int rc = rmlp_h3_launch(a, true, (hipStream_t)st);
+  if (rc != HOLD_OK || !wpack_r6) return rc;
+  return hold_fused_sdf_r6_if(xc, ldx, P, wpack_r6, bias, w8, b8, barf_w, sdf, ld_sdf, guard, st);
 }
 
 // Training forward trunk in the f16x3 arithmetic: h[l] [P][ldh] (l = 0..7) = softplus outputs of lin0..lin7 (fp32,
 // unscaled); columns 217..255 of h[3] receive the embedding (the contract of hold_trunk_r6).
+// (`guard`, `wpack_r6`, `bias`: as for hold_fused_sdf_h3; the fallback is hold_trunk_r6_if)
 extern "C" int hold_trunk_h3(const float* xc, int32_t ldx, int64_t P, const void* wpack_h3, const float* bias_scaled,
-                             const float* c3, const float* barf_w, float* const* h, int32_t ldh, hold_stream_t st) {
+                             const float* c3, const float* barf_w, float* const* h, int32_t ldh, uint32_t* guard,
+                             const void* wpack_r6, const float* bias, hold_stream_t st) {
   if (!xc || !wpack_h3 || !bias_scaled || !c3 || !h || ldx < 3 || ldh < 256 || (ldh & 3) || P < 0) return HOLD_E_ARG;
-  if (((uintptr_t)wpack_h3 & 15) || ((uintptr_t)bias_scaled & 15)) return HOLD_E_ARG;
+  if (((uintptr_t)wpack_h3 & 15) || ((uintptr_t)bias_scaled & 15) || ((uintptr_t)guard & 3)) return HOLD_E_ARG;
+  if ((wpack_r6 != nullptr) != (bias != nullptr) || (wpack_r6 && !guard)) return HOLD_E_ARG;
   H3Args a = {};
   for (int l = 0; l < 8; ++l) {
     if (!h[l] || ((uintptr_t)h[l] & 15)) return HOLD_E_ARG;
@@ -599,6 +620,8 @@ extern "C" int hold_trunk_h3(const float* xc, int32_t ldx, int64_t P, const void
   if (P == 0) return HOLD_OK;
   if (((uint64_t)P + 128) * (uint64_t)ldh * 4 >= (1ull << 32)) return HOLD_E_ARG;  // 32-bit buffer offsets: split by rows
   a.xc = xc; a.ldx = ldx; a.P = (long)P; a.wpack = (const char*)wpack_h3; a.bias = bias_scaled; a.c3 = c3; a.barf = barf_w;
-  a.ldh = ldh;
-  return rmlp_h3_launch(a, false, (hipStream_t)st);
+  a.ldh = ldh; a.guard = guard;
+  const int rc = rmlp_h3_launch(a, false, (hipStream_t)st);
+  if (rc != HOLD_OK || !wpack_r6) return rc;
+  return hold_trunk_r6_if(xc, ldx, P, wpack_r6, bias, barf_w, h, ldh, guard, st);
 }

@@ -270,7 +270,9 @@ __device__ __forceinline__ void wgrad_r6_body(const float* R, int ldr, const flo
 // row outside the sample CAN exceed that headroom: every pass therefore keeps the exact maximum of the scaled values of each
 // operand (one v_max3_f32 per value pair), and a workgroup that saw one beyond 65504 repeats its share once with that
 // operand's scale taken from the exact maximum -- no overflow ever reaches dW (GPU call 12 of round 5: the first version,
-// without this, returned NaN gradients on the beta = 0.005 scene).  Workgroups need not agree on scales: a partial tile is
+// without this, returned NaN gradients on the beta = 0.005 scene).  The opposite failure -- every sampled row exactly zero, so a
+// scale of 1 for cotangents of 1e-9 in the rows not sampled -- is caught by the same maximum (non-zero but below 2^4) and repeated
+// the same way (round 6).  Workgroups need not agree on scales: a partial tile is
 // multiplied by 1 / (s_R s_X) (exact) before it is written, the reduction adds unscaled fp32 tiles as before.
 struct LimbsH { u32x4 l[8][2]; };
 struct FragH { float x[8]; f32x2 xs[4]; uint32_t hi[4]; float ra[4], rb[4]; };
@@ -504,8 +506,13 @@ __device__ __forceinline__ void wgrad_h3_body(const float* R, int ldr, const flo
     }
     WG_WAIT_VM(0);  // no LDS-DMA in flight when the ring is refilled (or released)
     // ---- did a scaled value leave fp16's range?  (65504 is the largest finite value; a NaN operand is not an overflow) ----
+    // ... or stay far BELOW the range the sample aimed at?  The sample only sees a subset of the rows: when every sampled row of
+    // an operand is exactly zero (rays that miss the node, alpha == 0) its scale is 1, and cotangents of 1e-9 .. 1e-4 in the rows
+    // it did not see would be split at that scale -- lo in fp16's subnormal range, hi with <= 11 bits, anything below 3e-8 flushed
+    // (advisor, round 5).  A non-zero exact maximum below 2^4 (the sampled maximum lands in [2^6, 2^7), and the exact one is never
+    // below the sampled one) can only mean that: the operand is re-scaled from its exact maximum like an overflowing one.
     wg_max2(mR, mX);
-    const bool ovR = mR > 65504.f, ovX = mX > 65504.f;
+    const bool ovR = mR > 65504.f || (mR > 0.f && mR < 16.f), ovX = mX > 65504.f || (mX > 0.f && mX < 16.f);
     if (!(ovR || ovX)) break;
     if (ovR) kR = __builtin_amdgcn_readfirstlane(scale_exp(mR * bitsf((uint32_t)(127 - kR) << 23), 13));
     if (ovX) kX = __builtin_amdgcn_readfirstlane(scale_exp(mX * bitsf((uint32_t)(127 - kX) << 23), 13));

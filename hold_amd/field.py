@@ -449,7 +449,7 @@ class NodeField:
             if need_in0:
                 K.embed_fwd(xc, 3, sp.L, P, in0, barf_w=barf_w)
             if USE_H3_TRUNK and "trunk_h3" in pk:
-                K.trunk_h3(xc, P, pk["trunk_h3"], pk["bias8_h3"], pk["c3_h3"], barf_w, h)
+                K.trunk_h3(xc, P, pk["trunk_h3"], pk["bias8_h3"], pk["c3_h3"], barf_w, h, pk["trunk_r6"], pk["fused"][1])
             else:
                 K.trunk_r6(xc, P, pk["trunk_r6"], pk["fused"][1], barf_w, h)
             return in0, h
@@ -504,7 +504,8 @@ class NodeField:
         self.gen += 1  # overwrites the pooled canonical points a pending backward would read
         xc, _ = self._deform(x, P, ppf, dfm, want_w=False)
         if FUSED_SDF and USE_R6 and "trunk_h3" in pk:
-            K.fused_sdf_h3(xc, P, pk["trunk_h3"], pk["bias8_h3"], pk["c3_h3"], pk["w8_sdf"], pk["b8_sdf"], barf_w, out_sdf)
+            K.fused_sdf_h3(xc, P, pk["trunk_h3"], pk["bias8_h3"], pk["c3_h3"], pk["w8_sdf"], pk["b8_sdf"], barf_w, out_sdf,
+                           pk["trunk_r6"], pk["fused"][1])
             return
         if FUSED_SDF and USE_R6 and "trunk_r6" in pk:
             K.fused_sdf_r6(xc, P, pk["trunk_r6"], pk["fused"][1], pk["w8_sdf"], pk["b8_sdf"], barf_w, out_sdf)

@@ -156,17 +156,37 @@ def alive_index(sdf, P, beta):
     return idx
 
 
-def fused_sdf_h3(xc, P, wpack_h3, bias8_scaled, c3, w8, b8, barf_w, out_sdf):
+_H3_GUARD = {}
+
+
+def h3_guard(device):
+    """the overflow guard of the f16x3 trunk kernels (include/hold_hip.h): 4 device words per device, zeroed once -- [0] the
+    flag a launch sets when a scaled activation left fp16's range, [2] how many launches were recomputed in f32x6 because of it
+    (the conditional launch behind every f16x3 call; no host read on the path)"""
+    k = str(device)
+    if k not in _H3_GUARD:
+        _H3_GUARD[k] = torch.zeros(4, dtype=torch.int32, device=device)
+    return _H3_GUARD[k]
+
+
+def h3_overflow_count(device):
+    """launches of the f16x3 trunk kernels on `device` so far whose result came from the f32x6 fallback (one host read)"""
+    return int(h3_guard(device)[2]) if str(device) in _H3_GUARD else 0
+
+
+def fused_sdf_h3(xc, P, wpack_h3, bias8_scaled, c3, w8, b8, barf_w, out_sdf, wpack_r6=None, bias8=None):
     """the sampler's SDF query in the two-limb fp16 arithmetic (csrc/rmlp_h3.hip): wpack_h3 / bias8_scaled / c3 from
-    field.pack_weights in mode f16x3 (field.pack_h3); otherwise the contract of fused_sdf_r6"""
+    field.pack_weights in mode f16x3 (field.pack_h3); otherwise the contract of fused_sdf_r6.  wpack_r6 / bias8 (fused_sdf_r6's
+    operands): the f32x6 kernel follows as a conditional launch that recomputes the query iff an activation overflowed fp16."""
     L = _lib.lib()
     assert wpack_h3.numel() * wpack_h3.element_size() == L.hold_trunk_h3_pack_bytes() and wpack_h3.dtype == torch.float16
     assert b8.is_cuda and b8.numel() == 1 and b8.dtype == torch.float32 and c3.numel() == 8 and c3.dtype == torch.float32
     from . import field as _f, gemm as _g
     assert L.hold_trunk_h3_act_scale() == _f.H3_ACT_SCALE
     e0 = _g._prof_begin()
+    assert (wpack_r6 is None) == (bias8 is None)
     call("hold_fused_sdf_h3", ptr(xc), _ld(xc), P, ptr(wpack_h3), ptr(bias8_scaled), ptr(c3), ptr(w8), ptr(b8),
-         ptr(barf_w), ptr(out_sdf), _ld(out_sdf))
+         ptr(barf_w), ptr(out_sdf), _ld(out_sdf), ptr(h3_guard(xc.device)), ptr(wpack_r6), ptr(bias8))
     _g._prof_end(e0, 2.0 * P * (40 * 256 + 6 * 65536 + 217 * 256 + 256), "fused_sdf_kernel", 20.0 * P)
 
 
@@ -194,8 +214,10 @@ def trunk_r6(xc, P, wpack_r6, bias8, barf_w, h):
         _g._prof_end(e0, 2.0 * n * (40 * 256 + 6 * 65536 + 217 * 256), "trunk_r6_kernel", n * (16.0 + 8 * 1024))
 
 
-def trunk_h3(xc, P, wpack_h3, bias8_scaled, c3, barf_w, h):
-    """training forward trunk in the two-limb fp16 arithmetic: the contract of trunk_r6 (h in fp32, unscaled)"""
+def trunk_h3(xc, P, wpack_h3, bias8_scaled, c3, barf_w, h, wpack_r6=None, bias8=None):
+    """training forward trunk in the two-limb fp16 arithmetic: the contract of trunk_r6 (h in fp32, unscaled); wpack_r6 /
+    bias8: the conditional f32x6 fallback, as for fused_sdf_h3"""
+    assert (wpack_r6 is None) == (bias8 is None)
     import ctypes as C
     assert wpack_h3.numel() * wpack_h3.element_size() == _lib.lib().hold_trunk_h3_pack_bytes()
     from . import gemm as _g
@@ -206,7 +228,8 @@ def trunk_h3(xc, P, wpack_h3, bias8_scaled, c3, barf_w, h):
         n = min(step, P - r0)
         arr = (C.c_void_p * 8)(*[t[r0:].data_ptr() for t in h])
         e0 = _g._prof_begin()
-        call("hold_trunk_h3", ptr(xc[r0:]), _ld(xc), n, ptr(wpack_h3), ptr(bias8_scaled), ptr(c3), ptr(barf_w), arr, ld)
+        call("hold_trunk_h3", ptr(xc[r0:]), _ld(xc), n, ptr(wpack_h3), ptr(bias8_scaled), ptr(c3), ptr(barf_w), arr, ld,
+             ptr(h3_guard(xc.device)), ptr(wpack_r6), ptr(bias8))
         _g._prof_end(e0, 2.0 * n * (40 * 256 + 6 * 65536 + 217 * 256), "trunk_r6_kernel", n * (16.0 + 8 * 1024))
 
 

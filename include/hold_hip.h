@@ -387,6 +387,16 @@ int hold_fused_sdf_r6(const float* xc, int32_t ldx, int64_t P, const void* wpack
                       const float* b8, const float* barf_w, float* sdf, int32_t ld_sdf, hold_stream_t stream);
 int hold_trunk_r6(const float* xc, int32_t ldx, int64_t P, const void* wpack_r6, const float* bias, const float* barf_w,
                   float* const* h, int32_t ldh, hold_stream_t stream);
+/* CONDITIONAL launches of the two (the device-side fallback of the f16x3 entry points below; no host read involved):
+ * `guard` = 4 x uint32 of device memory, zeroed once by the caller, used by ONE stream at a time.  guard == NULL: exactly
+ * hold_fused_sdf_r6 / hold_trunk_r6.  Otherwise every workgroup exits at once unless guard[0] != 0; if the kernel ran, the
+ * last workgroup to finish adds 1 to guard[2] (a monotone count the caller may read whenever it likes) and clears guard[0]
+ * (and guard[1], the arrival counter it uses). */
+int hold_fused_sdf_r6_if(const float* xc, int32_t ldx, int64_t P, const void* wpack_r6, const float* bias, const float* w8,
+                         const float* b8, const float* barf_w, float* sdf, int32_t ld_sdf, uint32_t* guard,
+                         hold_stream_t stream);
+int hold_trunk_r6_if(const float* xc, int32_t ldx, int64_t P, const void* wpack_r6, const float* bias, const float* barf_w,
+                     float* const* h, int32_t ldh, uint32_t* guard, hold_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * The same trunk in the TWO-LIMB fp16 arithmetic "f16x3" (hold_amd/csrc/rmlp_h3.hip; shape_net.py:84-130): every operand
@@ -394,10 +404,18 @@ int hold_trunk_r6(const float* xc, int32_t ldx, int64_t P, const void* wpack_r6,
  * hi_w hi_x + hi_w lo_x + lo_w hi_x go to v_mfma_f32_32x32x16_f16 with fp32 accumulation -- three matrix instructions per
  * product instead of six, 16 KiB of weight limbs per k step instead of 24; error against fp64 as hold_fused_sdf_r6
  * (tests/test_rmlp_gpu.py holds it to <= 1.5 x that kernel's).  Activations are scaled by hold_trunk_h3_act_scale() = 2^6
- * inside the kernel (an activation >= 1023 overflows fp16 to +inf: the output is then inf / NaN, never silently wrong);
- * weights by a per-matrix s_w[l] = 2^k chosen by the caller with max |W_l| s_w[l] < 2^15 ([2^13, 2^14) recommended).
- * wpack_h3: hold_trunk_h3_pack_bytes() bytes of fp16, [115 k steps][8 n-tiles nt][2 limbs t][2 halves h][32 rows i][8 e],
- *   the k steps, rows and k order of wpack_r6, limb_t of s_w[l] W_l.
+ * inside the kernel; weights by a per-matrix s_w[l] = 2^k chosen by the caller with max |W_l| s_w[l] < 2^15 ([2^13, 2^14)
+ * recommended).
+ * OVERFLOW GUARD: a (scaled) activation >= 65504, i.e. an activation >= 1023.5, has no fp16 representation.  The kernels keep
+ *   the exact maximum of every value they split and set guard[0] when one left the range (guard: the 4 words of
+ *   hold_*_r6_if above; NULL = unreported).  With wpack_r6 / bias (hold_trunk_r6's operands for the same weights; both or
+ *   neither; they require guard) the entry point enqueues the f32x6 kernel right behind as a conditional launch: the result
+ *   of an overflowing call is then hold_fused_sdf_r6's / hold_trunk_r6's bit for bit, guard[2] counts such calls and
+ *   guard[0] is clear again -- never a silent infinity, and no host synchronisation.
+ * wpack_h3: hold_trunk_h3_pack_bytes() bytes of fp16, [116 k steps][8 n-tiles nt][2 limbs t][2 halves h][32 rows i][8 e]:
+ *   k steps 0..3 = layer 0 with K = 64 (columns 39.. zero: FOUR k steps, one more than wpack_r6's K = 48 -- the ring slot of a
+ *   k step is then the same in every layer), limb_t(s_w[0] W_0)[32 nt + i][16 step + 8 h + e]; k steps 4 + 16 (l - 1) + j =
+ *   layer l = 1..7 in the rows and k order of wpack_r6, limb_t(s_w[l] W_l).
  * bias_scaled: [8][256] = bias_l s_w[l] hold_trunk_h3_act_scale();  c3: [8] = 1 / s_w[l] (device memory).
  * hold_fused_sdf_h3 / hold_trunk_h3: otherwise the contracts of hold_fused_sdf_r6 / hold_trunk_r6 (outputs in fp32, unscaled).
  * ---------------------------------------------------------------------------------------- */
@@ -405,9 +423,10 @@ int64_t hold_trunk_h3_pack_bytes(void);
 float hold_trunk_h3_act_scale(void);
 int hold_fused_sdf_h3(const float* xc, int32_t ldx, int64_t P, const void* wpack_h3, const float* bias_scaled,
                       const float* c3, const float* w8, const float* b8, const float* barf_w, float* sdf, int32_t ld_sdf,
-                      hold_stream_t stream);
+                      uint32_t* guard, const void* wpack_r6, const float* bias, hold_stream_t stream);
 int hold_trunk_h3(const float* xc, int32_t ldx, int64_t P, const void* wpack_h3, const float* bias_scaled, const float* c3,
-                  const float* barf_w, float* const* h, int32_t ldh, hold_stream_t stream);
+                  const float* barf_w, float* const* h, int32_t ldh, uint32_t* guard, const void* wpack_r6,
+                  const float* bias, hold_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * LDS-resident layer chains of the ImplicitNet for the TRAINING path (hold_amd/csrc/chain.hip): up to 8 consecutive

@@ -210,6 +210,32 @@ def sampler_round(z_vals, sdf, beta, beta0, eps=0.1, beta_iters=10):
     return beta, dists, d_star, weights, trans
 
 
+def beta_search_conditioning(z_vals, sdf, beta, beta0, eps=0.1, beta_iters=10, rel_noise=1e-4):
+    """fp64 run of the beta line search of ray_sampler.py:207-220 (sampler_round above) that also reports which rays are
+    BORDERLINE: the search takes 1 + beta_iters threshold decisions `error_bound(beta_mid) <= eps` per ray, and a ray whose error
+    bound comes within rel_noise * eps of the threshold at one of them is decided by the rounding of whoever evaluates the bound
+    (exp of a 640-term cumulative sum, minus one: fp32 evaluations of the same bound differ by ~1e-5 relative) -- a different
+    decision moves beta by up to half the current bracket.  Every other ray follows the same bracket sequence in any fp32-class
+    arithmetic, and its beta is defined to rounding.  Returns (beta64 [N], borderline [N] bool, margin [N]) with margin = the
+    smallest |error bound - eps| / eps over the decisions the fp64 search took."""
+    z, s = z_vals.double(), sdf.double()
+    b = beta.double().reshape(-1).clone()
+    beta0 = float(beta0)
+    dists, d_star = d_star_bound(z, s)
+    cur = error_bound(beta0, s, dists, d_star)
+    margin = (cur - eps).abs() / eps
+    b[cur <= eps] = beta0
+    bmin, bmax = beta0 * torch.ones_like(b), b
+    for _ in range(beta_iters):
+        bmid = (bmin + bmax) / 2.0
+        cur = error_bound(bmid.unsqueeze(-1), s, dists, d_star)
+        live = bmax > bmin  # a ray already at beta0 re-decides at beta0 itself: the same decision as the first
+        margin = torch.where(live, torch.minimum(margin, (cur - eps).abs() / eps), margin)
+        bmax = torch.where(cur <= eps, bmid, bmax)
+        bmin = torch.where(cur > eps, bmid, bmin)
+    return bmax, margin <= rel_noise, margin
+
+
 def round_cdf(z_vals, sdf, beta, more, add_tiny=1e-6):
     """the CDF a round samples from (ray_sampler.py:247-293), given the round's final beta: the error-bound pdf while the
     hierarchy grows (`more`), the rendering weights + 1e-5 in the last round.  Any float dtype (the parity tests evaluate

@@ -554,5 +554,24 @@ def test_wgrad_h3_scales_follow_the_operands(rscale, xscale):
         ref2 = R2.double().t() @ X.double()
         assert torch.isfinite(dW2).all()
         assert ((dW2.double() - ref2).abs().max() / ref2.abs().max()).item() < 1e-5
+        # UNDER-scaling (advisor, round 5): every row the sample sees is exactly zero (rays that miss the node, alpha == 0), so
+        # the sampled scale is 1, while the rows it does not see carry cotangents of ~1e-6 (and one workgroup's of ~1e-9): split
+        # at scale 1 their lo limbs would be fp16 subnormals and anything below 3e-8 would vanish.  The exact running maximum
+        # tells the workgroup (non-zero, far below the sample's target) and it repeats its share with exact scales.
+        R3 = torch.randn(P, 256, device=dev) * 1e-6 * rscale
+        R3[rows % 64 < 4] = 0.0
+        R3[8192:12288] *= 1e-3
+        dW3 = torch.zeros(256, 256, device=dev)
+        db3 = torch.zeros(256, device=dev)
+        gemm.wgrad(R3, X, dW3, db3)
+        ref3 = R3.double().t() @ X.double()
+        assert ((dW3.double() - ref3).abs().max() / ref3.abs().max()).item() < 1e-5
+        # the 1e-9 workgroup on its own (its share is invisible in the full sum): same relative accuracy
+        dW4 = torch.zeros(256, 256, device=dev)
+        gemm.wgrad(R3[8192:12288], X[8192:12288], dW4, None)
+        ref4 = R3[8192:12288].double().t() @ X[8192:12288].double()
+        assert ((dW4.double() - ref4).abs().max() / ref4.abs().max()).item() < 1e-5
+        refb3 = R3.double().sum(0)
+        assert ((db3.double() - refb3).abs().max() / refb3.abs().max()).item() < 1e-5
     finally:
         hold_amd.set_precision(prev)

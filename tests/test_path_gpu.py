@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from hold_amd import field as F
-from parity_common import hip_input, hip_net, ho, oracle_input, rel_err, setup
+from parity_common import hip_input, hip_net, ho, oracle_input, rel_err, setup, z_in_reference_order
 
 pytestmark = pytest.mark.gpu
 
@@ -53,18 +53,22 @@ def test_eval_forward_matches_oracle_given_z(ctx, arith):
 
 
 def test_eval_forward_matches_reference_golden(ctx, gold_dir):
-    """reference outputs (recorded by scripts/make_golden.py) with the reference's own z_vals fed in.
-    Per-node and background quantities are tie-free and must agree to 1e-4; the merged composite depends
-    on torch.sort's unspecified order of equal z (see oracle.merge_factors) and is checked loosely."""
+    """reference outputs (recorded by scripts/make_golden.py) with the reference's own z_vals fed in -- EVERY output key at
+    1e-4, the merged composite included: the reference's order of equal z (an artefact of its unstable sort) is made explicit
+    in the z fed to the HIP path (parity_common.z_in_reference_order), so the stable HIP merge IS the reference's merge.
+    (Round 5 held the composite keys to the reference only through rgb's PSNR.)"""
     g = dict(np.load(os.path.join(gold_dir, "eval.npz")))
     sc = ctx["sc"]
     b, _ = oracle_input(sc, ctx["sd"], [1, 3], 8, 8)
     net = hip_net(sc, ctx["sd_np"])
-    zo = {n: torch.from_numpy(g[f"{n}.z_vals"]).cuda() for n in sc["entities"]}
+    zo = {n: z.cuda() for n, z in z_in_reference_order(g, list(sc["entities"])).items()}
     out = net(hip_input(b, net), z_override=zo)
     for k in ["right.fg_rgb", "right.normal", "right.depth", "right.mask_prob", "object.fg_rgb", "object.normal",
-              "object.depth", "object.bg_weights", "bg_rgb_only"]:
+              "object.depth", "object.bg_weights", "bg_rgb_only",
+              "rgb", "fg_rgb", "normal", "depth", "mask_prob", "semantics", "fg_weights", "bg_weights", "fg_semantics",
+              "right.fg_weights", "object.fg_weights"]:
         assert np.abs(out[k].cpu().numpy() - g["out." + k]).max() < 1e-4, k
+    assert np.array_equal(out["instance_map"].cpu().numpy(), g["out.instance_map"])
     fac = net._last_factors
     for n in sc["entities"]:
         assert np.abs(fac[n]["canonical_pts"].cpu().numpy() - g[f"{n}.x_c"].reshape(-1, 3)).max() < 1e-5
@@ -157,8 +161,25 @@ def test_sampler_rounds_match_trace(ctx, gold_dir):
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         K.sampler_beta(zw, sw, S, N, None, None, 0, beta, beta0, 0.1, 10, flag)
         ref = torch.from_numpy(g[f"r{r}.beta"]).to(dev)
-        ok = ((beta - ref).abs() <= 1e-4 * ref.abs() + 1e-7)
-        assert float(ok.float().mean()) > 0.97, (r, float((beta - ref).abs().max()))
+        # EVERY ray whose search is well conditioned at 1e-4 (round 5 waved 3 % of the rays through): the line
+        # search (ray_sampler.py:207-220) is 11 threshold decisions `error bound <= eps` per ray, and only a ray whose bound comes
+        # within 1e-4 eps of the threshold at one of them (fp32 evaluations of that bound differ by ~1e-5) can be decided
+        # differently by a different rounding -- ho.beta_search_conditioning finds those rays in fp64; every other ray follows
+        # the same brackets in any fp32 arithmetic.  Against the fp64 search AND against the reference-pinned fp32 trace.
+        if r == 0:  # (the kernel has overwritten `beta` with its result: the search's starting value again)
+            b_in = torch.sqrt((1.0 / (4.0 * np.log(1.1))) * ((z[:, 1:] - z[:, :-1]) ** 2).sum(-1)).cpu()
+        else:
+            b_in = torch.from_numpy(g[f"r{r - 1}.beta"])
+        b64, borderline, _ = ho.beta_search_conditioning(z.cpu(), sdf.cpu(), b_in, beta0, 0.1, 10, 1e-4)
+        well = ~borderline
+        assert int(borderline.sum()) <= max(2, N // 50), int(borderline.sum())  # ... and that is almost every ray
+        err64 = (beta.cpu().double() - b64).abs()
+        assert bool((err64[well] <= 1e-4 * b64[well] + 1e-7).all()), (r, float((err64 / b64)[well].max()))
+        assert bool(((ref.cpu().double() - b64).abs()[well] <= 1e-4 * b64[well] + 1e-7).all())
+        errr = (beta - ref).abs().cpu()
+        assert bool((errr[well] <= 1e-4 * ref.cpu().abs()[well] + 1e-7).all()), (r, float(errr[well].max()))
+        # a borderline ray ends inside the bracket its other decision would have left: within a factor 2 of the fp64 beta
+        assert bool(((beta.cpu().double() / b64)[borderline] < 2.0001).all() and ((b64 / beta.cpu().double())[borderline] < 2.0001).all())
         assert abs(float(flag.view(torch.float32)) - float(ref.max())) < 1e-3 * float(ref.max())
         more = r < nr - 1
         n_new = 128 if more else 64
@@ -391,14 +412,16 @@ def _check_against_reference_golden(net, out, g, nodes, max_tie_frac):
         en = np.abs(out[f"{n}.normal"].cpu().numpy() - g[f"out.{n}.normal"])[ok]
         assert np.quantile(en, 0.99) < 1e-4 and en.max() < 1e-3, (n, en.max())
     assert np.abs(out["bg_rgb_only"].cpu().numpy() - g["out.bg_rgb_only"]).max() < 1e-4
-    # The merged composite depends on torch.sort's unspecified order of EQUAL z in the reference (near = 0 and the sphere exit
-    # exist in every node; oracle.merge_factors): which node's sample survives the [(n-1) : -n] trim at either end moves depth /
-    # normal by up to 1e-2 on a ray.  As in the single-hand golden test only the rendered colour is held to the reference
-    # (PSNR > 50 dB over the tie-free rays); the composite keys are held to 1e-4 against the oracle in stable-merge mode --
-    # which the CPU suite pins to these same fixtures in the reference's own order (tests/test_oracle_golden.py) -- by
-    # test_two_hand_scene_three_nodes / test_c1_c5_sampler_configs_match_oracle.
-    d = (out["rgb"].cpu().numpy() - g["out.rgb"])[ok]
-    assert 10 * np.log10(1.0 / max(float((d ** 2).mean()), 1e-20)) > 50
+    # The merged composite: the reference's order of EQUAL z (torch.sort without `stable`; near = 0 and the sphere exit exist in
+    # every node, eval-mode extras repeat shared uniform samples; which node's sample gets the interval behind a tie moves depth /
+    # normal by up to 1e-2 on EVERY ray) is explicit in the z the callers feed in (parity_common.z_in_reference_order), so every
+    # composite key of every ray without a K = 15 tie is held to the reference's own output at 1e-4 (round 5: rgb's PSNR only).
+    for k in ("rgb", "fg_rgb", "depth", "mask_prob", "semantics", "fg_semantics", "fg_weights", "bg_weights"):
+        if "out." + k in g:
+            assert np.abs(out[k].cpu().numpy() - g["out." + k])[ok].max() < 1e-4, k
+    en = np.abs(out["normal"].cpu().numpy() - g["out.normal"])[ok]
+    assert np.quantile(en, 0.99) < 1e-4 and en.max() < 1e-3, en.max()
+    assert (out["instance_map"].cpu().numpy() == g["out.instance_map"])[ok].mean() > 0.999
     return int(tie_ray.sum())
 
 
@@ -410,7 +433,7 @@ def test_two_hand_scene_matches_reference_golden(gold_dir):
     sc, sd_np, sd, osc = setup(n_frames=2, two_hands=True)
     b, _ = oracle_input(sc, sd, [0, 1], 6, 6)
     net = hip_net(sc, sd_np)
-    zo = {n: torch.from_numpy(g[f"{n}.z_vals"]).cuda() for n in sc["entities"]}
+    zo = {n: z.cuda() for n, z in z_in_reference_order(g, list(sc["entities"])).items()}
     out = net(hip_input(b, net), z_override=zo)
     assert out["fg_weights"].shape[1] == g["out.fg_weights"].shape[1] == 3 * 98 - 2 * 3 + 1
     _check_against_reference_golden(net, out, g, list(sc["entities"]), 0.15)
@@ -441,7 +464,7 @@ def test_c1_c5_match_reference_golden(ctx, gold_dir, name, n_samples, W, frames)
         assert (dz > 1e-3).mean() < 0.02, (n, dz.max())
     mse = ((out["rgb"].cpu().numpy() - g["out.rgb"]) ** 2).mean()
     assert 10 * np.log10(1.0 / max(mse, 1e-20)) > 50
-    out = net(hip_input(b, net), z_override={n: torch.from_numpy(g[f"{n}.z_vals"]).cuda() for n in sc["entities"]})
+    out = net(hip_input(b, net), z_override={n: z.cuda() for n, z in z_in_reference_order(g, list(sc["entities"])).items()})
     _check_against_reference_golden(net, out, g, list(sc["entities"]), 0.15)
 
 

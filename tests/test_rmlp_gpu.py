@@ -248,3 +248,65 @@ def test_h3_kernels_do_not_depend_on_stale_lds():
                 assert torch.equal(a, b)
     finally:
         hold_amd.set_precision(prev)
+
+
+@pytest.mark.parametrize("where", ["activation", "coordinate"])
+def test_h3_overflow_is_caught_on_the_device_and_recomputed_in_f32x6(where):
+    """the f16x3 trunk scales its activations by the constant 2^6, so an activation >= 1023.5 has no fp16
+    representation -- and an fp16 infinity is not guaranteed to stay visible (inf x negative weight -> -inf -> softplus -> 0).
+    The kernels keep the exact maximum of everything they split; a launch in which one left the range sets the guard word, and the
+    conditional f32x6 launch the entry point enqueues behind it recomputes the WHOLE launch: the result is hold_fused_sdf_r6's /
+    hold_trunk_r6's bit for bit, the event is counted, the guard is armed again -- and a launch without an overflow is untouched by
+    all of it.  Driven here by one layer-1 bias of 1100 (a softplus output beyond 1023.5 for every point) or by ONE point whose
+    coordinate is 2000 (the raw coordinates are activations of layer 0)."""
+    from hold_amd import field as F, kernels as K
+    dev = _dev()
+    P = 128 * 300 + 77
+    w0, S, bias, w8, bw = _net(11, dev, True)
+    g = torch.Generator().manual_seed(12)
+    xc = torch.zeros(P, 4)
+    xc[:, :3] = torch.rand(P, 3, generator=g) * 1.6 - 0.8
+    bias_ovf, xc_ovf = bias.clone(), xc.clone()
+    if where == "activation":
+        bias_ovf[1, 5] = 1100.0
+    else:
+        xc_ovf[12345, 1] = -2000.0  # a NEGATIVE coordinate: the guard looks at magnitudes
+    xc, xc_ovf = xc.to(dev), xc_ovf.to(dev)
+    b8 = torch.full((1,), 0.25, device=dev)
+    guard = K.h3_guard(dev)
+    pr6 = F.pack_r6(w0, S)
+
+    def both(xq, bq):
+        pk, bs, c3 = _h3_pack(w0, S, bq)
+        o3, o6 = torch.empty(P, 1, device=dev), torch.empty(P, 1, device=dev)
+        K.fused_sdf_h3(xq, P, pk, bs, c3, w8, b8, bw, o3, pr6, bq)
+        K.fused_sdf_r6(xq, P, pr6, bq, w8, b8, bw, o6)
+        h3 = [torch.empty(P, 256, device=dev) for _ in range(8)]
+        h6 = [torch.empty(P, 256, device=dev) for _ in range(8)]
+        K.trunk_h3(xq, P, pk, bs, c3, bw, h3, pr6, bq)
+        K.trunk_r6(xq, P, pr6, bq, bw, h6)
+        return o3, o6, h3, h6
+
+    n0 = K.h3_overflow_count(dev)
+    o3, o6, h3, h6 = both(xc, bias)  # no overflow: the f16x3 results, not the fallback's
+    assert K.h3_overflow_count(dev) == n0 and guard[:2].tolist() == [0, 0]
+    assert not torch.equal(o3, o6) and (o3 - o6).abs().max().item() < 2e-5
+    o3, o6, h3, h6 = both(xc_ovf, bias_ovf)
+    assert K.h3_overflow_count(dev) == n0 + 2 and guard[:2].tolist() == [0, 0]
+    assert torch.equal(o3, o6)
+    for a, b in zip(h3, h6):
+        assert torch.equal(a, b)
+    if where == "activation":
+        assert float(h6[1][:, 5].min()) > 1023.5 and torch.isfinite(o6).all()
+    # without the fallback operands the flag is the report: it stays set until the caller clears it
+    pk, bs, c3 = _h3_pack(w0, S, bias_ovf)
+    K.fused_sdf_h3(xc_ovf, P, pk, bs, c3, w8, b8, bw, o3)
+    assert guard[:3].tolist() == [1, 0, n0 + 2]
+    guard[0] = 0
+    # ... and the next clean launch is a clean launch
+    o3b, _, _, _ = both(xc, bias)
+    assert K.h3_overflow_count(dev) == n0 + 2 and guard[:2].tolist() == [0, 0]
+    pk, bs, c3 = _h3_pack(w0, S, bias)
+    o3c = torch.empty(P, 1, device=dev)
+    K.fused_sdf_h3(xc, P, pk, bs, c3, w8, b8, bw, o3c)
+    assert torch.equal(o3b, o3c)
