@@ -208,14 +208,22 @@ class FlatAdam:
         names = {id(p): n for n, p in self.net.named_parameters()}
         self.load_named_state({names[id(p)]: opt.state[p] for p in self.params if p in opt.state and opt.state[p]})
 
-    def load_reference_state(self, opt_state_dict):
+    def load_reference_state(self, opt_state_dict, ambiguous="raise", index_to_name=None):
         """Adam state of a REFERENCE checkpoint (`ckpt["optimizer_states"][0]`: {"state": {index: {...}}, "param_groups":
         [{"params": [indices], ...}, ...]}) -> this optimiser.  The group structure must be the reference's (one group per
         node, then the main group: reference_groups()); the main group's order is `model.parameters()` order, the same
         here, so its entries map by position.  Inside a NODE group the reference's order comes from a python set: entries
         are matched to that node's parameters by SHAPE, and where two parameters of a node share a shape (MANO's
-        global_orient / transl tables) and carry different state the assignment is ambiguous and this raises -- pass
-        `torch.optim.Adam.load_state_dict` + import_from instead if the order is known."""
+        global_orient / transl tables, both [n_frames, 3] and both trained: EVERY real reference checkpoint) and carry
+        different state the assignment is ambiguous.  What then happens is the caller's choice:
+          ambiguous="raise" (default)  ValueError -- nothing is loaded;
+          ambiguous="zero"             those tables start from zero moments (Adam's bias correction keeps running from the
+                                       checkpoint's step count: their first updates are damped, not wrong), everything
+                                       else -- all network weights, the unambiguous tables -- is loaded; a warning names them;
+          index_to_name={index: name}  the caller knows the order (e.g. recorded `id()` order of the saving process, or
+                                       recovered by matching exp_avg against the tables' sparsity pattern): explicit
+                                       assignment of checkpoint indices to parameter names, applied before shape matching.
+        Model WEIGHTS of a reference checkpoint are not affected by any of this (state_dict names are the reference's)."""
         groups = self.reference_groups()
         pg = opt_state_dict["param_groups"]
         if len(pg) != len(groups) or any(len(a["params"]) != len(b["params"]) for a, b in zip(pg, groups)):
@@ -230,10 +238,16 @@ class FlatAdam:
                     if idx in state and state[idx]:
                         named[names[id(p)]] = state[idx]
                 continue
-            entries = [state[idx] for idx in a["params"] if idx in state and state[idx]]
+            taken = set()
+            for idx in a["params"]:
+                if index_to_name and idx in index_to_name and idx in state and state[idx]:
+                    named[index_to_name[idx]] = state[idx]
+                    taken.add(idx)
+            entries = [state[idx] for idx in a["params"] if idx in state and state[idx] and idx not in taken]
             by_shape = {}
             for p in b["params"]:
-                by_shape.setdefault(tuple(p.shape), []).append(p)
+                if names[id(p)] not in named:
+                    by_shape.setdefault(tuple(p.shape), []).append(p)
             for shape, ps in by_shape.items():
                 cand = [e for e in entries if tuple(e["exp_avg"].shape) == shape]
                 if not cand:
@@ -244,9 +258,15 @@ class FlatAdam:
                          for c in cand) and len(cand) == len(ps):
                     for p_, c in zip(ps, cand):
                         named[names[id(p_)]] = c
+                elif ambiguous == "zero":
+                    import warnings
+                    warnings.warn("FlatAdam.load_reference_state: Adam moments of " + ", ".join(names[id(p_)] for p_ in ps) +
+                                  " start from zero (same shape, different state: the checkpoint's order inside a node group is "
+                                  "a python set's)")
                 else:
                     raise ValueError(f"FlatAdam.load_reference_state: {len(ps)} parameters of node group {gi} share the shape "
-                                     f"{shape}; the reference orders a node group by a python set, the assignment is ambiguous")
+                                     f"{shape}; the reference orders a node group by a python set, the assignment is ambiguous "
+                                     "(ambiguous='zero' loads everything else; index_to_name= resolves it)")
         self.load_named_state(named)
 
     def state_dict(self):

@@ -62,11 +62,20 @@ def tile_chunks(n_rays, world, chunk_rays):
     rank's own tile differs across ranks whenever a tile size straddles a multiple of chunk_rays (98 305 rays on 3 ranks in
     16 384-ray chunks: 2, 2 and 3 forwards) -- the third forward of the last rank would then wait for collectives nobody
     else issues.  Every rank derives the same number from (n_rays, world, chunk_rays) without communication."""
-    largest = max(hi - lo for lo, hi in (ray_tile(n_rays, r, world) for r in range(world)))
-    return max(1, -(-largest // chunk_rays))
+    tiles = [hi - lo for lo, hi in (ray_tile(n_rays, r, world) for r in range(world))]
+    n_chunks = max(1, -(-max(tiles) // chunk_rays))
+    # A tile with fewer rays than chunks would leave a rank with an EMPTY chunk, which train_step / render_frame refuse (an
+    # empty forward would have to mirror the other ranks' collectives).  Refused HERE, from numbers every rank shares, so
+    # that all ranks raise together before any of them has entered a collective (advisor r5: a rank raising alone while
+    # the others wait in an all-reduce is a hang, not an error).
+    if min(tiles) < n_chunks:
+        raise ValueError(f"tile_chunks: {n_rays} rays over {world} ranks in chunks of {chunk_rays} would give a rank fewer rays "
+                         f"({min(tiles)}) than forwards ({n_chunks}); use fewer ranks or a larger chunk")
+    return n_chunks
 
 
 def chunk_bounds(n, n_chunks):
-    """[(lo, hi)] of n_chunks balanced, contiguous chunks of n rays (sizes differ by at most one; none empty while
-    n >= n_chunks; an empty tail chunk (lo == hi) otherwise -- callers skip the forward but not the collectives)."""
+    """[(lo, hi)] of n_chunks balanced, contiguous chunks of n rays: sizes differ by at most one, none empty while
+    n >= n_chunks.  For n < n_chunks some chunks ARE empty (lo == hi) and train_step / render_frame refuse them -- which
+    tile_chunks rules out on every rank at once."""
     return [(n * c // n_chunks, n * (c + 1) // n_chunks) for c in range(n_chunks)]

@@ -51,11 +51,12 @@ def with_params(net, batch, epoch, step):
     return b
 
 
-def training_step(net, loss_fn, batch, epoch=0, step=0):
+def training_step(net, loss_fn, batch, epoch=0, step=0, **forward_kw):
     """hold.py:110-137 on an already flattened batch (uv [B,P,2], gt.rgb [B,P,3], gt.mask [B,P], idx [B], ...):
-    -> (loss tensor, loss dict, model outputs)."""
+    -> (loss tensor, loss dict, model outputs).  ``forward_kw``: HOLDNet.forward's test hooks (rng = recorded draws,
+    z_override = recorded z_vals: tests/test_dropin_gpu.py replays the reference's own steps with them)."""
     b = with_params(net, batch, epoch, step)
-    out = net(b)
+    out = net(b, **forward_kw)
     ld = loss_fn(b, out)
     return ld["loss"], ld, out
 
@@ -130,16 +131,20 @@ VIS_KEYS = ("rgb", "instance_map", "bg_rgb_only")  # + every key containing fg_r
 
 
 @torch.no_grad()
-def inference_step(net, batch, epoch=0, step=0, chunk_rays=65536, no_vis=False, render_downsample=1, device="cuda"):
+def inference_step(net, batch, epoch=0, step=0, chunk_rays=65536, no_vis=False, render_downsample=1, device="cuda",
+                   z_override=None):
     """hold.py:169-208: eval-mode render of the batch's full pixel grid.  Same output mapping as the reference
     (merged vis keys + the batch itself), but the frame is rendered in chunks of ``chunk_rays`` (default 65 536 instead
-    of the dataset's ``pixel_per_batch`` = 512) that stay on the device, and copied to the host once at the end."""
+    of the dataset's ``pixel_per_batch`` = 512) that stay on the device, and copied to the host once at the end.
+    ``z_override`` (test hook): {node: z_vals [B * total_pixels, S]} used instead of the sampler's, chunk by chunk."""
     XD = output_class()
     to = lambda v: v.to(device) if torch.is_tensor(v) else v
     b = {k: to(v) for k, v in batch.items()}
+    # model.eval() only (hold.py:171): nn.Module.eval() is train(False) on the children, it does NOT call the embedders' own
+    # eval() -- the BARF masks stay on in a validation pass during training; render.py:43-47 switches them off itself before it
+    # calls inference_step: disable_barf() below.  (Until round 6 this function did it too: found by replaying the reference
+    # module's own inference_step, tests/test_dropin_gpu.py.)
     net.eval()
-    for node in net.nodes.values():
-        node.implicit_network.embedder_obj.eval()
     b = with_params(net, b, epoch, step)
     output = {}
     if not no_vis:
@@ -151,7 +156,11 @@ def inference_step(net, batch, epoch=0, step=0, chunk_rays=65536, no_vis=False, 
         for lo in range(0, total, chunk_rays):
             c = dict(b)
             c["uv"] = b["uv"][:, lo:lo + chunk_rays].contiguous()
-            o = net(c)
+            zo = None
+            if z_override is not None:
+                zo = {n: z.reshape(B, total, -1)[:, lo:lo + chunk_rays].reshape(-1, z.shape[-1]).contiguous().to(device)
+                      for n, z in z_override.items()}
+            o = net(c, z_override=zo)
             keep = {k: v for k, v in o.items()
                     if k in VIS_KEYS or "fg_rgb.vis" in k or "mask_prob" in k or "normal" in k}
             parts.append(keep)
@@ -164,6 +173,17 @@ def inference_step(net, batch, epoch=0, step=0, chunk_rays=65536, no_vis=False, 
         output = {k: v.detach().cpu() for k, v in output.items()}  # the only D2H of the frame
     output.update({k: v for k, v in b.items() if k not in output})
     return XD(output)
+
+
+def disable_barf(net):
+    """render.py:43-47: `disable barf masks` -- the embedders of every node's implicit network and of the two background
+    networks; sticky, as in the reference (BarfEmbedder.eval sets no_barf, embedders.py:124-125)."""
+    for node in net.nodes.values():
+        node.implicit_network.embedder_obj.eval()
+    for name in ("bg_implicit_network", "bg_rendering_network"):
+        emb = getattr(getattr(net.background, name, None), "embedder_obj", None)
+        if emb is not None and hasattr(emb, "eval"):
+            emb.eval()
 
 
 def downsample_rendering(batch, k):
@@ -188,4 +208,4 @@ def downsample_rendering(batch, k):
     return out
 
 
-__all__ = ["Loss", "training_step", "train_step", "inference_step", "render_frame", "pixel_losses"]
+__all__ = ["Loss", "training_step", "train_step", "inference_step", "render_frame", "pixel_losses", "disable_barf"]

@@ -16,10 +16,8 @@ def sdf_func_with_deformer(deformer, sdf_fn, training, x, deform_info):
     verts = deform_info.get("verts")
     B = tfs.shape[0]
     x = x.reshape(B, -1, 3)
-    if tfs.dim() == 3:  # object: [B,4,4] (object_node.py:76-79)
-        x_c, _ = deformer.forward(x, tfs, return_weights=False, inverse=True, verts=verts)
-    else:
-        x_c, _ = deformer.forward(x, tfs, return_weights=False, inverse=True, verts=verts)
+    # tfs: [B,4,4] for the object (object_node.py:76-79), [B,16,4,4] for a hand -- both deformers take the same call
+    x_c, _ = deformer.forward(x, tfs, return_weights=False, inverse=True, verts=verts)
     out = sdf_fn(x_c, cond)
     return out[:, :, 0:1], x_c, out[:, :, 1:]
 

@@ -458,6 +458,28 @@ def test_flat_adam_loads_an_optimizer_state_shaped_like_the_reference_checkpoint
     opt2 = FlatAdam(net2, lr=5e-4)
     with pytest.raises(ValueError, match="ambiguous"):
         opt2.load_reference_state(ref2.state_dict())
+    # ... unless the caller chooses: (1) zero moments for the ambiguous tables, everything else loaded (advisor r5: every REAL
+    # reference checkpoint has MANO's global_orient / transl tables, both [n_frames, 3], both trained)
+    sd2 = ref2.state_dict()
+    with pytest.warns(UserWarning, match="start from zero"):
+        opt2.load_reference_state(sd2, ambiguous="zero")
+    names2 = {id(p): n for n, p in net2.named_parameters()}
+    n_zero = 0
+    for p, off in zip(opt2.params, opt2.offsets):
+        got = opt2.m[off:off + p.numel()].view(p.shape)
+        if torch.equal(got, ref2.state[p]["exp_avg"]):
+            continue
+        assert float(got.abs().max()) == 0.0, names2[id(p)]
+        n_zero += 1
+    assert n_zero == 2 and opt2.step_count == 1
+    # (2) an explicit index -> name map for the node group (here: the construction order, which this process knows)
+    idx_map = {}
+    for gi, (a, b) in enumerate(zip(sd2["param_groups"], opt2.reference_groups())):
+        if gi < len(net2.nodes):
+            idx_map.update({i: names2[id(p)] for i, p in zip(a["params"], b["params"])})
+    opt2.load_reference_state(sd2, index_to_name=idx_map)
+    for p, off in zip(opt2.params, opt2.offsets):
+        assert torch.equal(opt2.m[off:off + p.numel()].view(p.shape), ref2.state[p]["exp_avg"])
     t2 = opt2.torch_optimizer()
     t2.load_state_dict(ref2.state_dict())  # with the order known (same construction) torch's positional load is exact
     opt2.import_from(t2)

@@ -241,6 +241,75 @@ def test_beta_search_conditioning_on_the_reference_trace(gold_dir):
         assert torch.equal(b32, ref.float())  # the fp32 oracle IS the recorded trace
 
 
+def test_oracle_replays_the_reference_modules_three_training_steps(gold_dir):
+    """tests/golden/hold_steps.npz = the reference's Lightning module at work (scripts/make_golden_hold_steps.py:
+    HOLD.training_step x 3 with its Loss, configure_optimizers' Adam, clip_grad_norm_(0.5)).  The oracle, fed the recorded
+    draws, its OWN sampler in the loop, its Loss restatement, autograd, the same clip and torch.optim.Adam with the reference's
+    groups, must walk the same trajectory: per-step loss and gradient norm, z_vals up to the discontinuous inverse-CDF stage,
+    every parameter after the third update.  (The GPU suite replays the same recording through the HIP path:
+    tests/test_dropin_gpu.py.)"""
+    from oracle import targets_oracle as to
+    g = _load(gold_dir, "hold_steps.npz")
+    sc, sd_np, sd, osc = setup(n_frames=4, barf_iter=int(g["cfg.barf_iter"]))
+    nodes = list(sc["entities"])
+    sdg = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+    names = [k[2:] for k in g if k.startswith("p.")]
+    # (the MANO layer's own pose / shape parameters, body_models.py, are trainable by flag but never reached by a gradient)
+    assert all(float(g["dnorm." + n]) == 0.0 for n in names if n not in sdg)
+    names = [n for n in names if n in sdg]
+    node_names = [n for n in names if ".params." in n]
+    lr = float(g["cfg.lr"])
+    opt = torch.optim.Adam([{"params": [sdg[n] for n in node_names], "lr": 0.1 * lr},
+                            {"params": [sdg[n] for n in names if n not in node_names], "lr": lr}], lr=lr, eps=1e-8)
+    W, epoch = int(g["cfg.W"]), int(g["cfg.epoch"])
+    uv = syn.make_uv(W, W)
+    for k in range(int(g["cfg.steps"])):
+        pre = f"s{k}."
+        step = int(g["cfg.first_step"]) + k
+        b = syn.make_batch(sc, g["cfg.frames"][k].tolist(), uv, W, W, seed=1 + k)
+        inp = {kk: torch.from_numpy(v) for kk, v in b.items()}
+        idx = inp["idx"]
+        for nid in nodes:
+            p_ = f"nodes.{nid}.params."
+            inp[f"{nid}.global_orient"], inp[f"{nid}.transl"] = sdg[p_ + "global_orient.weight"][idx], sdg[p_ + "transl.weight"][idx]
+            if nid != "object":
+                inp[f"{nid}.pose"], inp[f"{nid}.betas"] = sdg[p_ + "pose.weight"][idx], sdg[p_ + "betas.weight"][torch.zeros_like(idx)]
+        rng = {"bg_t": torch.from_numpy(g[pre + f"rand.{2 * len(nodes)}"])}
+        for i, nid in enumerate(nodes):
+            rng[nid] = {"t_uniform": torch.from_numpy(g[pre + f"rand.{2 * i}"]), "u_final": torch.from_numpy(g[pre + f"rand.{2 * i + 1}"]),
+                        "perm": torch.from_numpy(g[pre + f"perm.{i}"])}
+        # the oracle's own sampler with the recorded draws ...
+        # (detached copies, not no_grad: the oracle's normal path takes d sdf / d x through autograd)
+        o_s = ho.holdnet_forward(osc, {kk: v.detach() for kk, v in sdg.items()}, {kk: (v.detach() if torch.is_tensor(v) else v) for kk, v in inp.items()},
+                                 True, rng=rng, current_epoch=epoch, barf_alpha_iter=int(g["cfg.barf_iter"]) + 1 + k) if k == 0 else None
+        if o_s is not None:
+            for nid in nodes:
+                dz = np.abs(o_s[f"{nid}.z_vals"].numpy() - g[pre + f"{nid}.z_vals"])
+                assert (dz > 1e-4).mean() < 0.02 and dz.max() < 0.1, (nid, dz.max())
+        # ... and the step itself on the reference's z (a moved sample would move the loss by more than the bar below)
+        zo = {nid: torch.from_numpy(g[pre + f"{nid}.z_vals"]) for nid in nodes}
+        out = ho.holdnet_forward(osc, sdg, inp, True, rng=rng, z_override=zo, current_epoch=epoch,
+                                 barf_alpha_iter=int(g["cfg.barf_iter"]) + 1 + k)
+        out["step"], out["epoch"] = step, epoch
+        ld = to.loss_forward({"gt.rgb": inp["gt.rgb"], "gt.mask": inp["gt.mask"]}, out)
+        assert abs(float(ld["loss"]) - float(g[pre + "loss"])) < 1e-5 * float(g[pre + "loss"]), (k, float(ld["loss"]), float(g[pre + "loss"]))
+        for key in ("rgb", "semantics", "depth", "mask_prob"):
+            assert np.abs(out[key].detach().numpy().reshape(g[pre + "out." + key].shape) - g[pre + "out." + key]).max() < 5e-5, (k, key)
+        opt.zero_grad()
+        ld["loss"].backward()
+        gn = torch.nn.utils.clip_grad_norm_([sdg[n] for n in names], float(g["cfg.clip"]))
+        assert abs(float(gn) - float(g[pre + "grad_norm"])) < 3e-4 * float(g[pre + "grad_norm"]), (k, float(gn), float(g[pre + "grad_norm"]))
+        opt.step()
+    worst = ("", 0.0)
+    for n in names:
+        t = sdg[n].detach().reshape(-1)
+        t = t if t.numel() <= 4096 else t[:: max(1, t.numel() // 1024)][:1024]
+        share = np.sqrt(t.numel() / sdg[n].numel())
+        r = np.linalg.norm(t.double().numpy() - g["p." + n]) / (float(g["pnorm." + n]) * share + 1e-30)
+        worst = max(worst, (n, r), key=lambda x: x[1])
+    assert worst[1] < 1e-4, worst
+
+
 def test_fitting_losses_match_reference(gold_dir):
     """oracle/fitting_oracle.py:loss_fn_h / loss_fn_ih against the reference's own code/src/fitting/loss.py outputs"""
     from fitting_loss_cases import run_single_hand, run_two_hand

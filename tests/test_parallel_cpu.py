@@ -2,6 +2,7 @@
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -301,6 +302,10 @@ def test_tile_chunks_give_every_rank_the_same_number_of_forwards():
                         assert all(0 < hi - lo <= chunk for lo, hi in b)
     assert hit > 20  # the cases above do contain the disagreement
     assert tile_chunks(98305, 3, 16384) == 3 and [-(-(hi - lo) // 16384) for lo, hi in (ray_tile(98305, r, 3) for r in range(3))] == [2, 2, 3]
+    # a tile with fewer rays than forwards would leave a rank an empty chunk: refused from numbers EVERY rank shares, i.e. by
+    # all ranks together and before any collective (advisor r5: one rank raising alone is a hang for the others)
+    with pytest.raises(ValueError):
+        tile_chunks(5, 4, 1)  # tiles 1, 1, 1, 2 -> 2 forwards, three ranks own one ray
 
 
 def _chunked_tile_worker(rank, world, port, n, chunk, out):

@@ -271,6 +271,8 @@ def test_h3_overflow_is_caught_on_the_device_and_recomputed_in_f32x6(where):
         bias_ovf[1, 5] = 1100.0
     else:
         xc_ovf[12345, 1] = -2000.0  # a NEGATIVE coordinate: the guard looks at magnitudes
+        bw = bw.clone()
+        bw[:3] = 1.0  # the raw coordinates' embedding weight (BARF only ever weights the frequencies, embedders.py:92-105)
     xc, xc_ovf = xc.to(dev), xc_ovf.to(dev)
     b8 = torch.full((1,), 0.25, device=dev)
     guard = K.h3_guard(dev)
