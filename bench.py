@@ -534,7 +534,8 @@ def main():
         # kernel families that run the two-limb fp16 arithmetic in mode f16x3 (3 limb products issued per algorithmic product on
         # v_mfma_f32_32x32x16_f16, same dense peak as bf16); every other split-precision family issues 6 bf16 limb products
         from hold_amd import field as _field
-        h3_fams = ({"fused_sdf_kernel", "wgrad_h3_kernel"} | ({"trunk_r6_kernel"} if _field.USE_H3_TRUNK else set())) if h3 else set()
+        h3_fams = ({"fused_sdf_kernel", "wgrad_h3_kernel", "rchain_h3_kernel", "rchain_a2_h3_kernel", "rchain_dbwd_h3_kernel"} |
+                   ({"trunk_r6_kernel"} if _field.USE_H3_TRUNK else set())) if h3 else set()
         scene = ("configs[3]-like ARCTIC two-hand (right+left+object+background), " if args.two_hands else
                  "hold_bottle1_itw-like single-hand (right+object+background), ")
         if args.mode == "c3":
@@ -607,7 +608,8 @@ def main():
             if args.shape_report:
                 json.dump(gemm_shapes(prof), open(args.shape_report, "w"), indent=1)
             split = {"fused_sdf_kernel", "wgrad_kernel", "wgrad_h3_kernel", "chain_kernel", "gemm_nt_kernel", "trunk_r6_kernel", "rchain_kernel",
-                     "rchain_bg_kernel", "rchain_a2_kernel", "rchain_dbwd_kernel", "rgemm_kernel", "rnarrow_kernel"} if x6 else set()
+                     "rchain_bg_kernel", "rchain_a2_kernel", "rchain_dbwd_kernel", "rgemm_kernel", "rnarrow_kernel",
+                     "rchain_h3_kernel", "rchain_a2_h3_kernel", "rchain_dbwd_h3_kernel"} if x6 else set()
             labels = {"gemm_nt_kernel": ("gemm_nt_kernel<x6> (one layer per launch, 3-limb split on v_mfma_f32_32x32x16_bf16)"
                                          if x6 else "gemm_nt_kernel (one layer per launch, v_mfma_f32_32x32x2_f32)"),
                       "trunk_r6_kernel": ("rmlp_h3_kernel<STORE> (forward trunk, 8 layers per launch, register-resident, two fp16 limbs, "
@@ -628,6 +630,13 @@ def main():
                       "rchain_dbwd_kernel": "rsweep_kernel<DBWD> (second-order ascending sweep, 8 layers per launch, register-resident, "
                                             "two side inputs and two results as whole lines through LDS, 3-limb split on "
                                             "v_mfma_f32_32x32x16_bf16)",
+                      "rchain_h3_kernel": "rsweep_h3_kernel<DSP> (descending sweep of the normal path, 7 layers per launch, register-resident, "
+                                          "two fp16 limbs / three products on v_mfma_f32_32x32x16_f16, per-point operand scales)",
+                      "rchain_a2_h3_kernel": "rsweep_h3_kernel<DSP+a2> (first-order backward sweep, 7 layers per launch, register-resident, "
+                                             "two side inputs as whole lines through LDS, two fp16 limbs, per-point operand scales)",
+                      "rchain_dbwd_h3_kernel": "rsweep_h3_kernel<DBWD> (second-order ascending sweep, 8 layers per launch, register-resident, "
+                                               "two side inputs and two results as whole lines through LDS, two fp16 limbs, per-point "
+                                               "operand scales)",
                       "chain_kernel": ("chain_x6_kernel (any sweep not routed to the register-resident kernels: 7-8 trunk layers per launch, "
                                        "LDS-resident, 3-limb split on v_mfma_f32_32x32x16_bf16)" if x6 else
                                        "chain_kernel (7-8 trunk layers per launch, LDS-resident, v_mfma_f32_32x32x2_f32)"),
@@ -690,8 +699,48 @@ def main():
                                              "frac": by_ / t_ / 1e9 / HBM_PEAK_GBPS, "launches": n_,
                                              "avg_launch_ms": t_ / n_ * 1e3, "time_share": t_ / dt,
                                              "algorithmic_bytes_per_launch_avg": by_ / n_}
-            dom = max((k for k in agg), key=lambda k: ent[k]["time_share"])
-            d = ent[dom]
+            # The top-level object is the dominant kernel TEMPLATE of the step: the sweeps are one kernel template
+            # instantiated per mode (rocprof lists rsweep[_h3]_kernel<...> rows), the weight gradients another (whole-dW kernel +
+            # its tile / reduction helpers stay separate families here).  A template's numbers are those of its families taken
+            # together: time-weighted, i.e. total FLOP, total bytes, total time, per average launch.
+            template_of = {"rchain_kernel": "rsweep_kernel", "rchain_a2_kernel": "rsweep_kernel", "rchain_dbwd_kernel": "rsweep_kernel",
+                           "rchain_bg_kernel": "rsweep_kernel", "rchain_h3_kernel": "rsweep_h3_kernel",
+                           "rchain_a2_h3_kernel": "rsweep_h3_kernel", "rchain_dbwd_h3_kernel": "rsweep_h3_kernel"}
+            tmpl = {}
+            for name in agg:
+                tmpl.setdefault(template_of.get(name, name), []).append(name)
+            dom_t = max(tmpl, key=lambda t: sum(ent[k]["time_share"] for k in tmpl[t]))
+            fams = tmpl[dom_t]
+            if len(fams) == 1:
+                dom = fams[0]
+                d = ent[dom]
+            else:
+                dom = dom_t
+                n_ = sum(agg[k][2] for k in fams)
+                t_ = sum(agg[k][0] for k in fams)
+                fl_iss = sum(agg[k][1] * ent[k]["limb_products_issued_per_product"] for k in fams)
+                fl_ = sum(agg[k][1] for k in fams)
+                alg_b = sum(agg[k][3] for k in fams)
+                have_pmc = all(ent[k]["traffic"] for k in fams)
+                pmc_b = sum(ent[k]["traffic"] * agg[k][2] for k in fams) if have_pmc else None
+                peak = ent[fams[0]]["mfma_peak"]
+                floor_mfma, floor_hbm = fl_iss / (peak * 1e12) / n_, (pmc_b if pmc_b else alg_b) / (HBM_PEAK_GBPS * 1e9) / n_
+                d = {"bound": "hbm" if floor_hbm > floor_mfma else "mfma", "mfma_achieved": fl_iss / t_ / 1e12, "mfma_peak": peak,
+                     "mfma_frac": fl_iss / t_ / 1e12 / peak, "hbm_frac": alg_b / t_ / 1e9 / HBM_PEAK_GBPS,
+                     "hbm_frac_measured_bytes": (pmc_b / t_ / 1e9 / HBM_PEAK_GBPS) if pmc_b else None,
+                     "floor_ms": {"mfma": floor_mfma * 1e3, "hbm": floor_hbm * 1e3}, "launches": n_, "avg_launch_ms": t_ / n_ * 1e3,
+                     "time_share": t_ / dt, "flop_per_launch_avg": fl_ / n_, "algorithmic_bytes_per_launch_avg": alg_b / n_,
+                     "traffic": (pmc_b / n_) if pmc_b else None, "traffic_source": ent[fams[0]]["traffic_source"],
+                     "arithmetic": ent[fams[0]]["arithmetic"], "fp32_equivalent_tflops": fl_ / t_ / 1e12,
+                     "note": "one kernel template, its instantiations taken together (time-weighted): " + ", ".join(
+                         f"{k} {ent[k]['time_share'] * 100:.1f} %" for k in sorted(fams, key=lambda k: -ent[k]["time_share"])) +
+                         "; each is listed on its own under kernels"}
+                if d["bound"] == "hbm":
+                    d.update(achieved=alg_b / t_ / 1e9, peak=HBM_PEAK_GBPS, unit="GB/s", frac=alg_b / t_ / 1e9 / HBM_PEAK_GBPS)
+                else:
+                    d.update(achieved=d["mfma_achieved"], peak=peak, unit="TFLOP/s", frac=d["mfma_frac"])
+                labels[dom] = (f"{dom} (csrc/rchain{'_h3' if 'h3' in dom else ''}.hip: the register-resident backward sweeps -- DSP, "
+                               "DSP+a2, DBWD instantiations of one template)")
             res["roofline"] = {"bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
                                "frac": d["frac"], "traffic": d["traffic"],
                                "mfma_frac": d["mfma_frac"], "hbm_frac": d["hbm_frac"],

@@ -161,6 +161,8 @@ SIGNATURES = {
     "hold_chain": [C.POINTER(ChainDesc), _P],
     "hold_chain_x6": [C.POINTER(ChainDesc), _P],
     "hold_chain_r6": [C.POINTER(ChainDesc), _P],
+    "hold_chain_r6_if": [C.POINTER(ChainDesc), _P, _P],
+    "hold_chain_h3": [C.POINTER(ChainDesc), _P, _P, _P, _P],
     "hold_mesh_sdf": [_P, _I, _L, _P, _I, _I, _P, _I, _F, _P, _P, _P],
     "hold_ray_off_surface": [_P, _I, _L, _I, _P, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P],
     "hold_pixel_loss_fwd": [_P, _P, _P, _P, _L, _I, C.POINTER(LossNodes), _P, _P, _P],
@@ -201,6 +203,7 @@ def _declare(L):
     L.hold_gemm_r6_pack_bytes.restype = C.c_int64
     L.hold_gemm_r6_pack_bytes.argtypes = [C.c_int32]
     L.hold_chain_r6_pack_bytes.restype = C.c_int64
+    L.hold_chain_h3_pack_bytes.restype = C.c_int64
     L.hold_chain_pack_floats.argtypes = [C.c_int32, C.c_int32]
     L.hold_chain_pack_floats.restype = C.c_int64
     L.hold_chain_x6_pack_bytes.argtypes = [C.c_int32, C.c_int32]

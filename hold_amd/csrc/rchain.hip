@@ -66,6 +66,10 @@ struct RCArgs {
   const float* aux2[8];
   float* out[8];
   float* out2[8];
+  // CONDITIONAL launch (hold_chain_r6_if: the fallback of hold_chain_h3, csrc/rchain_h3.hip; protocol of rmlp.hip): null =
+  // always run; otherwise 4 device words -- exit at once unless [0] != 0; having run, the last workgroup counts the event in
+  // [2] and clears [0] and its arrival counter [1]
+  uint32_t* guard;
 };
 
 __device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
@@ -165,6 +169,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int NW_IN0 = 8 * NAUX;  // DBWD chain layer 0, step 0: the two side tiles just requested stay in flight
   static_assert(NW_ODD < 64, "vmcnt field");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (a.guard && __hip_atomic_load(a.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;  // wave-uniform
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool is3 = wave == 3;
@@ -545,6 +550,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       uby = t;
     }
   }
+  if (a.guard) {  // the conditional launch ran: count it once and re-arm the guard
+    RC_WAIT_VM(0);
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+      if (atomicAdd(a.guard + 1, 1u) == gridDim.x - 1) {
+        a.guard[1] = 0u;
+        atomicAdd(a.guard + 2, 1u);
+        __threadfence();
+        __hip_atomic_store(a.guard, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
 }
 
 }  // namespace
@@ -598,8 +616,11 @@ static int rsweep_launch(const RCArgs& a, hipStream_t s) {
 //   mode DBWD (8 layers, first_chunks 5, skip_layer 3, aux1 / aux2 / out / out2 all given; d->wpack = the stream of
 //              hold_trunk_r6, hold_trunk_r6_pack_bytes() bytes; d->side is NOT read: the skip layer's side columns must
 //              be in aux2[3][:, 217..255], see the header of this file).
-extern "C" int hold_chain_r6(const hold_chain_desc* dp, hold_stream_t st) {
-  if (!dp) return HOLD_E_ARG;
+extern "C" int hold_chain_r6_if(const hold_chain_desc* dp, uint32_t* guard, hold_stream_t st);
+extern "C" int hold_chain_r6(const hold_chain_desc* dp, hold_stream_t st) { return hold_chain_r6_if(dp, nullptr, st); }
+// hold_chain_r6 as a CONDITIONAL launch (guard != NULL: see hold_fused_sdf_r6_if in include/hold_hip.h)
+extern "C" int hold_chain_r6_if(const hold_chain_desc* dp, uint32_t* guard, hold_stream_t st) {
+  if (!dp || ((uintptr_t)guard & 3)) return HOLD_E_ARG;
   const hold_chain_desc& d = *dp;
   if (d.P < 0 || !d.in || !d.wpack || d.skip_layer != 3) return HOLD_E_ARG;
   const int so = d.skip_out ? d.skip_out : 217;
@@ -613,7 +634,7 @@ extern "C" int hold_chain_r6(const hold_chain_desc* dp, hold_stream_t st) {
   if (((uint64_t)d.P + 128) * (uint64_t)d.ld * 4 >= (1ull << 32)) return HOLD_E_ARG;  // 32-bit byte offsets
   if (((uint64_t)d.P + 128) * (uint64_t)d.ld_in * 4 >= (1ull << 32)) return HOLD_E_ARG;
   RCArgs a = {};
-  a.P = (long)d.P; a.wpack = (const char*)d.wpack; a.in = d.in; a.ld_in = d.ld_in; a.ld = d.ld;
+  a.P = (long)d.P; a.wpack = (const char*)d.wpack; a.in = d.in; a.ld_in = d.ld_in; a.ld = d.ld; a.guard = guard;
   const bool has2 = d.aux2[0] != nullptr;
   if (db && !has2) return HOLD_E_ARG;
   for (int l = 0; l < nl; ++l) {

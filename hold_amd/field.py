@@ -38,6 +38,7 @@ COMPACT = os.environ.get("HOLD_COMPACT", "1") != "0"  # exact sample compaction 
 COMPACT_ALIGN = 128       # compacted row counts are padded to this (the kernels' fast paths: P % 16 == 0, 128-point blocks)
 COMPACT_MAX_LIVE = 0.85   # compaction moves 9 KiB per live sample: above this live fraction it costs more than it saves
 USE_R6_BWD = os.environ.get("HOLD_R6_BWD", "1") != "0"  # ... and for the descending sweeps (csrc/rchain.hip)
+USE_H3_BWD = os.environ.get("HOLD_H3_BWD", "1") != "0"  # mode f16x3: the three backward sweeps too (csrc/rchain_h3.hip; A/B switch)
 # the 256 x 256 weight gradients of a backward as one grouped launch (gemm.WgradGroup / hold_wgrad_group_x6)
 USE_WGRAD_GROUP = os.environ.get("HOLD_WGRAD_GROUP", "1") != "0"
 USE_R6_GEMM = os.environ.get("HOLD_R6_GEMM", "1") != "0"  # ... and for the rendering net's layers / lin8 (csrc/rgemm.hip)
@@ -234,6 +235,14 @@ def pack_h3(w0, S):
     return torch.cat([p0, ps]).contiguous(), sw
 
 
+def pack_h3_stack(S):
+    """hold_chain_h3 (DSP) stream of L [256, 256] matrices: every layer in the virtual k order (r6_kmap), two fp16 limbs of the
+    matrix scaled by its own s_w = 2^k (max |M| s_w in [2^13, 2^14)) -> (fp16 [L x 16 steps][8 nt][2 t][2 h][32 i][8 e], s_w [L])"""
+    _, ex = torch.frexp(S.abs().amax(dim=(1, 2)))
+    sw = torch.ldexp(torch.ones_like(ex, dtype=torch.float32), 14 - ex)
+    return _lay_r6_stack(torch.stack(split_limbs_h(S * sw.view(-1, 1, 1)))).contiguous(), sw
+
+
 def pack_r6_stack(S):
     """hold_chain_r6 (DSP) stream of L [256, 256] matrices: every layer in the virtual k order (r6_kmap)"""
     return _lay_r6_stack(torch.stack(split_limbs(S))).contiguous()
@@ -324,7 +333,9 @@ def _h3_plan(device):
     IS = n0 + torch.arange(ns, device=device).view(7, 256, 256)
     l2 = lambda I: torch.stack([I + t * N for t in range(2)])
     seg = torch.cat([torch.zeros(n0, dtype=torch.long, device=device), 1 + torch.arange(7, device=device).repeat_interleave(65536)])
-    return dict(idx=torch.cat([_lay_r6_0(l2(I0)), _lay_r6_stack(l2(IS))]).to(torch.int32).contiguous(), seg=seg)
+    ISTf = IS.transpose(1, 2).flip(0)  # descending sweeps (hold_chain_h3, DSP): chain layer j = W_{7-j}^T, scaled by s_w[7 - j]
+    return dict(idx=torch.cat([_lay_r6_0(l2(I0)), _lay_r6_stack(l2(IS))]).to(torch.int32).contiguous(), seg=seg,
+                idx_bwd=_lay_r6_stack(l2(ISTf)).to(torch.int32).contiguous())
 
 
 def frag_pack_stack(S):
@@ -383,9 +394,14 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool, trunk=None):
     if config.h3():  # two-limb fp16 stream of the forward trunk (csrc/rmlp_h3.hip) + its scales, all on the device
         sw = h3_scales(w0, S)
         src3 = torch.cat([torch.nn.functional.pad(w0, (0, H3_K0 - spec.K0)).reshape(-1), S.reshape(-1)])
-        pk["trunk_h3"] = torch.stack(split_limbs_h(src3 * sw[plan["h3"]["seg"]])).reshape(-1).index_select(0, plan["h3"]["idx"])
+        limbs_h = torch.stack(split_limbs_h(src3 * sw[plan["h3"]["seg"]])).reshape(-1)
+        pk["trunk_h3"] = limbs_h.index_select(0, plan["h3"]["idx"])
         pk["bias8_h3"] = (bias8 * (sw * H3_ACT_SCALE).view(8, 1)).contiguous()
         pk["c3_h3"] = (1.0 / sw).contiguous()
+        # the backward sweeps in the same arithmetic (hold_chain_h3): the descending ones read the transposed matrices (chain
+        # layer j = W_{7-j}^T, the same limbs gathered in another order), the ascending one the forward stream itself
+        pk["chain_bwd_h3"] = limbs_h.index_select(0, plan["h3"]["idx_bwd"])
+        pk["c3_bwd_h3"] = pk["c3_h3"][1:].flip(0).contiguous()
     if rw is None:  # implicit net only (ImplicitNet.forward / gradient)
         return pk
     return _pack_render(pk, spec, rw, rb, need_bwd, dev)
@@ -478,7 +494,8 @@ class NodeField:
         if USE_CHAIN:
             outs = [t[l - 1] if (keep_all or l - 1 in (0, 3)) else None for l in range(7, 0, -1)]
             K.chain(K.CHAIN_DSP, P, t[7], pk["chain_bwd"], 7, 32, skip_layer=3, aux1=[h[l - 1] for l in range(7, 0, -1)],
-                    out=outs, wpack_x6=pk.get("chain_bwd_x6"), wpack_r6=pk.get("chain_bwd_r6") if USE_R6_BWD else None)
+                    out=outs, wpack_x6=pk.get("chain_bwd_x6"), wpack_r6=pk.get("chain_bwd_r6") if USE_R6_BWD else None,
+                    **self._h3_bwd(pk, "chain_bwd_h3", "c3_bwd_h3"))
             # raw columns 217.. of t_3 = d sdf / d (skip embedding): `ge` IS that view (self._ge_buffer), no copy
             assert ge.data_ptr() == t[3].data_ptr() + 4 * sp.skip_out
         else:
@@ -491,6 +508,13 @@ class NodeField:
                 else:
                     G.gemm_nt(t[l], WT[l], t[l - 1], epi=G.EPI_MUL_DSP, aux1=h[l - 1])
         G.gemm_narrow(t[0], WT[0], ge, N=ge.shape[1], accumulate=True)
+
+    @staticmethod
+    def _h3_bwd(pk, stream, c3):
+        """K.chain's operands of the f16x3 sweeps (hold_chain_h3) when the pack carries them"""
+        if USE_H3_BWD and USE_R6_BWD and stream in pk:
+            return dict(wpack_h3=pk[stream], c3=pk[c3])
+        return {}
 
     def _ge_buffer(self, t, P):
         """d sdf / d embedding [P, E]: with the layer chains it stays where the descending sweep leaves its skip part --
@@ -641,7 +665,7 @@ class NodeField:
                 # (side_in_t3), this copy is for anyone who did not
                 K.copy_cols(gebar, t[3][:, sp.skip_out:], sp.E, P)
             K.chain(K.CHAIN_DBWD, P, gebar, pk["fused"][0], 8, 5, skip_layer=3, side=gebar, aux1=h, aux2=t, out=vb,
-                    out2=a2, wpack_x6=pk.get("chain_fwd_x6"), wpack_r6=wr6)
+                    out2=a2, wpack_x6=pk.get("chain_fwd_x6"), wpack_r6=wr6, **self._h3_bwd(pk, "trunk_h3", "c3_h3"))
             G.wgrad(t[0], gebar, dW[0], None, K=sp.K0, accumulate=True)
             # t_l, vbar_l live in buffers of their own until the next backward: their weight gradients may wait for the
             # grouped launch at the end of the caller (G.WgradGroup)
@@ -684,7 +708,8 @@ class NodeField:
                     out=[r[l - 1] for l in range(7, 0, -1)], wpack_x6=pk.get("chain_bwd_x6"),
                     # register-resident sweep, with or without the additive side input: since round 4 its side traffic moves
                     # as whole 128-byte lines through LDS (rtile_kernel: 140 vs 122 TF-eq for hold_chain_x6 with a2)
-                    wpack_r6=pk.get("chain_bwd_r6") if USE_R6_BWD else None)
+                    wpack_r6=pk.get("chain_bwd_r6") if USE_R6_BWD else None,
+                    **self._h3_bwd(pk, "chain_bwd_h3", "c3_bwd_h3"))
             ebar = r[3][:, sp.skip_out:] if ebar else None
             wg = G.wgrad if grp is None else grp.add
             for l in range(7, 0, -1):

@@ -240,7 +240,7 @@ _CHAIN_MAX_ROWS = _max_rows(256)  # 32-bit byte offsets inside the kernel (ld = 
 
 
 def chain(mode, P, x_in, wpack, n_layers, first_chunks, skip_layer=-1, side=None, bias=None, aux1=None, aux2=None,
-          out=None, out2=None, wpack_x6=None, wpack_r6=None, skip_out=0):
+          out=None, out2=None, wpack_x6=None, wpack_r6=None, skip_out=0, wpack_h3=None, c3=None):
     """hold_chain: n_layers consecutive 256-wide layers of one sweep with the activation resident in LDS.
     bias: per-layer [256] tensors; aux1 / aux2 / out / out2: per-layer [P,256] tensors (one common row stride) or None
     entries.  Batches beyond the kernel's 32-bit offset range are split by rows."""
@@ -251,6 +251,14 @@ def chain(mode, P, x_in, wpack, n_layers, first_chunks, skip_layer=-1, side=None
     # register-resident sweeps (hold_chain_r6, csrc/rchain.hip): same descriptor.  DSP: wpack_r6 = field.pack_r6_stack of the
     # seven matrices; DBWD: wpack_r6 = the stream of hold_trunk_r6 (field.pack_r6), and the CALLER has stored the skip
     # layer's side columns in aux2[3][:, 217:256] (the kernel does not read `side`)
+    # ... and in the two-limb fp16 arithmetic (hold_chain_h3, csrc/rchain_h3.hip): wpack_h3 = field's chain_bwd_h3 (DSP) / the
+    # stream of hold_trunk_h3 (DBWD), c3 = 1 / s_w of the chain layers; wpack_r6 stays the operand of the conditional f32x6
+    # fallback the entry point enqueues behind the kernel (the overflow guard of kernels.h3_guard)
+    h3 = wpack_h3 is not None and wpack_r6 is not None and mode in (CHAIN_DSP, CHAIN_DBWD) and skip_out in (0, 217)
+    if h3:
+        want = _lib.lib().hold_chain_h3_pack_bytes() if mode == CHAIN_DSP else _lib.lib().hold_trunk_h3_pack_bytes()
+        assert wpack_h3.numel() * wpack_h3.element_size() == want and wpack_h3.dtype == torch.float16
+        assert c3 is not None and c3.numel() == n_layers and c3.dtype == torch.float32 and c3.is_cuda
     r6 = wpack_r6 is not None and mode in (CHAIN_DSP, CHAIN_DBWD)
     if r6:
         want = _lib.lib().hold_chain_r6_pack_bytes() if mode == CHAIN_DSP else _lib.lib().hold_trunk_r6_pack_bytes()
@@ -265,7 +273,7 @@ def chain(mode, P, x_in, wpack, n_layers, first_chunks, skip_layer=-1, side=None
         if side is not None:
             d.side, d.ld_side = side[r0:r1].data_ptr(), _ld(side)
         assert r6 or wpack is not None
-        d.wpack = wpack_r6.data_ptr() if r6 else (wpack if wpack_x6 is None else wpack_x6).data_ptr()
+        d.wpack = wpack_h3.data_ptr() if h3 else wpack_r6.data_ptr() if r6 else (wpack if wpack_x6 is None else wpack_x6).data_ptr()
         ld = None
         for name, lst in (("bias", bias), ("aux1", aux1), ("aux2", aux2), ("out", out), ("out2", out2)):
             if lst is None:
@@ -283,12 +291,17 @@ def chain(mode, P, x_in, wpack, n_layers, first_chunks, skip_layer=-1, side=None
                 ld = _ld(t)
         d.ld = ld if ld is not None else 256
         e0 = _g._prof_begin()
-        call("hold_chain_r6" if r6 else ("hold_chain" if wpack_x6 is None else "hold_chain_x6"), C.byref(d))
+        if h3:
+            call("hold_chain_h3", C.byref(d), ptr(c3), ptr(h3_guard(x_in.device)), ptr(wpack_r6))
+        else:
+            call("hold_chain_r6" if r6 else ("hold_chain" if wpack_x6 is None else "hold_chain_x6"), C.byref(d))
         # algorithmic HBM bytes: the chain input row + per layer 1 KiB per side input and per stored result
         n_mats = sum(sum(t is not None for t in lst) for lst in (aux1, aux2, out, out2) if lst is not None)
         _g._prof_end(e0, 2.0 * (r1 - r0) * 256 * (8 * first_chunks + 256 * (n_layers - 1)),
-                     ("rchain_dbwd_kernel" if mode == CHAIN_DBWD else "rchain_a2_kernel" if aux2 is not None else
-                      "rchain_bg_kernel" if skip_out == 172 else "rchain_kernel") if r6 else "chain_kernel",
+                     (("rchain_dbwd_h3_kernel" if mode == CHAIN_DBWD else "rchain_a2_h3_kernel" if aux2 is not None else
+                       "rchain_h3_kernel") if h3 else
+                      ("rchain_dbwd_kernel" if mode == CHAIN_DBWD else "rchain_a2_kernel" if aux2 is not None else
+                       "rchain_bg_kernel" if skip_out == 172 else "rchain_kernel")) if r6 else "chain_kernel",
                      (r1 - r0) * (32.0 * first_chunks + 1024.0 * n_mats))
 
 

@@ -484,6 +484,24 @@ int hold_chain_x6(const hold_chain_desc* d, hold_stream_t stream);
  *             where the caller stores them before the launch (out2[3] is 0 in those columns, as with hold_chain_x6). */
 int64_t hold_chain_r6_pack_bytes(void);
 int hold_chain_r6(const hold_chain_desc* d, hold_stream_t stream);
+/* ... as a CONDITIONAL launch (guard: the 4 words of hold_fused_sdf_r6_if; NULL = hold_chain_r6): the fallback of hold_chain_h3 */
+int hold_chain_r6_if(const hold_chain_desc* d, uint32_t* guard, hold_stream_t stream);
+
+/* The same sweeps in the TWO-LIMB fp16 arithmetic "f16x3" (hold_amd/csrc/rchain_h3.hip; the arithmetic of hold_trunk_h3):
+ * 24 matrix instructions per k step instead of 48.  The weights scale per matrix at pack time (s_w[j] = 2^k with
+ * max |M_j| s_w[j] in [2^13, 2^14)); the running cotangent -- the B operand -- carries a power-of-two scale PER POINT that the
+ * kernel predicts layer by layer from the exact maximum of the point's values in the layer before (2^9 of headroom; the chain
+ * input's maximum is exact).
+ *   mode DSP : d->wpack = hold_chain_h3_pack_bytes() bytes of fp16, [7 x 16 k steps][8 nt][2 limbs][2 h][32 i][8 e], the rows and
+ *              k order of hold_chain_r6's stream, limb_t(s_w[j] M_j); skip_out 217 only (0 = 217);
+ *   mode DBWD: d->wpack = the stream of hold_trunk_h3 (hold_trunk_h3_pack_bytes() bytes; layer 0 = four k steps).
+ * c3: [n_layers] = 1 / s_w[j] of the chain layers, device memory.  Otherwise the contract of hold_chain_r6.
+ * OVERFLOW GUARD (as hold_fused_sdf_h3): a point whose values grow by more than the headroom within one layer would leave
+ * fp16's range; the kernel then sets guard[0] (guard NULL: unreported), and with wpack_r6 (hold_chain_r6's stream for the same
+ * matrices; requires guard) the entry point enqueues hold_chain_r6_if behind it: the results of such a launch are
+ * hold_chain_r6's, guard[2] counts it, no host synchronisation. */
+int64_t hold_chain_h3_pack_bytes(void);
+int hold_chain_h3(const hold_chain_desc* d, const float* c3, uint32_t* guard, const void* wpack_r6, hold_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * One 256-wide layer with the register-resident structure (hold_amd/csrc/rgemm.hip): the rendering net's layers

@@ -39,6 +39,15 @@ if os.environ.get("HOLD_X6") == "1":
     timeit("r6 DSP+a2 (7 layers)", lambda: K.chain(K.CHAIN_DSP, P, t[7], wb, 7, 32, skip_layer=3, aux1=h[:7], aux2=a2[:7], out=o1[:7], wpack_x6=xb, wpack_r6=rb), f7)
     rf = F.pack_r6(W[0], torch.stack(W[1:]))
     timeit("r6 DBWD (8 layers)", lambda: K.chain(K.CHAIN_DBWD, P, x0, wf, 8, 5, skip_layer=3, side=x0, aux1=h, aux2=t, out=o1, out2=a2, wpack_x6=xf, wpack_r6=rf), f8)
+    # ... and in two fp16 limbs (hold_chain_h3, csrc/rchain_h3.hip; each call includes its conditional f32x6 launch)
+    hb, swb = F.pack_h3_stack(torch.stack(W[1:]))
+    hf, swf = F.pack_h3(W[0], torch.stack(W[1:]))
+    cb, cf = (1.0 / swb).contiguous(), (1.0 / swf).contiguous()
+    n0 = K.h3_overflow_count(dev)
+    timeit("h3 DSP (7 layers)", lambda: K.chain(K.CHAIN_DSP, P, t[7], wb, 7, 32, skip_layer=3, aux1=h[:7], out=o1[:7], wpack_r6=rb, wpack_h3=hb, c3=cb), f7)
+    timeit("h3 DSP+a2 (7 layers)", lambda: K.chain(K.CHAIN_DSP, P, t[7], wb, 7, 32, skip_layer=3, aux1=h[:7], aux2=a2[:7], out=o1[:7], wpack_r6=rb, wpack_h3=hb, c3=cb), f7)
+    timeit("h3 DBWD (8 layers)", lambda: K.chain(K.CHAIN_DBWD, P, x0, wf, 8, 5, skip_layer=3, side=x0, aux1=h, aux2=t, out=o1, out2=a2, wpack_r6=rf, wpack_h3=hf, c3=cf), f8)
+    print("f32x6 fallbacks during the h3 timings:", K.h3_overflow_count(dev) - n0)
     sys.exit(0)
 def layered_sp():
     G.gemm_nt(x0, W[0], o1[0], bias=b[0], epi=G.EPI_SOFTPLUS, K=40)

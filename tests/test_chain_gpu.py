@@ -28,7 +28,9 @@ def _pack_x6(mats, first_k):
 
 
 ARITH = ["f32", "f32x6"]  # hold_chain (fp32 MFMA) and hold_chain_x6 (3-limb bf16 split, fp32 accumulate): same tolerance
-ARITH_BWD = ARITH + ["r6"]  # descending sweeps: + hold_chain_r6, the register-resident structure (csrc/rchain.hip)
+# descending / ascending sweeps: + hold_chain_r6, the register-resident structure (csrc/rchain.hip), and hold_chain_h3, the same
+# structure in two fp16 limbs with per-point operand scales (csrc/rchain_h3.hip)
+ARITH_BWD = ARITH + ["r6", "h3"]
 
 
 def _r6_stream(mode, mats):
@@ -37,6 +39,16 @@ def _r6_stream(mode, mats):
     if mode == "dsp":
         return F.pack_r6_stack(torch.stack(mats))
     return F.pack_r6(mats[0], torch.stack(mats[1:]))
+
+
+def _h3_stream(mode, mats):
+    """operands of hold_chain_h3: (stream, c3 = 1 / s_w per chain layer); DSP = field.pack_h3_stack, DBWD = field.pack_h3"""
+    from hold_amd import field as F
+    if mode == "dsp":
+        pk, sw = F.pack_h3_stack(torch.stack(mats))
+    else:
+        pk, sw = F.pack_h3(mats[0], torch.stack(mats[1:]))
+    return dict(wpack_h3=pk, c3=(1.0 / sw).contiguous())
 
 
 class _Guarded:
@@ -99,7 +111,7 @@ def test_chain_descending_dsp(P, with_a2, arith):
     out = guard.views
     K.chain(K.CHAIN_DSP, P, v7, _pack(Ms), 7, 32, skip_layer=3, aux1=hs, aux2=a2, out=out,
             wpack_x6=_pack_x6(Ms, 256) if arith == "f32x6" else None,
-            wpack_r6=_r6_stream("dsp", Ms) if arith == "r6" else None)
+            wpack_r6=_r6_stream("dsp", Ms) if arith in ("r6", "h3") else None, **(_h3_stream("dsp", Ms) if arith == "h3" else {}))
     guard.check()
     cur = v7.double()
     for j in range(7):
@@ -157,11 +169,11 @@ def test_chain_second_order_dbwd(P, arith):
     x0, Ws = x0.to(dev), [w.to(dev) for w in Ws]
     g1, g2 = _Guarded(8, P, dev), _Guarded(8, P, dev)
     o1, o2 = g1.views, g2.views
-    if arith == "r6":  # contract of hold_chain_r6 (DBWD): the skip layer's side columns come from aux2[3][:, 217:256]
+    if arith in ("r6", "h3"):  # contract of hold_chain_r6 / _h3 (DBWD): the skip layer's side columns come from aux2[3][:, 217:256]
         ts[3][:, SK:] = x0[:, :39]
     K.chain(K.CHAIN_DBWD, P, x0, _pack(Ws), 8, 5, skip_layer=3, side=x0, aux1=hs, aux2=ts, out=o1, out2=o2,
             wpack_x6=_pack_x6(Ws, 48) if arith == "f32x6" else None,
-            wpack_r6=_r6_stream("dbwd", Ws) if arith == "r6" else None)
+            wpack_r6=_r6_stream("dbwd", Ws) if arith in ("r6", "h3") else None, **(_h3_stream("dbwd", Ws) if arith == "h3" else {}))
     g1.check()
     g2.check()
     cur = x0.double()
@@ -306,3 +318,128 @@ def test_field_chain_route_matches_layered_route(kind, node):
         # pose_embed / time_code enter the rendering net's first layer: their gradients sit behind the same ReLU flips
         t = (2e-4 if k == "tfs" else 2e-3) * (1 if flips == 0 else 10)
         assert (ga[k] - gb[k]).abs().max().item() <= t * max(1e-3, ga[k].abs().max().item()), (k, flips)
+
+
+def _sweep_case(P, seed, dev, row_scale=None, a2_scale=1.0):
+    """operands of the three sweeps on P points: weights like the trunk's (N(0, 1/16)), softplus outputs, N(0,1) cotangents
+    optionally scaled row by row (a point's cotangent has ITS magnitude: compositing weights span many orders of magnitude)"""
+    g = torch.Generator().manual_seed(seed)
+    rs = torch.ones(P, 1) if row_scale is None else row_scale.view(P, 1)
+    Ms = [(torch.randn(256, 256, generator=g) / 16).to(dev) for _ in range(7)]
+    Ms[4][:, SK:] = 0
+    v7 = (torch.randn(P, 256, generator=g) * rs).to(dev)
+    hs = [_sp(torch.randn(P, 256, generator=g) * 0.03).to(dev) for _ in range(8)]
+    a2 = [(torch.randn(P, 256, generator=g) * rs * a2_scale).to(dev) for _ in range(7)]
+    x0 = torch.zeros(P, 40)
+    x0[:, :39] = torch.randn(P, 39, generator=g) * rs
+    Ws = [torch.zeros(256, 40)] + [torch.randn(256, 256, generator=g) / 16 for _ in range(7)]
+    Ws[0][:, :39] = torch.randn(256, 39, generator=g) / 6
+    Ws[3][SK:] = 0
+    ts = [(torch.randn(P, 256, generator=g)).to(dev) for _ in range(8)]
+    x0, Ws = x0.to(dev), [w.to(dev) for w in Ws]
+    ts[3][:, SK:] = x0[:, :39]
+    return Ms, v7, hs, a2, x0, Ws, ts
+
+
+def _run_sweeps(P, case, arith, dev):
+    """-> (DSP outs, DSP + a2 outs, DBWD out, DBWD out2) of one arithmetic ('r6' / 'h3')"""
+    from hold_amd import kernels as K
+    Ms, v7, hs, a2, x0, Ws, ts = case
+    kw_d = dict(wpack_r6=_r6_stream("dsp", Ms), **(_h3_stream("dsp", Ms) if arith == "h3" else {}))
+    kw_b = dict(wpack_r6=_r6_stream("dbwd", Ws), **(_h3_stream("dbwd", Ws) if arith == "h3" else {}))
+    new = lambda n: [torch.empty(P, 256, device=dev) for _ in range(n)]
+    o_t, o_r, o_v, o_a = new(7), new(7), new(8), new(8)
+    K.chain(K.CHAIN_DSP, P, v7, None, 7, 32, skip_layer=3, aux1=hs[:7], out=o_t, **kw_d)
+    K.chain(K.CHAIN_DSP, P, v7, None, 7, 32, skip_layer=3, aux1=hs[:7], aux2=a2, out=o_r, **kw_d)
+    K.chain(K.CHAIN_DBWD, P, x0, None, 8, 5, skip_layer=3, side=x0, aux1=hs, aux2=ts, out=o_v, out2=o_a, **kw_b)
+    return o_t, o_r, o_v, o_a
+
+
+def _ref_sweeps(case, sl):
+    """fp64 restatement of the three sweeps on the rows `sl` (teacher-forced: every layer from the fp64 result of the one before)"""
+    Ms, v7, hs, a2, x0, Ws, ts = case
+    t, r = [], []
+    for with_a2, dst in ((False, t), (True, r)):
+        cur = v7[sl].double()
+        for j in range(7):
+            y = cur @ Ms[j].double().t()
+            o = y * (-torch.expm1(-100 * hs[j][sl].double()))
+            if with_a2:
+                o = o + a2[j][sl].double()
+            if j == 3:
+                o[:, SK:] = y[:, SK:]
+            dst.append(o)
+            cur = o
+    v, aa = [], []
+    cur = x0[sl].double()
+    for l in range(8):
+        y = cur @ Ws[l].double().t()
+        e = torch.exp(-100 * hs[l][sl].double())
+        o, o2 = y * (1 - e), 100 * y * ts[l][sl].double() * e
+        if l == 3:
+            o = torch.cat([o[:, :SK], x0[sl, :39].double()], 1)
+            o2[:, SK:] = 0
+        v.append(o)
+        aa.append(o2)
+        cur = o
+    return t, r, v, aa
+
+
+def test_chain_h3_error_against_fp64_is_within_one_and_a_half_of_r6_on_half_a_million_points():
+    """the gate of the f16x3 sweeps: on 524 288 points the error of t (descending sweep of the normal path),
+    r (first-order backward with the additive side input) and vbar / a2 (second-order ascending sweep) against fp64 is at most
+    1.5 x that of the exact three-limb bf16 kernels (hold_chain_r6), max and rms, END TO END through the chain (each kernel feeds
+    its own layers) -- (a) with O(1) cotangents and (b) with per-point magnitudes spread log-uniformly over 1e-12 .. 1e+2
+    (a point's cotangent has its own magnitude: compositing weights along a ray), where the error of a point is measured
+    against THAT POINT's largest value of the layer (a common absolute bound would only see the largest points)."""
+    from hold_amd import kernels as K
+    dev = _dev()
+    P = 524288
+    g = torch.Generator().manual_seed(77)
+    for name, rs in (("unit", None), ("spread", 10.0 ** (torch.rand(P, generator=g) * 14 - 12))):
+        case = _sweep_case(P, 31, dev, rs)
+        n0 = K.h3_overflow_count(dev)
+        o6, o3 = _run_sweeps(P, case, "r6", dev), _run_sweeps(P, case, "h3", dev)
+        assert K.h3_overflow_count(dev) == n0, "the f16x3 sweeps fell back to f32x6 on well-behaved operands"
+        worst = {}
+        for c0 in range(0, P, 65536):
+            sl = slice(c0, c0 + 65536)
+            ref = _ref_sweeps(case, sl)
+            for fam, (a6, a3, rf) in enumerate(zip(o6, o3, ref)):
+                for l, (x6, x3, xr) in enumerate(zip(a6, a3, rf)):
+                    den = xr.abs().amax(1, keepdim=True).clamp_min(1e-300)  # the point's own scale
+                    e6, e3 = ((x6[sl].double() - xr).abs() / den), ((x3[sl].double() - xr).abs() / den)
+                    w = worst.setdefault(fam, [0.0, 0.0, 0.0, 0.0, 0])
+                    w[0], w[1] = max(w[0], float(e6.max())), max(w[1], float(e3.max()))
+                    w[2], w[3], w[4] = w[2] + float(e6.pow(2).sum()), w[3] + float(e3.pow(2).sum()), w[4] + e6.numel()
+        for fam, w in worst.items():
+            r6m, h3m, r6r, h3r = w[0], w[1], (w[2] / w[4]) ** 0.5, (w[3] / w[4]) ** 0.5
+            print(f"{name} family {('t', 'r', 'vbar', 'a2')[fam]}: r6 max {r6m:.3e} rms {r6r:.3e} | h3 max {h3m:.3e} rms {h3r:.3e}")
+            assert h3m <= 1.5 * r6m and h3r <= 1.5 * r6r, (name, fam, w)
+
+
+def test_chain_h3_overflow_falls_back_to_r6_on_the_device():
+    """a point whose running value grows by more than the 2^9 headroom of its predicted scale within ONE layer (here: an
+    additive side input 1e5 x the running cotangent at layer 2 on a few rows) leaves fp16's
+    range: the launch sets the guard, the conditional hold_chain_r6 launch behind it recomputes it, the results are hold_chain_r6's
+    bit for bit and the event is counted; a well-behaved launch afterwards is the f16x3 kernel's again."""
+    from hold_amd import kernels as K
+    dev = _dev()
+    P = 128 * 257 + 3
+    case = _sweep_case(P, 5, dev)
+    Ms, v7, hs, a2, x0, Ws, ts = case
+    a2[2][1000:1004] *= 1e5
+    guard = K.h3_guard(dev)
+    n0 = K.h3_overflow_count(dev)
+    o6, o3 = _run_sweeps(P, case, "r6", dev), _run_sweeps(P, case, "h3", dev)
+    assert K.h3_overflow_count(dev) == n0 + 1 and guard[:2].tolist() == [0, 0]  # only the sweep that reads a2 overflowed
+    for x6, x3 in zip(o6[1], o3[1]):
+        assert torch.equal(x6, x3)
+    assert not all(torch.equal(a, b) for a, b in zip(o6[0], o3[0]))  # the others ran in f16x3
+    a2[2][1000:1004] *= 1e-5
+    o3b = _run_sweeps(P, case, "h3", dev)
+    assert K.h3_overflow_count(dev) == n0 + 1
+    ref = _ref_sweeps(case, slice(0, 4096))
+    for fam in range(4):
+        for x3, xr in zip(o3b[fam], ref[fam]):
+            assert (x3[:4096].double() - xr).abs().max().item() < 3e-5 * max(1.0, xr.abs().max().item())

@@ -140,7 +140,20 @@ def test_h3_stream_is_the_r6_stream_in_two_fp16_limbs():
         assert torch.equal(pkw["c3_h3"], 1.0 / sw2)
         b8 = torch.stack([torch.nn.functional.pad(b, (0, 256 - b.shape[0])) for b in ib[:8]])
         assert torch.equal(pkw["bias8_h3"], b8 * (sw2 * F.H3_ACT_SCALE).view(8, 1))
-        assert "trunk_r6" in pkw  # the sweeps without an fp16 variant still find their bf16 streams
+        assert "trunk_r6" in pkw  # the f32x6 fallback of every f16x3 kernel still finds its bf16 stream
+        # the descending sweeps' stream (hold_chain_h3, DSP): chain layer j = W_{7-j}^T with THAT matrix's scale -- the same limbs,
+        # gathered transposed -- and c3 in chain order; equal to the stand-alone packer on the transposed matrices
+        MT = S2.transpose(1, 2).flip(0).contiguous()
+        refb, swb = F.pack_h3_stack(MT)
+        assert torch.equal(swb, sw2[1:].flip(0))  # a matrix and its transpose share their maximum
+        assert torch.equal(pkw["chain_bwd_h3"], refb)
+        assert torch.equal(pkw["c3_bwd_h3"], 1.0 / swb)
+        # ... which is pack_r6_stack's stream in two fp16 limbs (rows and k order pinned to the lane model above)
+        r6b = F.pack_r6_stack(MT).double().reshape(7 * 16, 8, 3, 2, 32, 8).sum(2)
+        h3b = refb.double().reshape(7 * 16, 8, 2, 2, 32, 8)
+        wsb = r6b * swb.double().repeat_interleave(16).view(-1, 1, 1, 1, 1)
+        errb = (h3b.sum(2) - wsb).abs()
+        assert torch.all(errb <= wsb.abs() * 2.0 ** -22 + 2.0 ** -25)
     finally:
         hold_amd.set_precision(prev)
 
