@@ -399,6 +399,8 @@ def main():
     for node in net.nodes.values():
         node.ray_sampler.sum_iters = node.ray_sampler.n_calls = 0
     calls0 = _L.CALLS
+    from hold_amd import kernels as _K
+    ovf0 = _K.h3_overflow_count(dev)  # launches of f16x3 kernels recomputed in f32x6 so far (a host read, outside the timed region)
     if args.sync_debug and rank == 0:
         import collections, traceback, warnings
         sync_sites = collections.Counter()
@@ -772,6 +774,9 @@ def main():
                                              "step_floor_s": {"hbm": hbm_step / (HBM_PEAK_GBPS * 1e9),
                                                               "mfma": mf6 / args.steps / ((BF16_MFMA_PEAK_TFLOPS if x6 else FP32_MFMA_PEAK_TFLOPS) * 1e12)}}
         res["config"]["c_abi_calls_per_step"] = (_L.CALLS - calls0) / args.steps
+        res["config"]["f16x3_launches_recomputed_in_f32x6_per_step"] = (_K.h3_overflow_count(dev) - ovf0) / args.steps
+        res["config"]["f16x3_fallback_note"] = ("overflow guard of the f16x3 kernels (trunk, sampler queries, backward sweeps): a launch in which a "
+                                                "scaled operand left fp16's range is recomputed by a conditional f32x6 launch on the device")
         if args.mode == "c3" and not args.no_refine:
             try:
                 res["config"]["pose_refine"] = refine_bench(dev)

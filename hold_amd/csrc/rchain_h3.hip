@@ -174,8 +174,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // At an odd step's rendezvous the even step's side pieces are younger than the weights it needs; at an even step's the odd
   // step's stores are.  (rchain.hip issues the stores BEFORE the odd step's weight pieces: its constants differ.)  The first
   // 16-step layer of a block has no stores in front of its first rendezvous: a full wait stands in front of that layer.
-  constexpr int NW_EVEN = 4 * NOUT;
-  constexpr int NW_ODD = 4 * NAUX;
+  //   DIST 3 (requested three rendezvous ago; 16-unit ring).  Even step g:  .. W(g-3) st(g-3) | W(g-2) S(g-2) | W(g-1) st(g-1) | --
+  //           S(g-2) is read from step g + 1 on and must be forced here: only W(g-1) and st(g-1) stay in flight.  Odd step g:
+  //           .. W(g-3) S(g-3) | W(g-2) st(g-2) | W(g-1) S(g-1) | -- everything behind W(g-3) may stay in flight.
+  constexpr int NW_EVEN = DIST == 1 ? 4 * NOUT : 4 + 4 * NOUT;
+  constexpr int NW_ODD = DIST == 1 ? 4 * NAUX : 8 + 8 * NAUX + 4 * NOUT;
   constexpr int NW_IN0 = 8 * NAUX;  // DBWD chain layer 0, step 0: the two side tiles just requested stay in flight
   static_assert(NW_ODD < 64, "vmcnt field");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -693,9 +696,24 @@ extern "C" int hold_chain_h3(const hold_chain_desc* dp, const float* c3, uint32_
   if (d.P == 0) return HOLD_OK;
   hipStream_t s = (hipStream_t)st;
   int rc;
-  if (db) rc = rsweep_h3_launch<RC_DBWD, true, 1>(a, s);
-  else if (has2) rc = rsweep_h3_launch<RC_DSP, true, 1>(a, s);
-  else rc = rsweep_h3_launch<RC_DSP, false, 1>(a, s);
+  // DIST = how many rendezvous ahead a weight group is requested (ring of 4 + 4 DIST units = 32 / 64 KiB).  Measured (GPU call 8
+  // of round 6, 1.6 M points, developer build): DIST 3 against DIST 1: DSP 7.57 -> 6.95 ms, DSP + a2 8.48 -> 8.04, DBWD 11.10 -> 11.17
+  // (HBM-bound: 58 GB at 5.2 TB/s) -- the descending sweeps take 3, the ascending one keeps the 32 KiB ring (128 instead of 160 KiB
+  // of LDS).  What is left is the side traffic: with the side tiles served from L2-resident rows 6.5 / 7.1 / 9.7 ms, without the
+  // result stores as well 5.8 / 6.3 / 6.7 (profiles/r06_rsweep_h3_dist_ablation.log).
+  int dist = db ? 1 : 3;
+#ifdef HOLD_DEV
+  if (const char* v = getenv("HOLD_H3C_DIST")) dist = atoi(v);
+#endif
+  if (dist == 3) {
+    if (db) rc = rsweep_h3_launch<RC_DBWD, true, 3>(a, s);
+    else if (has2) rc = rsweep_h3_launch<RC_DSP, true, 3>(a, s);
+    else rc = rsweep_h3_launch<RC_DSP, false, 3>(a, s);
+  } else {
+    if (db) rc = rsweep_h3_launch<RC_DBWD, true, 1>(a, s);
+    else if (has2) rc = rsweep_h3_launch<RC_DSP, true, 1>(a, s);
+    else rc = rsweep_h3_launch<RC_DSP, false, 1>(a, s);
+  }
   if (rc != HOLD_OK || !wpack_r6) return rc;
   hold_chain_desc f = d;
   f.wpack = (const float*)wpack_r6;
