@@ -536,7 +536,7 @@ def main():
         # kernel families that run the two-limb fp16 arithmetic in mode f16x3 (3 limb products issued per algorithmic product on
         # v_mfma_f32_32x32x16_f16, same dense peak as bf16); every other split-precision family issues 6 bf16 limb products
         from hold_amd import field as _field
-        h3_fams = ({"fused_sdf_kernel", "wgrad_h3_kernel", "rchain_h3_kernel", "rchain_a2_h3_kernel", "rchain_dbwd_h3_kernel"} |
+        h3_fams = ({"fused_sdf_kernel", "wgrad_h3_kernel", "rchain_h3_kernel", "rchain_a2_h3_kernel", "rchain_dbwd_h3_kernel", "rgemm_h3_kernel"} |
                    ({"trunk_r6_kernel"} if _field.USE_H3_TRUNK else set())) if h3 else set()
         scene = ("configs[3]-like ARCTIC two-hand (right+left+object+background), " if args.two_hands else
                  "hold_bottle1_itw-like single-hand (right+object+background), ")
@@ -611,7 +611,7 @@ def main():
                 json.dump(gemm_shapes(prof), open(args.shape_report, "w"), indent=1)
             split = {"fused_sdf_kernel", "wgrad_kernel", "wgrad_h3_kernel", "chain_kernel", "gemm_nt_kernel", "trunk_r6_kernel", "rchain_kernel",
                      "rchain_bg_kernel", "rchain_a2_kernel", "rchain_dbwd_kernel", "rgemm_kernel", "rnarrow_kernel",
-                     "rchain_h3_kernel", "rchain_a2_h3_kernel", "rchain_dbwd_h3_kernel"} if x6 else set()
+                     "rchain_h3_kernel", "rchain_a2_h3_kernel", "rchain_dbwd_h3_kernel", "rgemm_h3_kernel"} if x6 else set()
             labels = {"gemm_nt_kernel": ("gemm_nt_kernel<x6> (one layer per launch, 3-limb split on v_mfma_f32_32x32x16_bf16)"
                                          if x6 else "gemm_nt_kernel (one layer per launch, v_mfma_f32_32x32x2_f32)"),
                       "trunk_r6_kernel": ("rmlp_h3_kernel<STORE> (forward trunk, 8 layers per launch, register-resident, two fp16 limbs, "
@@ -620,6 +620,9 @@ def main():
                                           "v_mfma_f32_32x32x16_bf16)"),
                       "rgemm_kernel": "rgemm_kernel (rendering-net layers, their input gradients, lin8 features: one 256-wide layer "
                                       "per launch, register-resident, 3-limb split on v_mfma_f32_32x32x16_bf16)",
+                      "rgemm_h3_kernel": "rgemm_h3_kernel (rendering-net layers, their input gradients, lin8 features: one 256-wide layer "
+                                         "per launch, register-resident, two fp16 limbs / three products on v_mfma_f32_32x32x16_f16, every "
+                                         "operand row scaled by its own power of two from the producer's row maxima)",
                       "rnarrow_kernel": "rnarrow_kernel (the N <= 64 layers: d sdf / d embedding, the non-feature columns of the colour "
                                         "net's input gradient; A streamed once, ceil(N / 32) output tiles, 3-limb split on "
                                         "v_mfma_f32_32x32x16_bf16)",

@@ -136,6 +136,8 @@ SIGNATURES = {
     "hold_copy_cols": [_P, _I, _P, _I, _I, _L, _I, _P],
     "hold_bg_points": [_P, _P, _P, _I, _L, _F, _P, _I, _P],
     "hold_gemm_r6": [_P, _I, _L, _P, _I, _P, _I, _P, _I, _P, _I, _P],
+    "hold_gemm_r6_if": [_P, _I, _L, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P],
+    "hold_gemm_h3": [_P, _I, _L, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _F, _P, _P, _P, _P],
     "hold_weight_norm_fwd": [C.POINTER(WnDesc), _P],
     "hold_weight_norm_bwd": [C.POINTER(WnDesc), _P],
     "hold_rowdot": [_P, _I, _P, _I, _F, _P, _L, _P, _I, _P],
@@ -202,6 +204,8 @@ def _declare(L):
     L.hold_trunk_h3_act_scale.restype = C.c_float
     L.hold_gemm_r6_pack_bytes.restype = C.c_int64
     L.hold_gemm_r6_pack_bytes.argtypes = [C.c_int32]
+    L.hold_gemm_h3_pack_bytes.restype = C.c_int64
+    L.hold_gemm_h3_pack_bytes.argtypes = [C.c_int32]
     L.hold_chain_r6_pack_bytes.restype = C.c_int64
     L.hold_chain_h3_pack_bytes.restype = C.c_int64
     L.hold_chain_pack_floats.argtypes = [C.c_int32, C.c_int32]

@@ -44,6 +44,8 @@ struct RGArgs {
   const float* bias;   // [256] or null (not with EPI_MASK)
   const float* aux; int ld_aux;  // EPI_MASK: C = y * (aux > 0)
   float* C; int ldc;
+  float* amax_out;     // [P] max |C[p][:]| (null: not wanted) -- what hold_gemm_h3 (csrc/rgemm_h3.hip) scales its operand rows by
+  uint32_t* guard;     // CONDITIONAL launch (hold_gemm_r6_if, the fallback of hold_gemm_h3; protocol of rmlp.hip): null = always run
 };
 
 __device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
@@ -86,10 +88,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // side requests, three stores
   constexpr int NWAIT = 6 + 2 * NSIDE + 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (a.guard && __hip_atomic_load(a.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;  // wave-uniform
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, li = lane & 31;
   const uint32_t lane16 = lane * 16;
+  float omx = 0.f;   // running maximum of the outputs of the block held in P (amax_out)
+  long row_P = -1;   // first row of this wave's share of that block
   const char* ring_lane = smem + lane * 16;
   const uint32_t side_dst0 = (uint32_t)(OFF_SIDE + wave * (SIDE_RING * SIDE_SLOT));
   const float* side_rd = reinterpret_cast<const float*>(smem + OFF_SIDE + wave * (SIDE_RING * SIDE_SLOT)) + lane * 4;
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   //   stage 1: epilogue of the 8 values
   //   stage 2 / 3: limb split of the input dwords 0, 1 / 2, 3 (11 operations each, alternating) -> out; one 16-byte store
   struct EpiState { float x[8], y[8], mk[8]; uint32_t w[2][8]; };
-  static constexpr int CNT[4] = {8, 8, 23, 23};
+  static constexpr int CNT[4] = {8, 12, 23, 23};
   auto mop = [&](int e, bool unit, int stage, int k, Limbs& out, EpiState& st) {
     const int ss = e & 3;
     if (stage == 0) {
@@ -191,12 +196,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         st.y[i] = t;
       }
     } else if (stage == 1) {
-      if (unit) {
+      if (unit && k < 8) {
         float t = st.y[k];
         if (EPI == EPI_RELU) t = relu1(t);
         if (EPI == EPI_MASK) t = st.mk[k] > 0.f ? t : 0.f;
         asm volatile("" : "+v"(t));
         st.y[k] = t;
+      } else if (unit) {  // running maximum of the results, one v_max3_f32 per pair
+        const int p = k - 8;
+        asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(omx) : "v"(st.y[2 * p]), "v"(st.y[2 * p + 1]));
       }
     } else {
       const int h2 = stage - 2;
@@ -301,6 +309,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int j = 16; j < 20; ++j) kstep(j, CNT, [&](int c, int k) { mop(j + 1, false, c, k, Bn, st); });
     }
+    // ---- every unit of the block held in P has been stored: its rows' maxima (both lane halves hold the same point) ----
+    if (a.amax_out && row_P >= 0) {
+      const float o = fmaxf(omx, __shfl_xor(omx, 32));
+      if (hh == 0 && row_P + li < a.P) a.amax_out[row_P + li] = o;
+    }
+    omx = 0.f;
+    row_P = blk * BPTS + wave * 32;
     // ---- the block is finished: it becomes P; its stores run behind the next block ----
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) P[nt] = Q[nt];
@@ -331,9 +346,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           if (EPI == EPI_RELU) t = relu1(t);
           if (EPI == EPI_MASK) t = bitsf(mv[k]) > 0.f ? t : 0.f;
           v[k] = t;
+          omx = fmaxf(omx, fabsf(t));
         }
         store4(v, crs, cvoff + co);
       }
+    if (a.amax_out && row_P >= 0) {
+      const float o = fmaxf(omx, __shfl_xor(omx, 32));
+      if (hh == 0 && row_P + li < a.P) a.amax_out[row_P + li] = o;
+    }
+  }
+  if (a.guard) {  // the conditional launch ran: count it once and re-arm the guard
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+      if (atomicAdd(a.guard + 1, 1u) == gridDim.x - 1) {
+        a.guard[1] = 0u;
+        atomicAdd(a.guard + 2, 1u);
+        __threadfence();
+        __hip_atomic_store(a.guard, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 }
 
@@ -369,8 +401,19 @@ extern "C" int64_t hold_gemm_r6_pack_bytes(int32_t K) { return (int64_t)((K + 63
 // limb_t(W)[32 nt + i][16 j + 8 (e / 4) + 4 h + e % 4], KS = 4 ceil(K / 64), zero for columns >= K and rows >= N.
 // K a multiple of 16 in 256 .. 320 (the padded k steps multiply columns 0..15 of A by the zero weights: no read past a
 // row).  32-bit offsets: P * max(lda, ldc, ld_aux) * 4 < 2^32.
+extern "C" int hold_gemm_r6_if(const float* A, int32_t lda, int64_t P, const void* wpack, int32_t K, const float* bias,
+                               int32_t epilogue, const float* aux, int32_t ld_aux, float* C, int32_t ldc, float* amax_out,
+                               uint32_t* guard, hold_stream_t st);
 extern "C" int hold_gemm_r6(const float* A, int32_t lda, int64_t P, const void* wpack, int32_t K, const float* bias,
                             int32_t epilogue, const float* aux, int32_t ld_aux, float* C, int32_t ldc, hold_stream_t st) {
+  return hold_gemm_r6_if(A, lda, P, wpack, K, bias, epilogue, aux, ld_aux, C, ldc, nullptr, nullptr, st);
+}
+// ... with the per-row maxima of C as a second output (amax_out [P] or NULL) and as a CONDITIONAL launch (guard != NULL: see
+// hold_fused_sdf_r6_if in include/hold_hip.h) -- the fallback of hold_gemm_h3
+extern "C" int hold_gemm_r6_if(const float* A, int32_t lda, int64_t P, const void* wpack, int32_t K, const float* bias,
+                               int32_t epilogue, const float* aux, int32_t ld_aux, float* C, int32_t ldc, float* amax_out,
+                               uint32_t* guard, hold_stream_t st) {
+  if (((uintptr_t)amax_out & 3) || ((uintptr_t)guard & 3)) return HOLD_E_ARG;
   if (!A || !wpack || !C || P < 0 || K < 256 || K > 320 || (K & 15) || lda < K || (lda & 3) || ldc < 256 || (ldc & 3)) return HOLD_E_ARG;
   if (((uintptr_t)A & 15) || ((uintptr_t)C & 15) || ((uintptr_t)wpack & 15) || (bias && ((uintptr_t)bias & 15))) return HOLD_E_ARG;
   if (epilogue < 0 || epilogue > 2) return HOLD_E_ARG;
@@ -380,7 +423,7 @@ extern "C" int hold_gemm_r6(const float* A, int32_t lda, int64_t P, const void* 
   if (((uint64_t)P + BPTS) * (uint64_t)ldmax * 4 >= (1ull << 32)) return HOLD_E_ARG;
   RGArgs a;
   a.A = A; a.lda = lda; a.P = (long)P; a.wpack = (const char*)wpack; a.KS = (K + 63) / 64 * 4; a.K16 = K / 16; a.bias = bias; a.aux = aux;
-  a.ld_aux = ld_aux; a.C = C; a.ldc = ldc;
+  a.ld_aux = ld_aux; a.C = C; a.ldc = ldc; a.amax_out = amax_out; a.guard = guard;
   hipStream_t s = (hipStream_t)st;
   return epilogue == 0 ? launch<EPI_NONE>(a, s) : epilogue == 1 ? launch<EPI_RELU>(a, s) : launch<EPI_MASK>(a, s);
 }

@@ -1,0 +1,495 @@
+// One 256-wide layer per launch, register-resident, in the TWO-LIMB fp16 arithmetic "f16x3" (gfx950): the kernel of csrc/rgemm.hip
+//   C[p][0..255] = epi(A[p][0..K) . W^T + bias)        K = 256 .. 320, epi = none | ReLU | x (aux > 0)
+// -- the rendering net's layers (texture_net.py:95-101), their input gradients and lin8's 256 feature rows (shape_net.py:128-130)
+// -- with 24 instead of 48 matrix instructions per k step (x = hi + lo, hi = RN_f16(s x), lo = RN_f16(s x - hi); hi hi + hi lo +
+// lo hi on v_mfma_f32_32x32x16_f16; csrc/rmlp_h3.hip), 16 KiB of weight limbs per k step instead of 24.
+//
+// SCALES.  Weights: per matrix, at pack time (s_w = 2^k, max |W| s_w in [2^13, 2^14); c3 = 1 / s_w comes with the stream).  The B
+// operand is a ROW of A per point -- an activation of O(1) in the forward layers, a loss cotangent of any magnitude in the input-
+// gradient launches -- and an MFMA column is a point, so every point carries its own power-of-two scale 2^k (csrc/rchain_h3.hip).
+// Here the row's magnitude is KNOWN before its first k step: the launch that produced A reports the exact maximum of every row it
+// wrote (amax_out, 4 bytes per point, from the values in its epilogue registers), and this launch reads it (amax_in; the next
+// block's 32 values per wave travel by LDS-DMA one block ahead) -- max(amax_in, amax_floor) goes to [2^12, 2^13): 2^3 of headroom
+// for the columns of A the producer did not write (the rendering net's first layer reads [features | xc | normal | pose | time]:
+// amax_in covers the features, amax_floor the rest).  Without amax_in the scale is the constant one of amax_floor (lin8's input, the
+// trunk's last softplus output: amax_floor = 64 is the 2^6 of rmlp_h3.hip).  OVERFLOW GUARD as in rmlp_h3.hip: exact running maximum
+// of the scaled values, guard word, conditional f32x6 launch (hold_gemm_r6_if) behind the kernel.
+// Structure, rings, queue accounting: csrc/rgemm.hip (4-slot weight ring = 64 KiB here, wave-private 4-slot side rings).
+// Roofline: fp16 MFMA pipe at 3 limb products per product; HBM per point 4 (K + 256) B (+ 1 KiB mask operand) + 8 B of maxima.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hold_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int NW = 4, BPTS = 32 * NW, PIECE = 1024, SLOT = 16 * PIECE;
+constexpr int R3 = 4;         // weight ring slots, DMA distance R3 - 1 k steps
+constexpr int SIDE_RING = 4;  // side ring slots: a fragment is requested four k steps before its k step
+
+enum { EPI_NONE = 0, EPI_RELU = 1, EPI_MASK = 2 };
+
+struct RGArgs {
+  const float* A; int lda; long P;
+  const char* wpack;   // [KS][8 n-tiles][2 limbs][2 halves][32 rows][8 e] fp16 of s_w W, k order of field.r6_kmap
+  const float* c3;     // device scalar 1 / s_w
+  const float* amax_in; float amax_floor;  // per-row maximum of A (null: amax_floor alone)
+  float* amax_out;     // per-row maximum of |C| (null: not wanted)
+  uint32_t* guard;     // overflow guard word (null: unreported)
+  int KS, K16;         // k steps run (16 or 20), k steps that exist in A (K / 16)
+  const float* bias;   // [256] or null (not with EPI_MASK)
+  const float* aux; int ld_aux;  // EPI_MASK: C = y * (aux > 0)
+  float* C; int ldc;
+};
+
+__device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ float bitsf(uint32_t x) { return __builtin_bit_cast(float, x); }
+__device__ __forceinline__ float relu1(float y) {  // one v_max_i32 (rmlp.hip)
+  const int b = __builtin_bit_cast(int, y);
+  return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const float* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, p ? bytes : 0u, 0x00020000);
+}
+// column offset in the instruction immediate, soffset = 0 (the gfx950 store-data hazard, rmlp.hip)
+__device__ __forceinline__ void store4(const f32x4& v, rsrc_t rs, uint32_t voff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, voff, 0, 0);
+  asm volatile("s_nop 3");
+}
+
+struct Limbs { u32x4 l[2]; };
+
+__device__ __forceinline__ uint32_t cvt_pk(float a, float b) {  // v_cvt_pk_f16_f32 (round to nearest)
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+template <int SEL>
+__device__ __forceinline__ float resid(uint32_t hi, float x) {  // x - (float) half SEL of hi: one v_fma_mix_f32, exact
+  float r;
+  if (SEL == 0)
+    asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi), "v"(x));
+  else
+    asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi), "v"(x));
+  return r;
+}
+__device__ __forceinline__ float pow2f(int k) { return bitsf((uint32_t)(127 + k) << 23); }
+// exponent k that puts a row maximum m at [2^12, 2^13) (|k| <= 96; m = 0, inf, NaN: 0)
+__device__ __forceinline__ int row_scale(float m) {
+  const int e = (int)((fbits(m) >> 23) & 0xffu);
+  int k = 127 + 12 - e;
+  k = k > 96 ? 96 : (k < -96 ? -96 : k);
+  return (e != 0 && e != 255) ? k : 0;
+}
+// 4-byte-per-lane LDS-DMA (lane L -> LDS byte dst + 4 L)
+__device__ __forceinline__ void dma_dword(const char* src, uint32_t voff, uint32_t dst) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dword %0, %1"
+      :
+      : "v"(voff), "s"(src), "s"(dst)
+      : "memory");
+}
+
+__device__ __forceinline__ void dma_piece(const char* src, uint32_t voff, uint32_t dst) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1"
+      :
+      : "v"(voff), "s"(src), "s"(dst)
+      : "memory");
+}
+#define RG_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rgemm_h3_kernel(RGArgs a) {
+  constexpr int NSIDE = EPI == EPI_MASK ? 2 : 1;  // side matrices: the input, and the mask operand
+  constexpr int SIDE_SLOT = NSIDE * 2 * PIECE;
+  constexpr int OFF_SIDE = R3 * SLOT;
+  constexpr int OFF_BIAS = OFF_SIDE + NW * SIDE_RING * SIDE_SLOT;
+  constexpr int OFF_AMAX = OFF_BIAS + 1024;  // [4 waves][2 slots][64 lanes] fp32: the row maxima of the running / the next block
+  // VMEM operations that may stay in flight at a rendezvous (rgemm.hip's accounting with four weight pieces per wave and step):
+  // the previous rendezvous' four weight pieces and side requests, three stores.  The true number of operations younger than the
+  // weights a rendezvous needs is 8 + 4 NSIDE (rgemm.hip), so the two extra operations of a block -- the DMA of the next block's
+  // row maxima and the store of the finished block's -- stay inside the slack
+  constexpr int NWAIT = 4 + 2 * NSIDE + 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, li = lane & 31;
+  const uint32_t lane16 = lane * 16;
+  const char* ring_lane = smem + lane * 16;
+  const uint32_t side_dst0 = (uint32_t)(OFF_SIDE + wave * (SIDE_RING * SIDE_SLOT));
+  const float* side_rd = reinterpret_cast<const float*>(smem + OFF_SIDE + wave * (SIDE_RING * SIDE_SLOT)) + lane * 4;
+  const int KS = a.KS;
+
+  reinterpret_cast<float*>(smem + OFF_BIAS)[tid] = (EPI != EPI_MASK && a.bias) ? a.bias[tid] : 0.f;
+  __syncthreads();
+  const float c3 = *a.c3, s_w = 1.0f / c3;  // exact powers of two
+  // per-point scale state: kB / sB = exponent / scale of the B operand of the block being accumulated (its row maximum, or the
+  // floor, at [2^12, 2^13)); yscP = what un-scales the block held in P; mx = exact running maximum of the scaled values (guard);
+  // omx = running maximum of the finished block's outputs (amax_out)
+  int kB = 0;
+  float sB = 1.f, yscP = 0.f, mx = 0.f, omx = 0.f;
+  const uint32_t amax_dst0 = (uint32_t)(OFF_AMAX + wave * 512);
+  const float* amax_rd = reinterpret_cast<const float*>(smem + OFF_AMAX + wave * 512) + lane;
+  const char* AMb = reinterpret_cast<const char*>(a.amax_in);
+
+  f32x16 P[8], Q[8];
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) P[nt][r] = 0.f;
+  u32x4 A[2][4];
+  Limbs Bc, Bn;
+
+  auto init_q = [&]() {  // bias of this lane's rows (features 32 nt + 8 g + 4 hh + k), in the accumulators' scale s_w 2^kB
+    const float swB = s_w * sB;
+    if (EPI == EPI_MASK) {
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Q[nt][r] = 0.f;
+      return;
+    }
+    const float* bl = reinterpret_cast<const float*>(smem + OFF_BIAS) + 4 * hh;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bl + 32 * nt + 8 * g);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Q[nt][4 * g + k] = b[k] * swB;
+      }
+  };
+
+  const uint32_t cbytes = (uint32_t)(a.P * a.ldc * 4);
+  const uint32_t xbytes = (uint32_t)(a.P * (long)a.ld_aux * 4);
+
+  long blk = blockIdx.x;
+  if (blk * BPTS >= a.P) return;
+  auto clamp_row = [&](long b) {
+    const long r = b * BPTS + wave * 32 + li;
+    return r < a.P ? r : a.P - 1;  // reads of rows >= P are redirected (their results are dropped by the stores)
+  };
+  uint32_t in_off = (uint32_t)((clamp_row(blk) * a.lda + 4 * hh) * 4);  // side-DMA lane offsets of the running block
+  uint32_t in_off_next = (uint32_t)((clamp_row(blk + gridDim.x) * a.lda + 4 * hh) * 4);
+  uint32_t ax_off_prev = (uint32_t)((clamp_row(blk) * (long)a.ld_aux + 4 * hh) * 4);  // mask rows of the block held in P
+  uint32_t ax_off_cur = ax_off_prev;
+  uint32_t am_off = (uint32_t)(clamp_row(blk) * 4), am_off_next = (uint32_t)(clamp_row(blk + gridDim.x) * 4);  // (lane li's row; both halves)
+  long row_P = -1;  // first row of this wave's share of the block held in P (none yet)
+  int bi = 0;       // blocks this workgroup has started (parity = the row maxima's LDS slot)
+  const char* Ab = reinterpret_cast<const char*>(a.A);
+  const char* Xb = reinterpret_cast<const char*>(a.aux);
+  const char* wbase = a.wpack;
+
+  // ---- once per workgroup: the first R3 - 1 weight steps, the input fragments of the k steps 0..3 ----
+#pragma unroll
+  for (int s0 = 0; s0 < R3 - 1; ++s0)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      dma_piece(a.wpack + (long)s0 * SLOT + wave * (4 * PIECE) + i * PIECE, lane16, (uint32_t)(s0 * SLOT + wave * (4 * PIECE) + i * PIECE));
+  if (AMb) dma_dword(AMb, am_off, amax_dst0);  // the first block's row maxima -> slot 0
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      dma_piece(Ab + (16 * e + 8 * h2) * 4, in_off, side_dst0 + e * SIDE_SLOT + h2 * PIECE);
+      if (EPI == EPI_MASK) dma_piece(Xb + (16 * e + 8 * h2) * 4, ax_off_prev, side_dst0 + e * SIDE_SLOT + (2 + h2) * PIECE);
+    }
+  RG_WAIT_VM(0);
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) A[0][i] = *reinterpret_cast<const u32x4*>(ring_lane + i * PIECE);
+  rsrc_t crs = make_rsrc(nullptr, 0);  // stores of the block held in P (none before the first block is finished)
+  uint32_t cvoff = 0;
+
+  // Preparation of k step / epilogue unit e (side slot e & 3), four stages of micro-operations:
+  //   stage 0: the 8 input values (and mask values) from the side ring, the 8 values of P's unit e (un-scaled)
+  //   stage 1: epilogue of the 8 values, running maximum of the results (amax_out)
+  //   stage 2 / 3: two-limb fp16 split of the input dwords 0, 1 / 2, 3 (6 operations each, alternating: scale by the point's
+  //                2^kB, exact running maximum, hi, two residuals, lo) -> out; one 16-byte store
+  struct EpiState { float x[8], y[8], mk[8]; float xs[2][2], ra[2], rb[2]; uint32_t hi[2]; };
+  static constexpr int CNT[4] = {8, 12, 13, 13};
+#define RG_PIN(x) asm volatile("" : "+v"(x))
+  // track: does the k step exist (its values count for the guard)?  0 = no (the slot holds the NEXT block's k step 0, split again at
+  // its block start with ITS scale), 1 = yes, 2 = only with KS = 20
+  auto mop = [&](int e, bool unit, int stage, int k, Limbs& out, EpiState& st, int track = 1) {
+    const int ss = e & 3;
+    if (stage == 0) {
+      const int i = k;
+      if ((i & 3) == 0) {
+        const float* sp = side_rd + ss * (SIDE_SLOT / 4) + (i >> 2) * (PIECE / 4);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(sp);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) st.x[i + v] = xv[v];
+        if (EPI == EPI_MASK) {
+          const f32x4 mv = *reinterpret_cast<const f32x4*>(sp + 2 * (PIECE / 4));
+#pragma unroll
+          for (int v = 0; v < 4; ++v) st.mk[i + v] = mv[v];
+        }
+      }
+      if (unit) {
+        float t = P[e >> 1][8 * (e & 1) + i] * yscP;
+        RG_PIN(t);
+        st.y[i] = t;
+      }
+    } else if (stage == 1) {
+      if (!unit) return;
+      if (k < 8) {
+        float t = st.y[k];
+        if (EPI == EPI_RELU) t = relu1(t);
+        if (EPI == EPI_MASK) t = st.mk[k] > 0.f ? t : 0.f;
+        RG_PIN(t);
+        st.y[k] = t;
+      } else {
+        const int p = k - 8;
+        asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(omx) : "v"(st.y[2 * p]), "v"(st.y[2 * p + 1]));
+      }
+    } else {
+      const int h2 = stage - 2;
+      if (k == 12) {
+        if (unit) {
+          const f32x4 v = {st.y[4 * h2], st.y[4 * h2 + 1], st.y[4 * h2 + 2], st.y[4 * h2 + 3]};
+          store4(v, crs, cvoff + (16 * e + 8 * h2) * 4);
+        }
+        return;
+      }
+      const int d = k & 1, op = k >> 1;
+      if (op == 0) {
+        st.xs[d][0] = st.x[4 * h2 + 2 * d] * sB;
+        st.xs[d][1] = st.x[4 * h2 + 2 * d + 1] * sB;
+        RG_PIN(st.xs[d][0]);
+        RG_PIN(st.xs[d][1]);
+      } else if (op == 1) {
+        if (track == 1) asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mx) : "v"(st.xs[d][0]), "v"(st.xs[d][1]));
+        if (track == 2) {
+          float t = mx;
+          asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(t) : "v"(st.xs[d][0]), "v"(st.xs[d][1]));
+          mx = KS > 16 ? t : mx;
+        }
+      } else if (op == 2) {
+        uint32_t hi = cvt_pk(st.xs[d][0], st.xs[d][1]);
+        RG_PIN(hi);
+        st.hi[d] = hi;
+        out.l[0][2 * h2 + d] = hi;
+      } else if (op == 3) st.ra[d] = resid<0>(st.hi[d], st.xs[d][0]);
+      else if (op == 4) st.rb[d] = resid<1>(st.hi[d], st.xs[d][1]);
+      else {
+        uint32_t lo = cvt_pk(st.ra[d], st.rb[d]);
+        RG_PIN(lo);
+        out.l[1][2 * h2 + d] = lo;
+      }
+    }
+  };
+
+  // One k step j (rgemm.hip:kstep with 6 instead of 12 MFMAs per group): 4 groups x 6 MFMAs (hi hi, hi lo, lo hi for two n-tiles);
+  // behind every MFMA one fragment read (gaps 0..3), in the group behind the rendezvous the four weight pieces of stream step
+  // gs + R3 - 1, in the last group -- BEHIND them in the queue -- the side fragments of k step j + 4 (of the next block once
+  // j + 4 >= KS), and cnt[group] / 6 micro-operations.
+  auto kstep = [&](int j, const int (&cnt)[4], auto&& mp) {
+    // KS % R3 == 0 and every block starts a new pass over the stream: ring slots are compile-time functions of j
+    const int slot = j % R3, nslot = (j + 1) % R3, fslot = (j + R3 - 1) % R3;
+    int jw = j + R3 - 1;
+    jw = jw >= KS ? jw - KS : jw;
+    const char* wsrc = wbase + (long)jw * SLOT + wave * (4 * PIECE);
+    const uint32_t wdst = (uint32_t)(fslot * SLOT + wave * (4 * PIECE));
+    const int e4 = j + 4;
+    const bool wrap = e4 >= KS;
+    const int ec = wrap ? e4 - KS : e4;  // k step (and epilogue unit) the side request is for
+    const uint32_t sd = side_dst0 + (j & 3) * SIDE_SLOT;
+    const char* s1 = Ab + 64 * (ec < a.K16 ? ec : 0);  // padded k steps (zero weights) re-read k step 0: never past a row
+    const uint32_t o1 = wrap ? in_off_next : in_off;
+    const char* s2 = Xb + 64 * (ec < 16 ? ec : 15);
+    const uint32_t o2 = wrap ? ax_off_cur : ax_off_prev;  // unit ec of the block in P, or (wrapped) of the running block
+#pragma unroll
+    for (int pair = 0; pair < 4; ++pair) {
+      if (pair == 2) {  // rendezvous: the weights of stream step gs + 1 have landed in every wave; slot gs - 1 is free
+        RG_WAIT_VM(NWAIT);
+        __builtin_amdgcn_s_barrier();
+      }
+      const char* rd = ring_lane + (pair < 3 ? slot * SLOT + (pair + 1) * (4 * PIECE) : nslot * SLOT);
+#pragma unroll
+      for (int m = 0; m < 6; ++m) {
+        const int pr = m >> 1, tt = m & 1;            // (w limb, act limb): hi hi, hi lo, lo hi
+        const int wl = pr == 2 ? 1 : 0, al = pr == 1 ? 1 : 0;
+        Q[2 * pair + tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[pair & 1][2 * tt + wl]),
+                                                                 __builtin_bit_cast(f16x8, Bc.l[al]), Q[2 * pair + tt], 0, 0, 0);
+        if (m < 4) A[(pair + 1) & 1][m] = *reinterpret_cast<const u32x4*>(rd + m * PIECE);
+        if (pair == 2 && m < 4) dma_piece(wsrc + m * PIECE, lane16, wdst + m * PIECE);
+        if (pair == 3 && (m == 0 || m == 2)) dma_piece(s1 + 32 * (m == 2), o1, sd + (m == 2) * PIECE);
+        if (pair == 3 && NSIDE == 2 && (m == 3 || m == 5)) dma_piece(s2 + 32 * (m == 5), o2, sd + 2 * PIECE + (m == 5) * PIECE);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // constant trip count (the slice bounds fold once pair and m are unrolled)
+          const int k = cnt[pair] * m / 6 + u;
+          if (k < cnt[pair] * (m + 1) / 6) mp(pair, k);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    Bc = Bn;
+  };
+  static constexpr int CNT_NONE[4] = {0, 0, 0, 0};
+  auto no_mop = [](int, int) {};
+
+  for (; blk * BPTS < a.P; blk += gridDim.x) {
+    // the stream bases are made opaque once per block: loop-invariant, the ~160 DMA source addresses of a block would be
+    // hoisted out of the block loop and live in spilled scalar registers (two v_readlane per DMA) instead of two s_add each
+    asm volatile("" : "+s"(wbase), "+s"(Ab), "+s"(Xb));
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) asm volatile("" : "+a"(P[nt][r]));  // the finished block lives in the AGPR half
+    // the scale of this block's rows: their maximum (landed in slot bi & 1 a block ago) or the floor, at [2^12, 2^13); the next
+    // block's maxima are requested into the other slot
+    {
+      float m = a.amax_floor;
+      if (AMb) {
+        m = fmaxf(m, amax_rd[(bi & 1) * 64]);
+        dma_dword(AMb, am_off_next, amax_dst0 + (uint32_t)(((bi + 1) & 1) * 256));
+      }
+      kB = row_scale(m);
+      sB = pow2f(kB);
+    }
+    init_q();
+    EpiState st;
+    // k step 0 / unit 0: not overlapped (once per block)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int k = 0; k < 13; ++k)
+        if (k < CNT[c]) mop(0, true, c, k, Bc, st);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j + 1 < 16)
+        kstep(j, CNT, [&](int c, int k) { mop(j + 1, true, c, k, Bn, st); });
+      else  // k step 16 exists only when KS = 20; its input fragment sits in side slot 0 either way
+        kstep(j, CNT, [&](int c, int k) { mop(j + 1, false, c, k, Bn, st, 2); });
+    }
+    if (KS > 16) {  // K padded to 320 (wave-uniform)
+#pragma unroll
+      for (int j = 16; j < 20; ++j) kstep(j, CNT, [&](int c, int k) { mop(j + 1, false, c, k, Bn, st, j + 1 < 20 ? 1 : 0); });
+    }
+    // ---- every unit of the block held in P has been stored: its rows' maxima (both lane halves hold the same point) ----
+    if (a.amax_out && row_P >= 0) {
+      const float o = fmaxf(omx, __shfl_xor(omx, 32));
+      if (hh == 0 && row_P + li < a.P) a.amax_out[row_P + li] = o;
+    }
+    omx = 0.f;
+    // ---- the block is finished: it becomes P; its stores run behind the next block ----
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) P[nt] = Q[nt];
+    yscP = c3 * pow2f(-kB);
+    row_P = blk * BPTS + wave * 32;
+    ++bi;
+    am_off_next = (uint32_t)(clamp_row(blk + 2 * (long)gridDim.x) * 4);
+    const long row = blk * BPTS + wave * 32 + li;  // unclamped: the buffer range check drops rows >= P
+    crs = make_rsrc(a.C, cbytes);
+    cvoff = (uint32_t)((row * a.ldc + 4 * hh) * 4);
+    in_off = in_off_next;
+    in_off_next = (uint32_t)((clamp_row(blk + 2 * (long)gridDim.x) * a.lda + 4 * hh) * 4);
+    ax_off_prev = ax_off_cur;
+    ax_off_cur = (uint32_t)((clamp_row(blk + gridDim.x) * (long)a.ld_aux + 4 * hh) * 4);
+  }
+  RG_WAIT_VM(0);  // no LDS-DMA in flight when the workgroup's LDS is released
+  (void)no_mop; (void)CNT_NONE; (void)xbytes;
+  // ---- epilogue of the last block (exposed): mask rows by ordinary buffer loads ----
+  {
+    const rsrc_t xrs = make_rsrc(EPI == EPI_MASK ? a.aux : nullptr, xbytes);
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint32_t co = (32 * nt + 8 * g) * 4;
+        u32x4 mv = {0u, 0u, 0u, 0u};
+        if (EPI == EPI_MASK) mv = __builtin_amdgcn_raw_buffer_load_b128(xrs, ax_off_prev + co, 0, 0);
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float t = P[nt][4 * g + k] * yscP;
+          if (EPI == EPI_RELU) t = relu1(t);
+          if (EPI == EPI_MASK) t = bitsf(mv[k]) > 0.f ? t : 0.f;
+          v[k] = t;
+          omx = fmaxf(omx, fabsf(t));
+        }
+        store4(v, crs, cvoff + co);
+      }
+    if (a.amax_out && row_P >= 0) {
+      const float o = fmaxf(omx, __shfl_xor(omx, 32));
+      if (hh == 0 && row_P + li < a.P) a.amax_out[row_P + li] = o;
+    }
+  }
+  if (a.guard) {
+    const float m2 = fmaxf(mx, __shfl_xor(mx, 32));
+    if (m2 >= 65504.f) __hip_atomic_store(a.guard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <int EPI>
+int launch_h3(const RGArgs& a, hipStream_t s) {
+  constexpr int NSIDE = EPI == EPI_MASK ? 2 : 1;
+  constexpr int lds = R3 * SLOT + NW * SIDE_RING * NSIDE * 2 * PIECE + 1024 + NW * 512;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static int n_cu = 0;
+  static bool attr_set = false;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return HOLD_E_LAUNCH;
+    n_cu = prop.multiProcessorCount;
+  }
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)rgemm_h3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return HOLD_E_LAUNCH;
+    attr_set = true;
+  }
+  const long blocks = (a.P + BPTS - 1) / BPTS;
+  hipLaunchKernelGGL((rgemm_h3_kernel<EPI>), dim3((unsigned)(blocks < n_cu ? blocks : n_cu)), dim3(256), lds, s, a);
+  return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int64_t hold_gemm_h3_pack_bytes(int32_t K) { return (int64_t)((K + 63) / 64 * 4) * SLOT; }
+
+extern "C" int hold_gemm_r6_if(const float* A, int32_t lda, int64_t P, const void* wpack, int32_t K, const float* bias,
+                               int32_t epilogue, const float* aux, int32_t ld_aux, float* C, int32_t ldc, float* amax_out,
+                               uint32_t* guard, hold_stream_t st);
+
+// hold_gemm_r6's contract in the f16x3 arithmetic.  wpack_h3 = hold_gemm_h3_pack_bytes(K) bytes of fp16, [KS k steps j][8 n-tiles
+// nt][2 limbs t][2 halves h][32 rows i][8 e] = limb_t(s_w W)[32 nt + i][16 j + 8 (e / 4) + 4 h + e % 4]; c3 = 1 / s_w (device
+// scalar).  amax_in [P] (or NULL): an upper bound of |A[p][:]| over the columns its producer wrote (exact when it is a producer's
+// amax_out); amax_floor >= the magnitude of the other columns (NULL amax_in: of every column); amax_out [P] (or NULL): receives
+// max |C[p][:]|.  guard / wpack_r6: overflow guard and conditional f32x6 fallback (hold_gemm_r6_if), as hold_fused_sdf_h3.
+extern "C" int hold_gemm_h3(const float* A, int32_t lda, int64_t P, const void* wpack_h3, const float* c3, int32_t K,
+                            const float* bias, int32_t epilogue, const float* aux, int32_t ld_aux, float* C, int32_t ldc,
+                            const float* amax_in, float amax_floor, float* amax_out, uint32_t* guard, const void* wpack_r6,
+                            hold_stream_t st) {
+  if (!A || !wpack_h3 || !c3 || !C || P < 0 || K < 256 || K > 320 || (K & 15) || lda < K || (lda & 3) || ldc < 256 || (ldc & 3)) return HOLD_E_ARG;
+  if (((uintptr_t)A & 15) || ((uintptr_t)C & 15) || ((uintptr_t)wpack_h3 & 15) || (bias && ((uintptr_t)bias & 15))) return HOLD_E_ARG;
+  if (epilogue < 0 || epilogue > 2) return HOLD_E_ARG;
+  if (epilogue == 2 && (!aux || bias || ld_aux < 256 || (ld_aux & 3) || ((uintptr_t)aux & 15))) return HOLD_E_ARG;
+  if (!(amax_floor >= 0.f) || (!amax_in && !(amax_floor > 0.f))) return HOLD_E_ARG;
+  if (((uintptr_t)amax_in & 3) || ((uintptr_t)amax_out & 3) || ((uintptr_t)guard & 3) || (wpack_r6 && !guard)) return HOLD_E_ARG;
+  if (P == 0) return HOLD_OK;
+  const int64_t ldmax = lda > ldc ? (lda > ld_aux ? lda : ld_aux) : (ldc > ld_aux ? ldc : ld_aux);
+  if (((uint64_t)P + BPTS) * (uint64_t)ldmax * 4 >= (1ull << 32)) return HOLD_E_ARG;
+  RGArgs a;
+  a.A = A; a.lda = lda; a.P = (long)P; a.wpack = (const char*)wpack_h3; a.c3 = c3; a.amax_in = amax_in; a.amax_floor = amax_floor;
+  a.amax_out = amax_out; a.guard = guard; a.KS = (K + 63) / 64 * 4; a.K16 = K / 16; a.bias = bias; a.aux = aux;
+  a.ld_aux = ld_aux; a.C = C; a.ldc = ldc;
+  hipStream_t s = (hipStream_t)st;
+  const int rc = epilogue == 0 ? launch_h3<EPI_NONE>(a, s) : epilogue == 1 ? launch_h3<EPI_RELU>(a, s) : launch_h3<EPI_MASK>(a, s);
+  if (rc != HOLD_OK || !wpack_r6) return rc;
+  return hold_gemm_r6_if(A, lda, P, wpack_r6, K, bias, epilogue, aux, ld_aux, C, ldc, amax_out, guard, st);
+}

@@ -42,6 +42,8 @@ USE_H3_BWD = os.environ.get("HOLD_H3_BWD", "1") != "0"  # mode f16x3: the three 
 # the 256 x 256 weight gradients of a backward as one grouped launch (gemm.WgradGroup / hold_wgrad_group_x6)
 USE_WGRAD_GROUP = os.environ.get("HOLD_WGRAD_GROUP", "1") != "0"
 USE_R6_GEMM = os.environ.get("HOLD_R6_GEMM", "1") != "0"  # ... and for the rendering net's layers / lin8 (csrc/rgemm.hip)
+USE_H3_GEMM = os.environ.get("HOLD_H3_GEMM", "1") != "0"  # mode f16x3: those layers in two fp16 limbs (csrc/rgemm_h3.hip; A/B switch)
+H3_ROW_FLOOR = 64.0  # assumed bound of activation columns no producer reported a maximum for (= 2^6, the trunk's activation scale)
 RIN_FEAT, RIN_X, RIN_N, RIN_POSE, RIN_TIME = 0, 256, 259, 262, 270
 
 
@@ -266,8 +268,21 @@ def _gemm_kmap(KS, device):
 
 
 def _lay_gemm_r6(l3, KS):
-    g = l3[:, :, _gemm_kmap(KS, l3.device)]  # [3 t, 256 out, KS j, 2 h, 8 e]
-    return g.reshape(3, 8, 32, KS, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(-1)
+    T = l3.shape[0]  # limbs: 3 (bf16, hold_gemm_r6) or 2 (fp16, hold_gemm_h3)
+    g = l3[:, :, _gemm_kmap(KS, l3.device)]  # [T t, 256 out, KS j, 2 h, 8 e]
+    return g.reshape(T, 8, 32, KS, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(-1)
+
+
+def pack_gemm_h3(W):
+    """limb pack of hold_gemm_h3 (include/hold_hip.h) for one matrix W [N <= 256, K in 256..320]: pack_gemm_r6's rows and k order,
+    two fp16 limbs of s_w W with s_w = 2^k, max |W| s_w in [2^13, 2^14) -> (stream fp16, c3 = 1 / s_w as a one-element tensor)"""
+    N, K = W.shape
+    KS = (K + 63) // 64 * 4
+    m = torch.zeros(256, 16 * KS, device=W.device)
+    m[:N, :K] = W
+    _, ex = torch.frexp(m.abs().amax())
+    sw = torch.ldexp(torch.ones((), device=W.device), 14 - ex)
+    return _lay_gemm_r6(torch.stack(split_limbs_h(m * sw)), KS).contiguous(), (1.0 / sw).reshape(1)
 
 
 _PLANS = {}
@@ -287,8 +302,17 @@ def render_plan(Kr, need_bwd, device):
         parts = [_lay_gemm_r6(l3(I0), 20)]
         for q in range(nm):
             parts.append(_lay_gemm_r6(l3(n0 + q * 65536 + torch.arange(65536, device=device).view(256, 256)), 16))
+        # the same packs in two fp16 limbs (hold_gemm_h3): the gather over [2, N] limbs of the SCALED source, and the matrix a
+        # source element belongs to (per-matrix power-of-two scales, computed on the device at pack time)
+        l2 = lambda I: torch.stack([I + t * N for t in range(2)])
+        parts_h = [_lay_gemm_r6(l2(I0), 20)]
+        for q in range(nm):
+            parts_h.append(_lay_gemm_r6(l2(n0 + q * 65536 + torch.arange(65536, device=device).view(256, 256)), 16))
+        seg = torch.cat([torch.zeros(n0, dtype=torch.long, device=device),
+                         1 + torch.arange(nm, device=device).repeat_interleave(65536)])
         _RPLANS[key] = dict(N=N, idx=torch.cat(parts).to(torch.int32).contiguous(),
-                            sizes=[p.numel() for p in parts])
+                            sizes=[p.numel() for p in parts], idx_h3=torch.cat(parts_h).to(torch.int32).contiguous(),
+                            sizes_h3=[p.numel() for p in parts_h], seg=seg, nm=1 + nm)
     return _RPLANS[key]
 
 
@@ -334,8 +358,11 @@ def _h3_plan(device):
     l2 = lambda I: torch.stack([I + t * N for t in range(2)])
     seg = torch.cat([torch.zeros(n0, dtype=torch.long, device=device), 1 + torch.arange(7, device=device).repeat_interleave(65536)])
     ISTf = IS.transpose(1, 2).flip(0)  # descending sweeps (hold_chain_h3, DSP): chain layer j = W_{7-j}^T, scaled by s_w[7 - j]
+    I8 = torch.arange(65536, device=device).view(256, 256)  # lin8's feature rows: a source of their own ([2, 65536] limbs)
+    l2_8 = torch.stack([I8, I8 + 65536])
     return dict(idx=torch.cat([_lay_r6_0(l2(I0)), _lay_r6_stack(l2(IS))]).to(torch.int32).contiguous(), seg=seg,
-                idx_bwd=_lay_r6_stack(l2(ISTf)).to(torch.int32).contiguous())
+                idx_bwd=_lay_r6_stack(l2(ISTf)).to(torch.int32).contiguous(),
+                idx_w8=_lay_gemm_r6(l2_8, 16).to(torch.int32).contiguous())
 
 
 def frag_pack_stack(S):
@@ -402,6 +429,12 @@ def pack_weights(spec: FieldSpec, iw, ib, rw, rb, need_bwd: bool, trunk=None):
         # layer j = W_{7-j}^T, the same limbs gathered in another order), the ascending one the forward stream itself
         pk["chain_bwd_h3"] = limbs_h.index_select(0, plan["h3"]["idx_bwd"])
         pk["c3_bwd_h3"] = pk["c3_h3"][1:].flip(0).contiguous()
+        # lin8's 256 feature rows for hold_gemm_h3 (its own scale)
+        w8f = w8[:256].reshape(-1)
+        _, ex8 = torch.frexp(w8f.abs().amax())
+        sw8 = torch.ldexp(torch.ones((), device=dev), 14 - ex8)
+        pk["w8_feat_h3"] = torch.stack(split_limbs_h(w8f * sw8)).reshape(-1).index_select(0, plan["h3"]["idx_w8"])
+        pk["c3_w8"] = (1.0 / sw8).reshape(1)
     if rw is None:  # implicit net only (ImplicitNet.forward / gradient)
         return pk
     return _pack_render(pk, spec, rw, rb, need_bwd, dev)
@@ -429,6 +462,17 @@ def _pack_render(pk, spec, rw, rb, need_bwd, dev):
         pk["R_r6"] = list(packs[:4])
         if need_bwd:
             pk["RT_r6"] = [packs[7]] + list(packs[4:7])
+        if config.h3():  # hold_gemm_h3 streams of the same matrices: per-matrix scales (one segmented maximum), two fp16 limbs
+            flat = torch.cat(mats)
+            amax = torch.zeros(plan["nm"], device=dev).scatter_reduce_(0, plan["seg"], flat.abs(), "amax")
+            _, ex = torch.frexp(amax)
+            sw = torch.ldexp(torch.ones_like(amax), 14 - ex)
+            limbs_h = torch.stack(split_limbs_h(flat * sw[plan["seg"]])).reshape(-1)
+            ph = limbs_h.index_select(0, plan["idx_h3"]).split(plan["sizes_h3"])
+            c3 = (1.0 / sw).contiguous()
+            pk["R_h3"], pk["c3_R"] = list(ph[:4]), [c3[i:i + 1] for i in range(4)]
+            if need_bwd:
+                pk["RT_h3"], pk["c3_RT"] = [ph[7]] + list(ph[4:7]), [c3[7:8]] + [c3[i:i + 1] for i in range(4, 7)]
     return pk
 
 
@@ -609,7 +653,13 @@ class NodeField:
         sp, pool = self.spec, self.pool
         rin = pool.get("rin", P, sp.Kr)
         # lin8 = 256 feature rows as a full-tile GEMM + the sdf row as a row dot (N = 257 would add a 256-wide tile for it)
-        if USE_R6_GEMM and "w8_feat_r6" in pk:
+        h3g = USE_H3_GEMM and USE_R6_GEMM and "w8_feat_h3" in pk and "R_h3" in pk
+        # row maxima travelling from launch to launch (hold_gemm_h3: every point's operand row is scaled by its own power of two)
+        amx = [pool.get(f"amx{i}", P, 1) for i in range(2)] if h3g else None
+        if h3g:  # input: the trunk's last softplus output (no reported maximum: the floor); output maxima -> lin0's features
+            G.gemm_h3(h[7], pk["w8_feat_h3"], pk["c3_w8"], rin[:, RIN_FEAT:RIN_FEAT + FEAT], K=256, wpack_r6=pk["w8_feat_r6"],
+                      bias=pk["b8_feat"], amax_floor=H3_ROW_FLOOR, amax_out=amx[0])
+        elif USE_R6_GEMM and "w8_feat_r6" in pk:
             G.gemm_r6(h[7], pk["w8_feat_r6"], rin[:, RIN_FEAT:RIN_FEAT + FEAT], K=256, bias=pk["b8_feat"])
         else:
             G.gemm_nt(h[7], pk["W8_feat"], rin[:, RIN_FEAT:RIN_FEAT + FEAT], bias=pk["b8_feat"], N=256)
@@ -635,7 +685,14 @@ class NodeField:
         # ---- rendering net ----
         R, rb = pk["R"], pk["rb"]
         r = [pool.get(f"r{l}", P, 256) for l in range(4)]
-        if USE_R6_GEMM and "R_r6" in pk:
+        if h3g:
+            # lin0 reads [features | xc | normal | pose | (time)]: the features' maxima are exact, the floor bounds the rest
+            G.gemm_h3(rin, pk["R_h3"][0], pk["c3_R"][0], r[0], K=sp.Kr, wpack_r6=pk["R_r6"][0], bias=rb[0], epi=G.R6_RELU,
+                      amax_in=amx[0], amax_floor=H3_ROW_FLOOR, amax_out=amx[1])
+            for l in (1, 2, 3):
+                G.gemm_h3(r[l - 1], pk["R_h3"][l], pk["c3_R"][l], r[l], K=256, wpack_r6=pk["R_r6"][l], bias=rb[l], epi=G.R6_RELU,
+                          amax_in=amx[l & 1], amax_out=amx[(l + 1) & 1] if l < 3 else None)
+        elif USE_R6_GEMM and "R_r6" in pk:
             G.gemm_r6(rin, pk["R_r6"][0], r[0], K=sp.Kr, bias=rb[0], epi=G.R6_RELU)
             for l in (1, 2, 3):
                 G.gemm_r6(r[l - 1], pk["R_r6"][l], r[l], K=256, bias=rb[l], epi=G.R6_RELU)
@@ -878,6 +935,13 @@ class NodeField:
         G.head3_bwd(dy, r[3], R[4], rr[1], dR[4], db4)  # input gradient + weight / bias gradients in one pass over r3
         dRb[4] = db4[:3]
         cur, ci = rr[1], 1
+        h3g = USE_H3_GEMM and USE_R6_GEMM and "RT_h3" in pk
+        if h3g:
+            # row bound of d r_3 = (R_3 > 0) * (dy . W_4): |dy_0| + |dy_1| + |dy_2| times the largest |W_4| -- an upper bound a few
+            # times above the row's maximum costs the two-limb split nothing (full precision over 14 binades below the bound)
+            bamx = [self.bpool.get(f"bamx{i}", P, 1) for i in range(2)]
+            torch.mul(dy[:, :3].abs().sum(1, keepdim=True), R[4].abs().amax(), out=bamx[1])
+            bi = 1
         for l in (3, 2, 1):
             if grp is None:
                 G.wgrad(cur, r[l - 1], dR[l], dRb[l])
@@ -885,14 +949,21 @@ class NodeField:
                 grp.add(cur, r[l - 1], dR[l], dRb[l])
             ci = (ci + 1) % len(rr)
             nxt = rr[ci]
-            if USE_R6_GEMM and "RT_r6" in pk:
+            if h3g:
+                G.gemm_h3(cur, pk["RT_h3"][l], pk["c3_RT"][l], nxt, K=256, wpack_r6=pk["RT_r6"][l], epi=G.R6_MASK, aux=r[l - 1],
+                          amax_in=bamx[bi], amax_out=bamx[bi ^ 1])
+                bi ^= 1
+            elif USE_R6_GEMM and "RT_r6" in pk:
                 G.gemm_r6(cur, pk["RT_r6"][l], nxt, K=256, epi=G.R6_MASK, aux=r[l - 1])
             else:
                 G.gemm_nt(cur, RT[l], nxt, epi=G.EPI_MUL_DRELU, aux1=r[l - 1])
             cur = nxt
         G.wgrad(cur, rin, dR[0], dRb[0], K=sp.Kr)
         d_rin = pool.get("d_rin", P, sp.Kr)
-        if USE_R6_GEMM and "RT_r6" in pk:  # the 256 feature columns register-resident, the 16 / 48 others a narrow GEMM
+        if h3g:
+            G.gemm_h3(cur, pk["RT_h3"][0], pk["c3_RT"][0], d_rin[:, :FEAT], K=256, wpack_r6=pk["RT_r6"][0], amax_in=bamx[bi])
+            G.gemm_narrow(cur, RT[0][FEAT:], d_rin[:, FEAT:], N=sp.Kr - FEAT)
+        elif USE_R6_GEMM and "RT_r6" in pk:  # the 256 feature columns register-resident, the 16 / 48 others a narrow GEMM
             G.gemm_r6(cur, pk["RT_r6"][0], d_rin[:, :FEAT], K=256)
             G.gemm_narrow(cur, RT[0][FEAT:], d_rin[:, FEAT:], N=sp.Kr - FEAT)
         else:

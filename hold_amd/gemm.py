@@ -58,6 +58,35 @@ def gemm_r6(A, wpack, out, *, K, bias=None, epi=R6_NONE, aux=None):
     return out
 
 
+def gemm_h3(A, wpack_h3, c3, out, *, K, wpack_r6, bias=None, epi=R6_NONE, aux=None, amax_in=None, amax_floor=0.0, amax_out=None):
+    """gemm_r6 in the two-limb fp16 arithmetic (hold_gemm_h3, csrc/rgemm_h3.hip): wpack_h3 / c3 from field.pack_gemm_h3 (c3 = a
+    one-element device tensor, 1 / s_w).  Every row of A is scaled by its own power of two from max(amax_in[p], amax_floor)
+    (amax_in [P]: the amax_out of the launch that produced A, or any upper bound; amax_floor: bound of the columns that launch did
+    not write / of everything without amax_in); amax_out [P] receives the row maxima of out.  wpack_r6 = gemm_r6's stream of the
+    same matrix: the conditional f32x6 fallback behind the overflow guard (kernels.h3_guard)."""
+    from . import kernels as _k
+    P = A.shape[0]
+    L = _lib.lib()
+    assert wpack_h3.numel() * wpack_h3.element_size() == L.hold_gemm_h3_pack_bytes(K) and wpack_h3.dtype == torch.float16
+    assert wpack_r6.numel() * wpack_r6.element_size() == L.hold_gemm_r6_pack_bytes(K)
+    assert c3.numel() == 1 and c3.dtype == torch.float32 and c3.is_cuda
+    for t in (amax_in, amax_out):
+        assert t is None or (t.numel() == P and t.dtype == torch.float32 and t.is_contiguous())
+    ldmax = max(_ld(A), _ld(out), _ld(aux) if aux is not None else 0)
+    rows = max(128, ((1 << 32) // (4 * ldmax) - 256) // 128 * 128)  # 32-bit offsets inside the kernel: split by rows
+    guard = _k.h3_guard(A.device)
+    e0 = _prof_begin()
+    for r0 in range(0, P, rows):
+        n = min(P, r0 + rows) - r0
+        check(L.hold_gemm_h3(ptr(A[r0:]), _ld(A), n, ptr(wpack_h3), ptr(c3), K, ptr(bias), int(epi),
+                             ptr(None if aux is None else aux[r0:]), 0 if aux is None else _ld(aux), ptr(out[r0:]), _ld(out),
+                             ptr(None if amax_in is None else amax_in.reshape(-1)[r0:]), float(amax_floor),
+                             ptr(None if amax_out is None else amax_out.reshape(-1)[r0:]), ptr(guard), ptr(wpack_r6), stream_ptr()),
+              "hold_gemm_h3")
+    _prof_end(e0, 2.0 * P * 256 * K, "rgemm_h3_kernel", 4.0 * P * (K + 256 + (256 if aux is not None else 0) + 2))
+    return out
+
+
 def gemm_nt(A, W, out, *, bias=None, epi=EPI_NONE, alpha=1.0, N=None, K=None, n_split=None, out_raw=None,
             aux1=None, aux2=None, out2=None, accumulate=False, r1_row=None, r1_col=None):
     """out[:, :N] = epi(alpha * A[:, :K] @ W[:N, :K].T + bias).  All tensors are 2-D fp32 CUDA views with unit

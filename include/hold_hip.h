@@ -515,6 +515,26 @@ int hold_chain_h3(const hold_chain_desc* d, const float* c3, uint32_t* guard, co
 int64_t hold_gemm_r6_pack_bytes(int32_t K);
 int hold_gemm_r6(const float* A, int32_t lda, int64_t P, const void* wpack, int32_t K, const float* bias, int32_t epilogue,
                  const float* aux, int32_t ld_aux, float* C, int32_t ldc, hold_stream_t stream);
+/* ... with the per-row maxima of C as a second output (amax_out [P] = max |C[p][:]|, or NULL) and as a CONDITIONAL launch (guard: the
+ * 4 words of hold_fused_sdf_r6_if; NULL = always run): the fallback of hold_gemm_h3 */
+int hold_gemm_r6_if(const float* A, int32_t lda, int64_t P, const void* wpack, int32_t K, const float* bias, int32_t epilogue,
+                    const float* aux, int32_t ld_aux, float* C, int32_t ldc, float* amax_out, uint32_t* guard,
+                    hold_stream_t stream);
+
+/* hold_gemm_r6 in the TWO-LIMB fp16 arithmetic "f16x3" (hold_amd/csrc/rgemm_h3.hip): 24 matrix instructions per k step instead of 48.
+ * wpack_h3: hold_gemm_h3_pack_bytes(K) bytes of fp16, [KS k steps j][8 n-tiles nt][2 limbs t][2 halves h][32 rows i][8 e] =
+ *   limb_t(s_w W)[32 nt + i][16 j + 8 (e / 4) + 4 h + e % 4] (the rows and k order of hold_gemm_r6's stream), s_w = 2^k with
+ *   max |W| s_w in [2^13, 2^14); c3 = 1 / s_w, one float in device memory.
+ * Every ROW of A (a point) is scaled by its own power of two: max(amax_in[p], amax_floor) goes to [2^12, 2^13).  amax_in [P] (or
+ *   NULL) = an upper bound of |A[p][c]| over the columns its producer wrote -- exact when it is the amax_out of the launch that wrote
+ *   A -- and amax_floor bounds the remaining columns (with amax_in == NULL: every column; must then be > 0).  amax_out [P] (or NULL)
+ *   receives max |C[p][:]| for the next launch.  Values up to 2^3 x that bound are representable; beyond it the overflow guard of
+ *   hold_fused_sdf_h3 applies (guard, wpack_r6 = hold_gemm_r6's stream of the same W: conditional recomputation in f32x6, C and
+ *   amax_out then hold_gemm_r6_if's). */
+int64_t hold_gemm_h3_pack_bytes(int32_t K);
+int hold_gemm_h3(const float* A, int32_t lda, int64_t P, const void* wpack_h3, const float* c3, int32_t K, const float* bias,
+                 int32_t epilogue, const float* aux, int32_t ld_aux, float* C, int32_t ldc, const float* amax_in, float amax_floor,
+                 float* amax_out, uint32_t* guard, const void* wpack_r6, hold_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Weight normalisation of all layers of a net in one launch per direction (hold_amd/csrc/wnorm.hip): every Linear of

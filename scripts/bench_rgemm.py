@@ -23,4 +23,8 @@ for K, epi in ((256, "relu"), (256, "mask"), (256, "none"), (304, "relu")):
     t1 = timeit(lambda: G.gemm_nt(A, W, o1, bias=None if epi == "mask" else b, epi=e_nt, aux1=aux, K=K))
     t2 = timeit(lambda: G.gemm_r6(A, pk, o2, K=K, bias=None if epi == "mask" else b, epi=e_r6, aux=aux))
     fl = 2.0 * P * 256 * K
+    pk3, c3 = F.pack_gemm_h3(W)
+    am_in, am_out, o3 = A.abs().amax(1).contiguous(), torch.empty(P, device=dev), torch.empty(P, 256, device=dev)
+    t3 = timeit(lambda: G.gemm_h3(A, pk3, c3, o3, K=K, wpack_r6=pk, bias=None if epi == "mask" else b, epi=e_r6, aux=aux, amax_in=am_in, amax_out=am_out))
+    print(f"K={K} {epi:5s} P={P}: gemm_h3 {t3:.3f} ms {2.0 * P * 256 * K / t3 / 1e9:.1f} TF-eq ({t2 / t3:.2f} x gemm_r6) | max diff to r6 {float((o3 - o2).abs().max()):.2e}", flush=True)
     print(f"K={K} {epi:5s} P={P}: gemm_nt_x6 {t1:.3f} ms {fl / t1 / 1e9:.1f} TF-eq | gemm_r6 {t2:.3f} ms {fl / t2 / 1e9:.1f} TF-eq | max diff {float((o1 - o2).abs().max()):.2e}", flush=True)

@@ -507,6 +507,72 @@ def test_gemm_r6_matches_fp64(P, K, lda, ldc, epi, split_arith):
         assert float((out[:, 256:] + 7.0).abs().max()) == 0.0  # columns beyond the 256 outputs are not touched
 
 
+@pytest.mark.parametrize("P,K,lda,ldc,epi", [(128 * 3, 256, 256, 256, "none"), (1000, 256, 256, 304, "relu"), (40000, 304, 304, 256, "relu"),
+                                             (70000, 256, 256, 256, "mask"), (33, 272, 272, 256, "none"), (300000, 256, 256, 256, "relu")])
+@pytest.mark.parametrize("rows", ["unit", "spread", "static"])
+def test_gemm_h3_matches_fp64_and_chains_its_row_maxima(P, K, lda, ldc, epi, rows):
+    """hold_gemm_h3 (csrc/rgemm_h3.hip: hold_gemm_r6 in two fp16 limbs, every operand ROW scaled by its own power of two) on the
+    shapes of test_gemm_r6_matches_fp64: error against fp64 PER ROW relative to that row's own largest result (the rows' magnitudes
+    spread log-uniformly over 1e-12 .. 1e+2 in 'spread': loss cotangents; a common absolute bound would only see the largest rows),
+    amax_out == the exact row maxima of the result, no fallback fired; 'static' = no amax_in (the floor alone, as for lin8's input)."""
+    from hold_amd import field as F, gemm, kernels as Kk
+    dev = _dev()
+    torch.manual_seed(P + K)
+    A = torch.randn(P, lda, device=dev)
+    if rows == "spread":
+        A = A * (10.0 ** (torch.rand(P, 1, device=dev) * 14 - 12))
+    W = torch.randn(256, K, device=dev) / 16
+    b = torch.randn(256, device=dev) if epi != "mask" else None
+    aux = torch.randn(P, 256, device=dev) if epi == "mask" else None
+    out = torch.full((P, ldc), -7.0, device=dev)
+    pk, c3 = F.pack_gemm_h3(W)
+    amax_in = None if rows == "static" else A[:, :K].abs().amax(1).contiguous()
+    amax_out = torch.full((P + 64,), -3.0, device=dev)
+    n0 = Kk.h3_overflow_count(dev)
+    gemm.gemm_h3(A[:, :K] if lda == K else A, pk, c3, out, K=K, wpack_r6=F.pack_gemm_r6(W), bias=b,
+                 epi={"none": gemm.R6_NONE, "relu": gemm.R6_RELU, "mask": gemm.R6_MASK}[epi], aux=aux, amax_in=amax_in,
+                 amax_floor=64.0 if rows == "static" else 0.0, amax_out=amax_out[:P])
+    assert Kk.h3_overflow_count(dev) == n0
+    y = A[:, :K].double() @ W.double().t()
+    if b is not None:
+        y = y + b.double()
+    if epi == "relu":
+        y = y.clamp_min(0)
+    if epi == "mask":
+        y = y * (aux > 0)
+    # per row: against the row's own scale (|A row| max x the weights' scale, + the bias where there is one)
+    den = (A[:, :K].double().abs().amax(1, keepdim=True) * float(W.abs().max()) * 16 + (float(b.abs().max()) if b is not None else 0.0)).clamp_min(1e-300)
+    err = ((out[:, :256].double() - y).abs() / den).max().item()
+    assert err < 3e-6, err
+    if ldc > 256:
+        assert float((out[:, 256:] + 7.0).abs().max()) == 0.0  # columns beyond the 256 outputs are not touched
+    assert torch.equal(amax_out[:P], out[:, :256].abs().amax(1)) and float((amax_out[P:] + 3.0).abs().max()) == 0.0
+
+
+def test_gemm_h3_overflow_falls_back_to_r6_with_its_row_maxima():
+    """rows beyond 2^3 x the bound the caller gave (here: no amax_in, floor 64, a few rows of 1e4) leave fp16's range: the guard
+    fires, the conditional hold_gemm_r6_if launch recomputes C AND amax_out, bit-identical to hold_gemm_r6, and counts the event"""
+    from hold_amd import field as F, gemm, kernels as Kk
+    dev = _dev()
+    P, K = 40000, 256
+    torch.manual_seed(3)
+    A = torch.randn(P, K, device=dev)
+    A[12345:12349] *= 1e4
+    W = torch.randn(256, K, device=dev) / 16
+    b = torch.randn(256, device=dev)
+    pk, c3 = F.pack_gemm_h3(W)
+    o3, o6 = torch.empty(P, 256, device=dev), torch.empty(P, 256, device=dev)
+    am = torch.empty(P, device=dev)
+    n0 = Kk.h3_overflow_count(dev)
+    gemm.gemm_h3(A, pk, c3, o3, K=K, wpack_r6=F.pack_gemm_r6(W), bias=b, epi=gemm.R6_RELU, amax_floor=64.0, amax_out=am)
+    gemm.gemm_r6(A, F.pack_gemm_r6(W), o6, K=K, bias=b, epi=gemm.R6_RELU)
+    assert Kk.h3_overflow_count(dev) == n0 + 1 and Kk.h3_guard(dev)[:2].tolist() == [0, 0]
+    assert torch.equal(o3, o6) and torch.equal(am, o6.abs().amax(1))
+    A[12345:12349] *= 1e-4
+    gemm.gemm_h3(A, pk, c3, o3, K=K, wpack_r6=F.pack_gemm_r6(W), bias=b, epi=gemm.R6_RELU, amax_floor=64.0, amax_out=am)
+    assert Kk.h3_overflow_count(dev) == n0 + 1 and torch.equal(am, o3.abs().amax(1))
+
+
 @pytest.mark.parametrize("rscale,xscale", [(1e-9, 1.0), (3e-7, 40.0), (1e4, 1e-5), (1.0, 1.0)])
 def test_wgrad_h3_scales_follow_the_operands(rscale, xscale):
     """the two-limb fp16 weight gradient picks power-of-two operand scales per workgroup from a sample of its rows: loss

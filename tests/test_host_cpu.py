@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert declared - {"hold_abi_version", "hold_wgrad_workspace_floats", "hold_fused_sdf_pack_floats", "hold_chain_pack_floats", "hold_fused_sdf_x6_pack_bytes",
                        "hold_silhouette_workspace_floats", "hold_reduce_workspace_floats", "hold_chain_x6_pack_bytes", "hold_trunk_r6_pack_bytes", "hold_chain_r6_pack_bytes", "hold_gemm_r6_pack_bytes",
                        "hold_wcolsum_workspace_floats", "hold_head3_workspace_floats", "hold_wgrad_group_workspace_floats", "hold_trunk_h3_pack_bytes",
-                       "hold_trunk_h3_act_scale", "hold_alive_blocks", "hold_chain_h3_pack_bytes"} == set(_lib.SIGNATURES)
+                       "hold_trunk_h3_act_scale", "hold_alive_blocks", "hold_chain_h3_pack_bytes", "hold_gemm_h3_pack_bytes"} == set(_lib.SIGNATURES)
     assert L.hold_abi_version() == 1
     assert not any(hasattr(L, n) for n in dev_only)
     # the product library reads no environment variables (stateless C ABI): no getenv import in the shared object

@@ -65,3 +65,35 @@ def test_pack_weights_matches_the_matrix_by_matrix_layouts(kind, mode, with_rend
                     assert t.stride(-1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0, k
     finally:
         hold_amd.set_precision(prev)
+
+
+@pytest.mark.parametrize("kind", ["hand", "object"])
+def test_pack_weights_f16x3_gemm_streams_match_the_matrix_by_matrix_packer(kind):
+    """mode f16x3: the hold_gemm_h3 streams of the rendering net and of lin8's feature rows (one segmented maximum + one gather
+    for all of them in pack_weights) == field.pack_gemm_h3 matrix by matrix, scales included; and pack_gemm_h3 is pack_gemm_r6's
+    stream (rows, k order: pinned to the lane model in tests/test_r6_pack_cpu.py) in two fp16 limbs of the scaled matrix"""
+    prev = hold_amd.precision()
+    hold_amd.set_precision("f16x3")
+    try:
+        spec, iw, ib, rw, rb = _weights(kind, 5)
+        pk = F.pack_weights(spec, iw, ib, rw, rb, True)
+        for name in ("R_h3", "RT_h3", "c3_R", "c3_RT", "w8_feat_h3", "c3_w8", "R_r6", "RT_r6", "w8_feat_r6"):
+            assert name in pk, name
+        ref8, c8 = F.pack_gemm_h3(pk["W8_feat"])
+        assert torch.equal(pk["w8_feat_h3"], ref8) and torch.equal(pk["c3_w8"], c8)
+        for l in range(4):
+            W = pk["R"][l][:, :spec.Kr if l == 0 else 256]
+            refl, cl = F.pack_gemm_h3(W)
+            assert torch.equal(pk["R_h3"][l], refl) and torch.equal(pk["c3_R"][l], cl), l
+            WT = pk["RT"][l] if l else pk["R"][0][:, :256].t().contiguous()
+            reft, ct = F.pack_gemm_h3(WT)
+            assert torch.equal(pk["RT_h3"][l], reft) and torch.equal(pk["c3_RT"][l], ct), ("T", l)
+            # two limbs of the scaled matrix, in pack_gemm_r6's order
+            KS = (W.shape[1] + 63) // 64 * 4
+            r6 = F.pack_gemm_r6(W).double().reshape(KS, 8, 3, 2, 32, 8).sum(2)
+            h3 = refl.double().reshape(KS, 8, 2, 2, 32, 8)
+            ws = r6 / float(cl)
+            assert float(ws.abs().max()) >= 2.0 ** 13 and float(ws.abs().max()) < 2.0 ** 14
+            assert torch.all((h3.sum(2) - ws).abs() <= ws.abs() * 2.0 ** -22 + 2.0 ** -25)
+    finally:
+        hold_amd.set_precision(prev)
