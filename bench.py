@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 matrix)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 matrix, same guide
 HBM_PEAK_GBPS = 8000.0  # HBM3E spec (6.3 TB/s achievable by a float4 copy), same guide
-ROUND = "r05"
+ROUND = "r06"
 
 
 def parse():
@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--precision", default=None, choices=["f32", "f32x6", "f16x3"],
                     help="arithmetic of the MFMA kernels (hold_amd/config.py); default: the package default")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--c2-alt", action="store_true",
+                    help="SURVEY 8(d)'s second reading of BASELINE's '64+64 samples': N_samples_eval=64 coarse + N_samples=64 fine, no extras "
+                         "(66 z per node instead of 128 -> 98) -- a secondary line")
     ap.add_argument("--op-sites", default=None, metavar="PATH",
                     help="diagnostic: count the non-view torch operators of ONE extra step by the hold_amd source line that "
                          "issued them (TorchDispatchMode; run after the timed steps) and write the table to PATH")
@@ -311,6 +314,8 @@ def main():
         from hold_amd import field as _fld
         _fld.COMPACT = False
     sampler_opt = dict(DEFAULT_SAMPLER, N_samples=128) if args.mode == "c5" else None
+    if args.c2_alt:
+        sampler_opt = dict(DEFAULT_SAMPLER, N_samples_eval=64, N_samples=64, N_samples_extra=0)
     net = hold_amd.build_from_scene(sc, sd_np, device=dev, sampler_opt=sampler_opt)
     for node in net.nodes.values():
         node.params.defrost()
@@ -550,11 +555,14 @@ def main():
                         "samples per fg node), eval forward only, frame stays on the device")
             metric = "rendered rays/sec (forward only, eval mode) at 1024x1024, 128 samples -- secondary metric (configs[4])"
         else:
-            workload = ("configs[1]: " + scene + f"1 frame {W}x{H} = {W * H} rays per GPU, 128-sample error-bound hierarchy -> "
-                        "64 importance + 2 + 32 extra samples per fg node, 32 bg samples, " +
+            workload = ("configs[1]: " + scene + f"1 frame {W}x{H} = {W * H} rays per GPU, " +
+                        ("SURVEY 8(d)'s ALTERNATIVE reading of '64+64': 64-sample error-bound hierarchy (N_samples_eval = 64) -> 64 "
+                         "importance + 2 samples per fg node (N_samples_extra = 0), 32 bg samples, " if args.c2_alt else
+                         "128-sample error-bound hierarchy -> 64 importance + 2 + 32 extra samples per fg node, 32 bg samples, ") +
                         ("fwd + " + ("full reference Loss (eikonal, MANO-cano SDF, opacity-sparsity targets on)" if loss_fn else
                                      "rgb/sem loss") + " + bwd + grad clip + Adam step" if training else "eval forward only"))
-            metric = ("rendered rays/sec (fwd+bwd) at 512x512, 64+64 samples" if training else
+            metric = ("rendered rays/sec (fwd+bwd) at 512x512, 64+64 samples read as N_samples_eval=64 + N_samples=64 -- secondary metric"
+                      if (training and args.c2_alt) else "rendered rays/sec (fwd+bwd) at 512x512, 64+64 samples" if training else
                       "rendered rays/sec (forward only, eval mode) -- secondary metric")
         res = {
             "metric": metric, "value": total_rays / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,

@@ -160,18 +160,22 @@ _H3_GUARD = {}
 
 
 def h3_guard(device):
-    """the overflow guard of the f16x3 trunk kernels (include/hold_hip.h): 4 device words per device, zeroed once -- [0] the
-    flag a launch sets when a scaled activation left fp16's range, [2] how many launches were recomputed in f32x6 because of it
-    (the conditional launch behind every f16x3 call; no host read on the path)"""
-    k = str(device)
-    if k not in _H3_GUARD:
-        _H3_GUARD[k] = torch.zeros(4, dtype=torch.int32, device=device)
-    return _H3_GUARD[k]
+    """the overflow guard of the f16x3 kernels (include/hold_hip.h): 4 device words per (device, STREAM) -- the protocol of the
+    conditional f32x6 launch assumes that the launches sharing a guard are ordered, i.e. on one stream -- zeroed once: [0] the flag a
+    launch sets when a scaled operand left fp16's range, [2] how many launches were recomputed in f32x6 because of it (the
+    conditional launch behind every f16x3 call; no host read on the path)"""
+    dev = torch.device(device)
+    k = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+    g = _H3_GUARD.get(k)
+    if g is None:
+        g = _H3_GUARD[k] = torch.zeros(4, dtype=torch.int32, device=dev)
+    return g
 
 
 def h3_overflow_count(device):
-    """launches of the f16x3 trunk kernels on `device` so far whose result came from the f32x6 fallback (one host read)"""
-    return int(h3_guard(device)[2]) if str(device) in _H3_GUARD else 0
+    """launches of the f16x3 kernels on `device` so far (all streams) whose result came from the f32x6 fallback (host reads)"""
+    d = str(torch.device(device))
+    return sum(int(g[2]) for (kd, _), g in _H3_GUARD.items() if kd == d)
 
 
 def fused_sdf_h3(xc, P, wpack_h3, bias8_scaled, c3, w8, b8, barf_w, out_sdf, wpack_r6=None, bias8=None):

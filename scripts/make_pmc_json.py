@@ -3,8 +3,8 @@ Unit / correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both
 reports half of wide coalesced reads, so read bytes = 2 * FETCH_SIZE * 1024."""
 import json, os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "prof_r05")
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r05"
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "prof_r06")
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r06"
 F = json.load(open(os.path.join(src, "FETCH_SIZE.json")))
 W = json.load(open(os.path.join(src, "WRITE_SIZE.json")))
 # bench.py's kernel families -> rocprof kernel names (rmlp_kernel is both the sampler query <HEAD> and the forward trunk
@@ -19,6 +19,11 @@ groups = {"fused_sdf_kernel": ["rmlp_h3_kernel<true,false,0>", "rmlp_kernel<true
           "rchain_a2_kernel": ["rsweep_kernel<1,true,1,0,217>", "rsweep_kernel<1,true,1>"],
           "rchain_dbwd_kernel": ["rsweep_kernel<2,true,1,0,217>", "rsweep_kernel<2,true,1>"],
           "rgemm_kernel": ["rgemm_kernel<0>", "rgemm_kernel<1>", "rgemm_kernel<2>"],
+          # round 6: the sweeps and the single-layer GEMM in two fp16 limbs (rsweep_h3_kernel<MODE, A2, DIST, ABL, SKIP_OUT>)
+          "rchain_h3_kernel": ["rsweep_h3_kernel<1,false,3,0,217>", "rsweep_h3_kernel<1,false,1,0,217>"],
+          "rchain_a2_h3_kernel": ["rsweep_h3_kernel<1,true,3,0,217>", "rsweep_h3_kernel<1,true,1,0,217>"],
+          "rchain_dbwd_h3_kernel": ["rsweep_h3_kernel<2,true,1,0,217>", "rsweep_h3_kernel<2,true,3,0,217>"],
+          "rgemm_h3_kernel": ["rgemm_h3_kernel<0>", "rgemm_h3_kernel<1>", "rgemm_h3_kernel<2>"],
           "chain_kernel": ["chain_x6_kernel<1,true,16>", "chain_x6_kernel<2,true,3>", "chain_x6_kernel<1,false,16>",
                            "chain_x6_kernel<0,false,3>", "chain_kernel"],
           "sampler_beta_kernel": ["sampler_beta_kernel"], "sampler_sample_kernel": ["sampler_sample_kernel"],
@@ -36,6 +41,10 @@ notes = {
     "rchain_a2_kernel": "first-order backward sweep: 1 KiB in (chain input) + per layer 2 KiB side in (h, a2), 1 KiB out, 7 layers",
     "rchain_dbwd_kernel": "second-order ascending sweep: 160 B in + per layer 2 KiB side in (h, t), 2 KiB out (vbar, a2), 8 layers",
     "rgemm_kernel": "rendering-net layers / dgrad / lin8 features: 4 (K + 256) B per point (+ 1 KiB mask operand)",
+    "rgemm_h3_kernel": "rendering-net layers / dgrad / lin8 features in two fp16 limbs: 4 (K + 256) B per point (+ 1 KiB mask operand) + 8 B of row maxima",
+    "rchain_h3_kernel": "descending sweep of the normal path (two fp16 limbs): 1 KiB in (chain input) + per layer 1 KiB side in, 1 KiB out, 7 layers",
+    "rchain_a2_h3_kernel": "first-order backward sweep (two fp16 limbs): 1 KiB in + per layer 2 KiB side in (h, a2), 1 KiB out, 7 layers",
+    "rchain_dbwd_h3_kernel": "second-order ascending sweep (two fp16 limbs): 160 B in + per layer 2 KiB side in (h, t), 2 KiB out (vbar, a2), 8 layers",
     "gemm_nt_kernel": "per-layer GEMMs (rendering net fwd+bwd, lin8 features, d/d embedding, background): (K + N) * 4 B per "
                       "point (+ N * 4 B per aux operand of the MUL_DSP / DRELU epilogues)",
     "rnarrow_kernel": "the N <= 64 layers (N = 39 / 16 / 48): 1 KiB in per point (A once) + 4 N B out (+ 4 N B in when accumulating)",
@@ -44,7 +53,7 @@ notes = {
     "wgrad_kernel": "dW[N,K] = R^T X over P = 1.61 M points: (N + K) * 4 B per point = 2 KiB (3.3 GB) for the 256x256 layers; "
                     "split-K partials (<= 256 x 256 KiB) are written here and reduced by wgrad_reduce4_kernel"}
 out = {"command": "rocprofv3 --kernel-trace --pmc <C> -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile "
-                  "(one pass per counter; scripts/lease_logs/r5_call14.sh), chunk 16384 rays, default precision (f16x3: the forward trunk kernels and the whole-dW weight gradients in the two-limb fp16 arithmetic, everything else f32x6)",
+                  "(one pass per counter; scripts/lease_logs/r6_call11.sh), chunk 16384 rays, default precision (f16x3: trunk, sampler queries, backward sweeps, single-layer GEMMs and whole-dW weight gradients in the two-limb fp16 arithmetic; gemm_nt / rnarrow / tile weight gradients / the background sweep f32x6)",
        "correction": "gfx950 FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md HBM section): read bytes = "
                      "2*FETCH_SIZE*1024; WRITE_SIZE taken as KiB", "kernels": {}}
 for g, names in groups.items():
