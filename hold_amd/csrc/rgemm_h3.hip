@@ -8,8 +8,8 @@
 // operand is a ROW of A per point -- an activation of O(1) in the forward layers, a loss cotangent of any magnitude in the input-
 // gradient launches -- and an MFMA column is a point, so every point carries its own power-of-two scale 2^k (csrc/rchain_h3.hip).
 // Here the row's magnitude is KNOWN before its first k step: the launch that produced A reports the exact maximum of every row it
-// wrote (amax_out, 4 bytes per point, from the values in its epilogue registers), and this launch reads it (amax_in; the next
-// block's 32 values per wave travel by LDS-DMA one block ahead) -- max(amax_in, amax_floor) goes to [2^12, 2^13): 2^3 of headroom
+// wrote (amax_out, 4 bytes per point, from the values in its epilogue registers), and this launch reads it (amax_in; a lane loads
+// its next block's value a whole block ahead) -- max(amax_in, amax_floor) goes to [2^12, 2^13): 2^3 of headroom
 // for the columns of A the producer did not write (the rendering net's first layer reads [features | xc | normal | pose | time]:
 // amax_in covers the features, amax_floor the rest).  Without amax_in the scale is the constant one of amax_floor (lin8's input, the
 // trunk's last softplus output: amax_floor = 64 is the 2^6 of rmlp_h3.hip).  OVERFLOW GUARD as in rmlp_h3.hip: exact running maximum
@@ -89,17 +89,6 @@ __device__ __forceinline__ int row_scale(float m) {
   k = k > 96 ? 96 : (k < -96 ? -96 : k);
   return (e != 0 && e != 255) ? k : 0;
 }
-// 4-byte-per-lane LDS-DMA (lane L -> LDS byte dst + 4 L)
-__device__ __forceinline__ void dma_dword(const char* src, uint32_t voff, uint32_t dst) {
-  asm volatile(
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dword %0, %1"
-      :
-      : "v"(voff), "s"(src), "s"(dst)
-      : "memory");
-}
-
 __device__ __forceinline__ void dma_piece(const char* src, uint32_t voff, uint32_t dst) {
   asm volatile(
       "s_mov_b32 m0, %2\n\t"
@@ -117,10 +106,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int SIDE_SLOT = NSIDE * 2 * PIECE;
   constexpr int OFF_SIDE = R3 * SLOT;
   constexpr int OFF_BIAS = OFF_SIDE + NW * SIDE_RING * SIDE_SLOT;
-  constexpr int OFF_AMAX = OFF_BIAS + 1024;  // [4 waves][2 slots][64 lanes] fp32: the row maxima of the running / the next block
   // VMEM operations that may stay in flight at a rendezvous (rgemm.hip's accounting with four weight pieces per wave and step):
   // the previous rendezvous' four weight pieces and side requests, three stores.  The true number of operations younger than the
-  // weights a rendezvous needs is 8 + 4 NSIDE (rgemm.hip), so the two extra operations of a block -- the DMA of the next block's
+  // weights a rendezvous needs is 8 + 4 NSIDE (rgemm.hip), so the two extra operations of a block -- the load of the next block's
   // row maxima and the store of the finished block's -- stay inside the slack
   constexpr int NWAIT = 4 + 2 * NSIDE + 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -141,9 +129,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // omx = running maximum of the finished block's outputs (amax_out)
   int kB = 0;
   float sB = 1.f, yscP = 0.f, mx = 0.f, omx = 0.f;
-  const uint32_t amax_dst0 = (uint32_t)(OFF_AMAX + wave * 512);
-  const float* amax_rd = reinterpret_cast<const float*>(smem + OFF_AMAX + wave * 512) + lane;
-  const char* AMb = reinterpret_cast<const char*>(a.amax_in);
+  const float* AMb = a.amax_in;
 
   f32x16 P[8], Q[8];
 #pragma unroll
@@ -186,9 +172,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   uint32_t in_off_next = (uint32_t)((clamp_row(blk + gridDim.x) * a.lda + 4 * hh) * 4);
   uint32_t ax_off_prev = (uint32_t)((clamp_row(blk) * (long)a.ld_aux + 4 * hh) * 4);  // mask rows of the block held in P
   uint32_t ax_off_cur = ax_off_prev;
-  uint32_t am_off = (uint32_t)(clamp_row(blk) * 4), am_off_next = (uint32_t)(clamp_row(blk + gridDim.x) * 4);  // (lane li's row; both halves)
+  // this lane's row maximum of the running block, and -- loaded a whole block ahead, so that no load latency is exposed: the
+  // compiler's wait for it counts only the stores it knows about, which is conservative in an in-order queue -- of the next one
+  float am_cur = AMb ? AMb[clamp_row(blk)] : 0.f;
+  float am_next = 0.f;
   long row_P = -1;  // first row of this wave's share of the block held in P (none yet)
-  int bi = 0;       // blocks this workgroup has started (parity = the row maxima's LDS slot)
   const char* Ab = reinterpret_cast<const char*>(a.A);
   const char* Xb = reinterpret_cast<const char*>(a.aux);
   const char* wbase = a.wpack;
@@ -199,7 +187,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       dma_piece(a.wpack + (long)s0 * SLOT + wave * (4 * PIECE) + i * PIECE, lane16, (uint32_t)(s0 * SLOT + wave * (4 * PIECE) + i * PIECE));
-  if (AMb) dma_dword(AMb, am_off, amax_dst0);  // the first block's row maxima -> slot 0
 #pragma unroll
   for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -350,13 +337,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) asm volatile("" : "+a"(P[nt][r]));  // the finished block lives in the AGPR half
-    // the scale of this block's rows: their maximum (landed in slot bi & 1 a block ago) or the floor, at [2^12, 2^13); the next
-    // block's maxima are requested into the other slot
+    // the scale of this block's rows: their maximum (loaded a block ago) or the floor, at [2^12, 2^13); the next block's maximum is
+    // requested now
     {
       float m = a.amax_floor;
       if (AMb) {
-        m = fmaxf(m, amax_rd[(bi & 1) * 64]);
-        dma_dword(AMb, am_off_next, amax_dst0 + (uint32_t)(((bi + 1) & 1) * 256));
+        m = fmaxf(m, am_cur);
+        am_next = AMb[clamp_row(blk + gridDim.x)];
       }
       kB = row_scale(m);
       sB = pow2f(kB);
@@ -391,8 +378,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int nt = 0; nt < 8; ++nt) P[nt] = Q[nt];
     yscP = c3 * pow2f(-kB);
     row_P = blk * BPTS + wave * 32;
-    ++bi;
-    am_off_next = (uint32_t)(clamp_row(blk + 2 * (long)gridDim.x) * 4);
+    am_cur = am_next;
     const long row = blk * BPTS + wave * 32 + li;  // unclamped: the buffer range check drops rows >= P
     crs = make_rsrc(a.C, cbytes);
     cvoff = (uint32_t)((row * a.ldc + 4 * hh) * 4);
@@ -438,7 +424,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 template <int EPI>
 int launch_h3(const RGArgs& a, hipStream_t s) {
   constexpr int NSIDE = EPI == EPI_MASK ? 2 : 1;
-  constexpr int lds = R3 * SLOT + NW * SIDE_RING * NSIDE * 2 * PIECE + 1024 + NW * 512;
+  constexpr int lds = R3 * SLOT + NW * SIDE_RING * NSIDE * 2 * PIECE + 1024;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static int n_cu = 0;
   static bool attr_set = false;

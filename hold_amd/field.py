@@ -464,7 +464,11 @@ def _pack_render(pk, spec, rw, rb, need_bwd, dev):
             pk["RT_r6"] = [packs[7]] + list(packs[4:7])
         if config.h3():  # hold_gemm_h3 streams of the same matrices: per-matrix scales (one segmented maximum), two fp16 limbs
             flat = torch.cat(mats)
-            amax = torch.zeros(plan["nm"], device=dev).scatter_reduce_(0, plan["seg"], flat.abs(), "amax")
+            # (the segments are contiguous: r0's 256 x 320 block, then 65 536 elements per matrix -- two plain reductions; a
+            # scatter_reduce_("amax") over 600 k elements into 8 bins is 600 k contended float atomics: 17 ms per node and step,
+            # which doubled the reference's 1 280-ray step until GPU call 12 of round 6 found it)
+            n0_ = 256 * 320
+            amax = torch.cat([flat[:n0_].abs().amax().view(1), flat[n0_:].view(-1, 65536).abs().amax(1)])
             _, ex = torch.frexp(amax)
             sw = torch.ldexp(torch.ones_like(amax), 14 - ex)
             limbs_h = torch.stack(split_limbs_h(flat * sw[plan["seg"]])).reshape(-1)

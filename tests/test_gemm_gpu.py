@@ -549,6 +549,47 @@ def test_gemm_h3_matches_fp64_and_chains_its_row_maxima(P, K, lda, ldc, epi, row
     assert torch.equal(amax_out[:P], out[:, :256].abs().amax(1)) and float((amax_out[P:] + 3.0).abs().max()) == 0.0
 
 
+def test_gemm_h3_is_bit_reproducible_whatever_ran_before():
+    """GPU call 11 of round 6: rendering one frame twice gave different bits (test_full_frame_512_invariants) -- results within
+    tolerance, i.e. some launch had picked another power-of-two row scale.  The scale of a row must depend on amax_in / amax_floor
+    alone: the same call repeated with other kernels (NaN-filled LDS rings, other row maxima) in between must return the same bits,
+    for a chain of launches as the rendering net issues it (row maxima travelling from launch to launch)."""
+    import hold_amd
+    from hold_amd import field as F, gemm
+    dev = _dev()
+    P = 128 * 256 * 3 + 77  # three blocks per workgroup and a ragged tail
+    torch.manual_seed(5)
+    A = torch.randn(P, 304, device=dev) * (10.0 ** (torch.rand(P, 1, device=dev) * 6 - 3))
+    Ws = [torch.randn(256, 304, device=dev) / 16] + [torch.randn(256, 256, device=dev) / 16 for _ in range(2)]
+    packs = [(F.pack_gemm_h3(W), F.pack_gemm_r6(W)) for W in Ws]
+    b = torch.randn(256, device=dev)
+
+    def chain():
+        am = [torch.empty(P, device=dev) for _ in range(3)]
+        o = [torch.empty(P, 256, device=dev) for _ in range(3)]
+        am_in = A[:, :256].abs().amax(1).contiguous()
+        gemm.gemm_h3(A, packs[0][0][0], packs[0][0][1], o[0], K=304, wpack_r6=packs[0][1], bias=b, epi=gemm.R6_RELU, amax_in=am_in,
+                     amax_floor=float(A[:, 256:].abs().max()), amax_out=am[0])
+        gemm.gemm_h3(o[0], packs[1][0][0], packs[1][0][1], o[1], K=256, wpack_r6=packs[1][1], bias=b, epi=gemm.R6_RELU, amax_in=am[0], amax_out=am[1])
+        gemm.gemm_h3(o[1], packs[2][0][0], packs[2][0][1], o[2], K=256, wpack_r6=packs[2][1], epi=gemm.R6_MASK, aux=o[0], amax_in=am[1], amax_out=am[2])
+        torch.cuda.synchronize()
+        return o + am
+
+    ref = chain()
+    prev = hold_amd.precision()
+    hold_amd.set_precision("f32x6")
+    try:
+        for fill in (float("nan"), 1e30, 0.0):
+            R = torch.full((16 * 4096, 256), fill, device=dev)
+            gemm.wgrad(R, R, torch.empty(256, 256, device=dev), None)  # 256 workgroups x a 128 KiB LDS ring of `fill`
+            junk = torch.empty(P, 256, device=dev)
+            gemm.gemm_h3(A * 1e3, packs[0][0][0], packs[0][0][1], junk, K=304, wpack_r6=packs[0][1], amax_floor=1e7)  # other scales in flight
+            for x, y in zip(chain(), ref):
+                assert torch.equal(x, y)
+    finally:
+        hold_amd.set_precision(prev)
+
+
 def test_gemm_h3_overflow_falls_back_to_r6_with_its_row_maxima():
     """rows beyond 2^3 x the bound the caller gave (here: no amax_in, floor 64, a few rows of 1e4) leave fp16's range: the guard
     fires, the conditional hold_gemm_r6_if launch recomputes C AND amax_out, bit-identical to hold_gemm_r6, and counts the event"""
