@@ -201,7 +201,18 @@ def cpu_baseline(sc, sd_np, threads=32, repeats=3, n_frames=1):
     times = [t + t_geo[0] for t in t_net]
     med = float(np.median(times))
     repeats = len(times)
+    # the reference ITSELF cannot run here (a Python reference does not travel to the GPU box): its own training step -- HOLD.training_step
+    # with its HOLDNet and Loss, backward, clip, its Adam, 10 frames x 128 rays, no loss-target geometry (steps < 200) -- was timed in
+    # the build container (scripts/time_reference_cpu.py) and is QUOTED from the committed record, labelled as what it is
+    ref_rec = None
+    try:
+        ref_rec = json.load(open(os.path.join(ROOT, "profiles", "r06_reference_cpu_step.json")))
+        ref_rec["note"] = ("NOT measured on this box: the reference's own training step timed on the build container's CPU cores "
+                           "(scripts/time_reference_cpu.py); compare with network_only_rays_per_s, the port's step without the geometry")
+    except Exception:
+        pass
     return {"value": N / med, "unit": "rays/s", "cores": cores, "kind": "port",
+            "reference_timed_in_build_container": ref_rec,
             "repeats": repeats, "step_s": {"median": med, "min": float(min(times)), "max": float(max(times)),
                                            "spread": float((max(times) - min(times)) / med), "all": [round(t, 3) for t in times]},
             "network_only_rays_per_s": N / float(np.median(t_net)),
@@ -569,11 +580,14 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if (args.split == "rays" and world > 1 and args.mode != "c3") else "weak",
             "vs_baseline": None,
-            "dtype": ("f16x3+f32x6 (fp32 results, fp32 accumulation everywhere; the forward trunk kernels -- sampler SDF queries and the "
-                      "training forward trunk -- split both fp32 operands, scaled by exact powers of two, into two fp16 limbs hi = "
-                      "RN(x), lo = RN(x - hi) and issue hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (3 MFMAs per product, error vs "
-                      "fp64 <= that of f32x6: tests/test_rmlp_gpu.py); every other MFMA kernel is f32x6; --precision f32x6 / "
-                      "--fp32-mfma select the other arithmetics)" if h3 else
+            "dtype": ("f16x3+f32x6 (fp32 results, fp32 accumulation everywhere; the trunk kernels (sampler SDF queries, training forward trunk), the "
+                      "three backward sweeps, the single-layer GEMMs of the rendering net and the whole-dW weight gradients split both fp32 "
+                      "operands, scaled by exact powers of two -- per matrix for weights, per point / per row / per workgroup for activations and "
+                      "loss cotangents -- into two fp16 limbs hi = RN(x), lo = RN(x - hi) and issue hi*hi + hi*lo + lo*hi on "
+                      "v_mfma_f32_32x32x16_f16 (3 MFMAs per product, error vs fp64 <= that of f32x6: tests/test_rmlp_gpu.py, test_chain_gpu.py, "
+                      "test_gemm_gpu.py; a launch whose scaled operand leaves fp16's range is recomputed in f32x6 by a conditional launch on the "
+                      "device: config.f16x3_launches_recomputed_in_f32x6_per_step); gemm_nt, rnarrow, the tile weight gradients and the background's "
+                      "sweep are f32x6; --precision f32x6 / --fp32-mfma select the other arithmetics)" if h3 else
                       "f32x6 (fp32 results; every MFMA product = exact 3-limb bf16 split of both fp32 operands, 6 of 9 limb "
                       "products on v_mfma_f32_32x32x16_bf16, fp32 accumulate; --fp32-mfma for true-fp32 operands)"
                       if x6 else "f32"),
