@@ -552,7 +552,7 @@ def main():
         # kernel families that run the two-limb fp16 arithmetic in mode f16x3 (3 limb products issued per algorithmic product on
         # v_mfma_f32_32x32x16_f16, same dense peak as bf16); every other split-precision family issues 6 bf16 limb products
         from hold_amd import field as _field
-        h3_fams = ({"fused_sdf_kernel", "wgrad_h3_kernel", "rchain_h3_kernel", "rchain_a2_h3_kernel", "rchain_dbwd_h3_kernel", "rgemm_h3_kernel"} |
+        h3_fams = ({"fused_sdf_kernel", "wgrad_h3_kernel", "rchain_h3_kernel", "rchain_a2_h3_kernel", "rchain_dbwd_h3_kernel", "rchain_bg_h3_kernel", "rgemm_h3_kernel"} |
                    ({"trunk_r6_kernel"} if _field.USE_H3_TRUNK else set())) if h3 else set()
         scene = ("configs[3]-like ARCTIC two-hand (right+left+object+background), " if args.two_hands else
                  "hold_bottle1_itw-like single-hand (right+object+background), ")
@@ -633,7 +633,7 @@ def main():
                 json.dump(gemm_shapes(prof), open(args.shape_report, "w"), indent=1)
             split = {"fused_sdf_kernel", "wgrad_kernel", "wgrad_h3_kernel", "chain_kernel", "gemm_nt_kernel", "trunk_r6_kernel", "rchain_kernel",
                      "rchain_bg_kernel", "rchain_a2_kernel", "rchain_dbwd_kernel", "rgemm_kernel", "rnarrow_kernel",
-                     "rchain_h3_kernel", "rchain_a2_h3_kernel", "rchain_dbwd_h3_kernel", "rgemm_h3_kernel"} if x6 else set()
+                     "rchain_h3_kernel", "rchain_a2_h3_kernel", "rchain_dbwd_h3_kernel", "rchain_bg_h3_kernel", "rgemm_h3_kernel"} if x6 else set()
             labels = {"gemm_nt_kernel": ("gemm_nt_kernel<x6> (one layer per launch, 3-limb split on v_mfma_f32_32x32x16_bf16)"
                                          if x6 else "gemm_nt_kernel (one layer per launch, v_mfma_f32_32x32x2_f32)"),
                       "trunk_r6_kernel": ("rmlp_h3_kernel<STORE> (forward trunk, 8 layers per launch, register-resident, two fp16 limbs, "
@@ -659,6 +659,7 @@ def main():
                                             "v_mfma_f32_32x32x16_bf16)",
                       "rchain_h3_kernel": "rsweep_h3_kernel<DSP> (descending sweep of the normal path, 7 layers per launch, register-resident, "
                                           "two fp16 limbs / three products on v_mfma_f32_32x32x16_f16, per-point operand scales)",
+                      "rchain_bg_h3_kernel": "rsweep_h3_kernel<DSP, skip 172> (the background net's first-order backward sweep, two fp16 limbs)",
                       "rchain_a2_h3_kernel": "rsweep_h3_kernel<DSP+a2> (first-order backward sweep, 7 layers per launch, register-resident, "
                                              "two side inputs as whole lines through LDS, two fp16 limbs, per-point operand scales)",
                       "rchain_dbwd_h3_kernel": "rsweep_h3_kernel<DBWD> (second-order ascending sweep, 8 layers per launch, register-resident, "
@@ -732,7 +733,8 @@ def main():
             # together: time-weighted, i.e. total FLOP, total bytes, total time, per average launch.
             template_of = {"rchain_kernel": "rsweep_kernel", "rchain_a2_kernel": "rsweep_kernel", "rchain_dbwd_kernel": "rsweep_kernel",
                            "rchain_bg_kernel": "rsweep_kernel", "rchain_h3_kernel": "rsweep_h3_kernel",
-                           "rchain_a2_h3_kernel": "rsweep_h3_kernel", "rchain_dbwd_h3_kernel": "rsweep_h3_kernel"}
+                           "rchain_a2_h3_kernel": "rsweep_h3_kernel", "rchain_dbwd_h3_kernel": "rsweep_h3_kernel",
+                           "rchain_bg_h3_kernel": "rsweep_h3_kernel"}
             tmpl = {}
             for name in agg:
                 tmpl.setdefault(template_of.get(name, name), []).append(name)

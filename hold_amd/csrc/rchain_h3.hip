@@ -659,7 +659,7 @@ static int rsweep_h3_launch(const RCArgs& a, hipStream_t s) {
 }
 
 // The descriptor and semantics of hold_chain_r6 (csrc/rchain.hip) in the f16x3 arithmetic:
-//   mode DSP  (7 layers, first_chunks 32, skip_layer 3, every out[] optional, aux2 optional; skip_out 217 only):
+//   mode DSP  (7 layers, first_chunks 32, skip_layer 3, every out[] optional, aux2 optional; skip_out 217, or 172 without aux2):
 //              d->wpack = hold_chain_h3_pack_bytes() bytes of fp16, [7 x 16 k steps][8 nt][2 limbs][2 h][32 i][8 e], the k order
 //              of hold_trunk_h3, limb_t of s_w[j] M_j;
 //   mode DBWD (8 layers, first_chunks 5, ...): d->wpack = the stream of hold_trunk_h3 (hold_trunk_h3_pack_bytes() bytes).
@@ -671,7 +671,8 @@ extern "C" int hold_chain_h3(const hold_chain_desc* dp, const float* c3, uint32_
   if (!dp || !c3) return HOLD_E_ARG;
   const hold_chain_desc& d = *dp;
   if (d.P < 0 || !d.in || !d.wpack || d.skip_layer != 3) return HOLD_E_ARG;
-  if (d.skip_out != 0 && d.skip_out != 217) return HOLD_E_ARG;
+  const int so = d.skip_out ? d.skip_out : 217;
+  if (so != 217 && so != 172) return HOLD_E_ARG;  // 172: the background net's skip width (DSP without a2 only, as hold_chain_r6)
   if (((uintptr_t)guard & 3) || (wpack_r6 && !guard)) return HOLD_E_ARG;
   const bool db = d.mode == HOLD_CHAIN_DBWD;
   if (d.mode != HOLD_CHAIN_DSP && !db) return HOLD_E_ARG;
@@ -705,7 +706,10 @@ extern "C" int hold_chain_h3(const hold_chain_desc* dp, const float* c3, uint32_
 #ifdef HOLD_DEV
   if (const char* v = getenv("HOLD_H3C_DIST")) dist = atoi(v);
 #endif
-  if (dist == 3) {
+  if (so == 172) {
+    if (db || has2) return HOLD_E_ARG;
+    rc = rsweep_h3_launch<RC_DSP, false, 3, 172>(a, s);
+  } else if (dist == 3) {
     if (db) rc = rsweep_h3_launch<RC_DBWD, true, 3>(a, s);
     else if (has2) rc = rsweep_h3_launch<RC_DSP, true, 3>(a, s);
     else rc = rsweep_h3_launch<RC_DSP, false, 3>(a, s);

@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int i = 0; i < 6; ++i) A[0][i] = *reinterpret_cast<const u32x4*>(ring_lane + i * PIECE);
   rsrc_t crs = make_rsrc(nullptr, 0);  // stores of the block held in P (none before the first block is finished)
+  const rsrc_t nullrs = make_rsrc(nullptr, 0);
   uint32_t cvoff = 0;
 
   // Preparation of k step / epilogue unit e (side slot e & 3), four stages of micro-operations:
@@ -209,10 +210,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     } else {
       const int h2 = stage - 2;
       if (k == 22) {
-        if (unit) {
-          const f32x4 v = {st.y[4 * h2], st.y[4 * h2 + 1], st.y[4 * h2 + 2], st.y[4 * h2 + 3]};
-          store4(v, crs, cvoff + (16 * e + 8 * h2) * 4);
-        }
+        // EVERY k step issues its two stores: the rendezvous' vmcnt(NWAIT) counts on the queue's shape -- the k steps without an
+        // epilogue unit (e >= 16: the last step of a block, and the four extra steps of K = 272 / 304) used to issue none, and with
+        // 8 instead of 12 operations behind the weight pieces it waits for, vmcnt(NWAIT) no longer forced them: in 3 of 3 000
+        // launches with K = 304 a workgroup read a ring slot before its pieces had landed (round 6, GPU call 16: the same latent
+        // race was in csrc/rgemm.hip since round 3).  Without a unit the store goes to a zero-length descriptor: dropped, counted.
+        const f32x4 v = {st.y[4 * h2], st.y[4 * h2 + 1], st.y[4 * h2 + 2], st.y[4 * h2 + 3]};
+        store4(v, unit ? crs : nullrs, unit ? cvoff + (16 * e + 8 * h2) * 4 : 0u);
         return;
       }
       const int d = k & 1, op = k >> 1;

@@ -172,10 +172,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   uint32_t in_off_next = (uint32_t)((clamp_row(blk + gridDim.x) * a.lda + 4 * hh) * 4);
   uint32_t ax_off_prev = (uint32_t)((clamp_row(blk) * (long)a.ld_aux + 4 * hh) * 4);  // mask rows of the block held in P
   uint32_t ax_off_cur = ax_off_prev;
-  // this lane's row maximum of the running block, and -- loaded a whole block ahead, so that no load latency is exposed: the
-  // compiler's wait for it counts only the stores it knows about, which is conservative in an in-order queue -- of the next one
+  // this lane's row maximum of the running block, and -- requested a whole block ahead -- of the next one.  The request is an
+  // assembler load straight into an ACCUMULATOR register: a load the compiler knows about made it put s_waitcnt vmcnt(0) behind
+  // the request (it cannot count the LDS-DMA pieces in the queue, so it drains it -- once per block, with the load's own HBM
+  // latency exposed); the value is read a block later, when the in-order queue has retired it long ago (>= 128 younger
+  // operations, every rendezvous leaves at most NWAIT of them in flight).  An earlier version moved the 32 values per wave by a
+  // 4-byte LDS-DMA: results within tolerance but not bit-reproducible (the row scales depended on stale LDS) -- GPU call 11.
   float am_cur = AMb ? AMb[clamp_row(blk)] : 0.f;
   float am_next = 0.f;
+  auto request_amax = [&](long b) {
+    const float* ptr = AMb + clamp_row(b);
+    asm volatile("global_load_dword %0, %1, off" : "=a"(am_next) : "v"(ptr) : "memory");
+  };
   long row_P = -1;  // first row of this wave's share of the block held in P (none yet)
   const char* Ab = reinterpret_cast<const char*>(a.A);
   const char* Xb = reinterpret_cast<const char*>(a.aux);
@@ -199,6 +207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int i = 0; i < 4; ++i) A[0][i] = *reinterpret_cast<const u32x4*>(ring_lane + i * PIECE);
   rsrc_t crs = make_rsrc(nullptr, 0);  // stores of the block held in P (none before the first block is finished)
+  const rsrc_t nullrs = make_rsrc(nullptr, 0);
   uint32_t cvoff = 0;
 
   // Preparation of k step / epilogue unit e (side slot e & 3), four stages of micro-operations:
@@ -246,10 +255,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     } else {
       const int h2 = stage - 2;
       if (k == 12) {
-        if (unit) {
-          const f32x4 v = {st.y[4 * h2], st.y[4 * h2 + 1], st.y[4 * h2 + 2], st.y[4 * h2 + 3]};
-          store4(v, crs, cvoff + (16 * e + 8 * h2) * 4);
-        }
+        // EVERY k step issues its two stores: the rendezvous' vmcnt(NWAIT) counts on the queue's shape -- the k steps without an
+        // epilogue unit (e >= 16: the last step of a block, and the four extra steps of K = 272 / 304) used to issue none, and with
+        // 8 instead of 12 operations behind the weight pieces it waits for, vmcnt(NWAIT) no longer forced them: in 3 of 3 000
+        // launches with K = 304 a workgroup read a ring slot before its pieces had landed (round 6, GPU call 16: the same latent
+        // race was in csrc/rgemm.hip since round 3).  Without a unit the store goes to a zero-length descriptor: dropped, counted.
+        const f32x4 v = {st.y[4 * h2], st.y[4 * h2 + 1], st.y[4 * h2 + 2], st.y[4 * h2 + 3]};
+        store4(v, unit ? crs : nullrs, unit ? cvoff + (16 * e + 8 * h2) * 4 : 0u);
         return;
       }
       const int d = k & 1, op = k >> 1;
@@ -343,7 +355,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       float m = a.amax_floor;
       if (AMb) {
         m = fmaxf(m, am_cur);
-        am_next = AMb[clamp_row(blk + gridDim.x)];
+        request_amax(blk + gridDim.x);
       }
       kB = row_scale(m);
       sB = pow2f(kB);

@@ -925,11 +925,16 @@ class Background(nn.Module):
             wkey = _pack_key([self.bg_implicit_network], True)
             if getattr(self, "_wr6_cache", (None, None))[0] != wkey:
                 stacked = torch.stack([F.pad(W[l], (0, 0, 0, 256 - W[l].shape[0])) for l in range(1, 8)])
-                self._wr6_cache = (wkey, _field.pack_r6_stack(stacked.transpose(1, 2).flip(0).contiguous()))  # layer j = W_{7-j}^T
+                MT = stacked.transpose(1, 2).flip(0).contiguous()  # layer j = W_{7-j}^T
+                h3 = None
+                if config.h3() and _field.USE_H3_BWD:  # the same sweep in two fp16 limbs (hold_chain_h3, skip width 172)
+                    pk3, sw3 = _field.pack_h3_stack(MT)
+                    h3 = dict(wpack_h3=pk3, c3=(1.0 / sw3).contiguous())
+                self._wr6_cache = (wkey, _field.pack_r6_stack(MT), h3)
             wr6 = self._wr6_cache[1]
             r = [pool.get(f"rs{l}", P, 256) for l in range(7)] + [cur]
             K.chain(K.CHAIN_DSP, P, cur, None, 7, 32, skip_layer=3, aux1=[h[l - 1] for l in range(7, 0, -1)],
-                    out=[r[l - 1] for l in range(7, 0, -1)], wpack_r6=wr6, skip_out=so)
+                    out=[r[l - 1] for l in range(7, 0, -1)], wpack_r6=wr6, skip_out=so, **(self._wr6_cache[2] or {}))
             grp = G.WgradGroup() if _field.USE_WGRAD_GROUP else None  # every r_l has a buffer of its own: one launch for the 7
             wg = G.wgrad if grp is None else grp.add
             for l in range(7, 0, -1):

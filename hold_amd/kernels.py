@@ -258,7 +258,8 @@ def chain(mode, P, x_in, wpack, n_layers, first_chunks, skip_layer=-1, side=None
     # ... and in the two-limb fp16 arithmetic (hold_chain_h3, csrc/rchain_h3.hip): wpack_h3 = field's chain_bwd_h3 (DSP) / the
     # stream of hold_trunk_h3 (DBWD), c3 = 1 / s_w of the chain layers; wpack_r6 stays the operand of the conditional f32x6
     # fallback the entry point enqueues behind the kernel (the overflow guard of kernels.h3_guard)
-    h3 = wpack_h3 is not None and wpack_r6 is not None and mode in (CHAIN_DSP, CHAIN_DBWD) and skip_out in (0, 217)
+    h3 = (wpack_h3 is not None and wpack_r6 is not None and mode in (CHAIN_DSP, CHAIN_DBWD) and
+          (skip_out in (0, 217) or (skip_out == 172 and mode == CHAIN_DSP and aux2 is None)))
     if h3:
         want = _lib.lib().hold_chain_h3_pack_bytes() if mode == CHAIN_DSP else _lib.lib().hold_trunk_h3_pack_bytes()
         assert wpack_h3.numel() * wpack_h3.element_size() == want and wpack_h3.dtype == torch.float16
@@ -303,7 +304,7 @@ def chain(mode, P, x_in, wpack, n_layers, first_chunks, skip_layer=-1, side=None
         n_mats = sum(sum(t is not None for t in lst) for lst in (aux1, aux2, out, out2) if lst is not None)
         _g._prof_end(e0, 2.0 * (r1 - r0) * 256 * (8 * first_chunks + 256 * (n_layers - 1)),
                      (("rchain_dbwd_h3_kernel" if mode == CHAIN_DBWD else "rchain_a2_h3_kernel" if aux2 is not None else
-                       "rchain_h3_kernel") if h3 else
+                       "rchain_bg_h3_kernel" if skip_out == 172 else "rchain_h3_kernel") if h3 else
                       ("rchain_dbwd_kernel" if mode == CHAIN_DBWD else "rchain_a2_kernel" if aux2 is not None else
                        "rchain_bg_kernel" if skip_out == 172 else "rchain_kernel")) if r6 else "chain_kernel",
                      (r1 - r0) * (32.0 * first_chunks + 1024.0 * n_mats))

@@ -493,7 +493,7 @@ int hold_chain_r6_if(const hold_chain_desc* d, uint32_t* guard, hold_stream_t st
  * kernel predicts layer by layer from the exact maximum of the point's values in the layer before (2^9 of headroom; the chain
  * input's maximum is exact).
  *   mode DSP : d->wpack = hold_chain_h3_pack_bytes() bytes of fp16, [7 x 16 k steps][8 nt][2 limbs][2 h][32 i][8 e], the rows and
- *              k order of hold_chain_r6's stream, limb_t(s_w[j] M_j); skip_out 217 only (0 = 217);
+ *              k order of hold_chain_r6's stream, limb_t(s_w[j] M_j); skip_out 217 (0 = 217), or 172 without aux2 as hold_chain_r6;
  *   mode DBWD: d->wpack = the stream of hold_trunk_h3 (hold_trunk_h3_pack_bytes() bytes; layer 0 = four k steps).
  * c3: [n_layers] = 1 / s_w[j] of the chain layers, device memory.  Otherwise the contract of hold_chain_r6.
  * OVERFLOW GUARD (as hold_fused_sdf_h3): a point whose values grow by more than the headroom within one layer would leave

@@ -127,8 +127,9 @@ def test_chain_descending_dsp(P, with_a2, arith):
         cur = out[j].double()
 
 
+@pytest.mark.parametrize("arith", ["r6", "h3"])
 @pytest.mark.parametrize("P", [130, 128 * 257 + 3])
-def test_chain_descending_dsp_background_skip_width(P):
+def test_chain_descending_dsp_background_skip_width(P, arith):
     """hold_chain_r6 (DSP) with skip_out = 172, the background net's skip width (256 - 84 embedding columns,
     code/src/model/renderables/background.py): columns 172.. of the skip layer's output are the raw products"""
     from hold_amd import kernels as K
@@ -141,7 +142,8 @@ def test_chain_descending_dsp_background_skip_width(P):
     hs = [_sp(torch.randn(P, 256, generator=g) * 0.03).to(dev) for _ in range(7)]
     guard = _Guarded(7, P, dev)
     out = guard.views
-    K.chain(K.CHAIN_DSP, P, v7, None, 7, 32, skip_layer=3, aux1=hs, out=out, wpack_r6=_r6_stream("dsp", Ms), skip_out=SKB)
+    K.chain(K.CHAIN_DSP, P, v7, None, 7, 32, skip_layer=3, aux1=hs, out=out, wpack_r6=_r6_stream("dsp", Ms), skip_out=SKB,
+            **(_h3_stream("dsp", Ms) if arith == "h3" else {}))
     guard.check()
     cur = v7.double()
     for j in range(7):
