@@ -1,5 +1,5 @@
-"""The bench line's contract, checked on the committed output of the default command (profiles/r05_bench_final.json is what
-`python bench.py` printed on an MI355X, scripts/lease_logs/r5_call15.sh) and on bench.py's command line -- no GPU needed."""
+"""The bench line's contract, checked on the committed output of the default command (profiles/r06_bench_final.json is what
+`python bench.py` printed on an MI355X, scripts/lease_logs/r6_call18.sh) and on bench.py's command line -- no GPU needed."""
 import json
 import os
 import subprocess
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    return json.load(open(os.path.join(ROOT, "profiles", "r05_bench_final.json")))
+    return json.load(open(os.path.join(ROOT, "profiles", "r06_bench_final.json")))
 
 
 def test_bench_line_carries_every_contract_field():
@@ -60,7 +60,17 @@ def test_bench_line_roofline_and_cpu_baseline_objects():
         n = v["limb_products_issued_per_product"]
         assert n in (1.0, 3.0, 6.0) and abs(v["mfma_achieved"] - n * v["fp32_equivalent_tflops"]) < 1e-6 * v["mfma_achieved"], k
     assert fam["fused_sdf_kernel"]["limb_products_issued_per_product"] == 3.0 and fam["wgrad_h3_kernel"]["arithmetic"] == "f16x3"
-    assert fam["rchain_dbwd_kernel"]["limb_products_issued_per_product"] == 6.0
+    # round 6: the sweeps and the single-layer GEMMs are f16x3 families too; the last f32x6 ones are named as such
+    for k in ("rchain_h3_kernel", "rchain_a2_h3_kernel", "rchain_dbwd_h3_kernel", "rgemm_h3_kernel"):
+        assert fam[k]["limb_products_issued_per_product"] == 3.0 and fam[k]["arithmetic"] == "f16x3", k
+    assert fam["gemm_nt_kernel"]["limb_products_issued_per_product"] == 6.0 and fam["rnarrow_kernel"]["arithmetic"] == "f32x6"
+    # the top-level object is the dominant kernel TEMPLATE: the sweeps' instantiations taken together
+    tmpl = [k for k in fam if k.startswith("rchain_") and k.endswith("_h3_kernel")]
+    assert "rsweep_h3_kernel" in r["kernel"] and abs(r["time_share"] - sum(fam[k]["time_share"] for k in tmpl)) < 1e-9
+    assert r["launches"] == sum(fam[k]["launches"] for k in tmpl)
+    # the overflow guard's fallback count is in the line, and the reference's own CPU timing is quoted as what it is
+    assert d["config"]["f16x3_launches_recomputed_in_f32x6_per_step"] == 0.0
+    assert c["reference_timed_in_build_container"]["rays_per_s"] > 0 and "NOT measured on this box" in c["reference_timed_in_build_container"]["note"]
 
 
 def test_bench_command_line_defaults():
