@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--op-sites", default=None, metavar="PATH",
                     help="diagnostic: count the non-view torch operators of ONE extra step by the hold_amd source line that "
                          "issued them (TorchDispatchMode; run after the timed steps) and write the table to PATH")
+    ap.add_argument("--step-times", default=None, metavar="PATH",
+                    help="diagnostic: after the timed steps run 16 more, each timed on its own with a synchronisation, and write the "
+                         "times with the caching allocator's counters to PATH")
     ap.add_argument("--sync-debug", default=None, metavar="PATH",
                     help="diagnostic: write the call sites of every host<->device synchronisation of the timed steps to PATH")
     ap.add_argument("--torch-profile", default=None, metavar="PATH",
@@ -81,6 +84,9 @@ def parse():
                     help="diagnostic: the host's Python time of the timed steps by function (cProfile on the main thread and, "
                          "through wrapped autograd Function.backward bodies, on the autograd engine's thread) -> PATH")
     ap.add_argument("--no-refine", action="store_true", help="--mode c3: skip the pose-refinement leg")
+    ap.add_argument("--c3-pixels", type=int, default=128,
+                    help="--mode c3: random pixels per frame (the reference's num_sample, general.yaml:82: 128 -> 1 280 rays per step; "
+                         "larger values show the 10-frame step device-bound -- a secondary line, labelled in config.workload)")
     ap.add_argument("--no-freeze", action="store_true",
                     help="let Adam move the weights during the run (default: the flat parameter bucket is restored after "
                          "every optimiser step, inside the timed region, so that every step sees the same SDF and runs the "
@@ -359,10 +365,10 @@ def main():
         gpix = torch.Generator().manual_seed(1234 + rank)
         batches = []
         for _ in range(4):
-            pix = torch.randperm(W * H, generator=gpix)[:128].numpy()
+            pix = torch.randperm(W * H, generator=gpix)[:args.c3_pixels].numpy()
             bb = syn.make_batch(sc, frames, uv[pix], W, H)
             batches.append({k: torch.from_numpy(v).to(dev) for k, v in bb.items()})
-        rays_per_step = 10 * 128
+        rays_per_step = 10 * args.c3_pixels
     else:
         split_rays = args.split == "rays" and world > 1
         if split_rays:  # one frame for the whole job; rank r owns rays [r, r + 1) * W * H / world of it
@@ -390,7 +396,7 @@ def main():
             from hold_amd.train import training_step
             bi = batches[i % len(batches)]
             if loss_fn is None:
-                loss, _ = train_step(net, bi, 128, step=i + 1, epoch=0)
+                loss, _ = train_step(net, bi, args.c3_pixels, step=i + 1, epoch=0)
                 lv = loss
             else:
                 loss, _, _ = training_step(net, loss_fn, bi, epoch=0, step=i + 1)
@@ -460,6 +466,18 @@ def main():
         loss = step(args.warmup + i)
         rays += rays_per_step
     torch.cuda.synchronize()
+    if args.step_times and rank == 0:  # diagnostic, after the timed region: every further step timed on its own, allocator counters
+        keys = ("num_device_alloc", "num_device_free", "num_alloc_retries", "reserved_bytes.all.current", "allocated_bytes.all.peak")
+        t_end = time.perf_counter()
+        with open(args.step_times, "w") as f:
+            for i in range(16):
+                m0 = torch.cuda.memory_stats()
+                ts = time.perf_counter()
+                step(args.warmup + args.steps + i)
+                torch.cuda.synchronize()
+                m1 = torch.cuda.memory_stats()
+                f.write(f"step {i}: {(time.perf_counter() - ts) * 1e3:.1f} ms  " + "  ".join(f"{k} {m0.get(k, 0)} -> {m1.get(k, 0)}" for k in keys) + "\n")
+        t0 += time.perf_counter() - t_end  # (not part of the timed region)
     if cprof is not None:
         import io, pstats
         cprof[0].disable()
@@ -557,7 +575,9 @@ def main():
         scene = ("configs[3]-like ARCTIC two-hand (right+left+object+background), " if args.two_hands else
                  "hold_bottle1_itw-like single-hand (right+object+background), ")
         if args.mode == "c3":
-            workload = ("configs[2]: the reference's training step -- 10 frames x 128 random pixels = 1 280 rays, " + scene +
+            workload = (("configs[2]: the reference's training step -- 10 frames x 128 random pixels = 1 280 rays, " if args.c3_pixels == 128
+                         else f"configs[2]-like 10-frame training step at {args.c3_pixels} random pixels per frame = {10 * args.c3_pixels} rays "
+                              "(NOT the reference's batch size: --c3-pixels), ") + scene +
                         f"fwd + {'full Loss (loss targets on)' if loss_fn else 'rgb/sem loss'} + bwd incl. pose-table "
                         "gradients + clip + Adam")
             metric = "rendered rays/sec (fwd+bwd) at the reference's 1 280-ray training batch -- secondary metric (configs[2])"
@@ -592,7 +612,7 @@ def main():
                       "products on v_mfma_f32_32x32x16_bf16, fp32 accumulate; --fp32-mfma for true-fp32 operands)"
                       if x6 else "f32"),
             "data": "synthetic",
-            "config": {"workload": workload, "chunk_rays": args.chunk if args.mode != "c3" else 1280,
+            "config": {"workload": workload, "chunk_rays": args.chunk if args.mode != "c3" else 10 * args.c3_pixels,
                        "sampler_rounds_last_call": iters, "sampler_rounds_mean_over_timed_calls": mean_iters,
                        "sigma_I": sum(mean_iters.values()),
                        "flop_per_ray": fpr, "flop_per_ray_note": "SURVEY 8(d) algorithmic FLOP (linear layers only) at the "

@@ -179,6 +179,7 @@ SIGNATURES = {
     "hold_trunk_r6": [_P, _I, _L, _P, _P, _P, C.POINTER(C.c_void_p), _I, _P],
     "hold_alive_count": [_P, _I, _L, _F, _P, _P],
     "hold_alive_index": [_P, _I, _L, _F, _P, _P, _P],
+    "hold_alive_mask": [_P, _I, _L, _F, _P, _P],
     "hold_fused_sdf_h3": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P],
     "hold_trunk_h3": [_P, _I, _L, _P, _P, _P, _P, C.POINTER(C.c_void_p), _I, _P, _P, _P, _P],
     "hold_fused_sdf_r6_if": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _I, _P, _P],

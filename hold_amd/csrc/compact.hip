@@ -71,6 +71,13 @@ __global__ __launch_bounds__(256) void alive_index_kernel(const float* __restric
   }
 }
 
+// mask[p] = 1 for a live sample, 0 for a dead one (the batch-of-frames compaction ranks the samples frame by frame on the host side)
+__global__ __launch_bounds__(256) void alive_mask_kernel(const float* __restrict__ sdf, int ld, long P, float beta,
+                                                         uint8_t* __restrict__ mask) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p < P) mask[p] = alive(sdf, ld, p, P, beta) ? 1 : 0;
+}
+
 inline int ok() { return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH; }
 
 }  // namespace
@@ -91,5 +98,12 @@ extern "C" int hold_alive_index(const float* sdf, int32_t ld, int64_t P, float b
   if (P == 0) return HOLD_OK;
   hipLaunchKernelGGL(alive_index_kernel, dim3((unsigned)hold_alive_blocks(P)), dim3(256), 0, (hipStream_t)st, sdf, ld, (long)P,
                      beta, reinterpret_cast<const long*>(block_offsets), reinterpret_cast<long*>(idx));
+  return ok();
+}
+
+extern "C" int hold_alive_mask(const float* sdf, int32_t ld, int64_t P, float beta, uint8_t* mask, hold_stream_t st) {
+  if (!sdf || !mask || ld < 1 || P < 0 || !(beta > 0.f)) return HOLD_E_ARG;
+  if (P == 0) return HOLD_OK;
+  hipLaunchKernelGGL(alive_mask_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)st, sdf, ld, (long)P, beta, mask);
   return ok();
 }

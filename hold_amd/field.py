@@ -37,6 +37,10 @@ USE_H3_TRUNK = os.environ.get("HOLD_H3_TRUNK", "1") != "0"  # mode f16x3: the tr
 COMPACT = os.environ.get("HOLD_COMPACT", "1") != "0"  # exact sample compaction behind the sdf (csrc/compact.hip); A/B switch
 COMPACT_ALIGN = 128       # compacted row counts are padded to this (the kernels' fast paths: P % 16 == 0, 128-point blocks)
 COMPACT_MAX_LIVE = 0.85   # compaction moves 9 KiB per live sample: above this live fraction it costs more than it saves
+COMPACT_BACKOFF = 16      # calls between two compaction attempts of a field while attempts keep failing (each one is a host read)
+COMPACT_MIN_POINTS = 1 << 18  # below this many samples per call a step is bound by the host's launch rate: the dozen
+#                               host operations of a compaction then cost more than the dropped rows save (measured: the reference's
+#                               10 x 128-ray batch at beta = 0.005, 125 k samples per node: 35.5-37.7 ms with, 34.0-34.8 ms without)
 USE_R6_BWD = os.environ.get("HOLD_R6_BWD", "1") != "0"  # ... and for the descending sweeps (csrc/rchain.hip)
 USE_H3_BWD = os.environ.get("HOLD_H3_BWD", "1") != "0"  # mode f16x3: the three backward sweeps too (csrc/rchain_h3.hip; A/B switch)
 # the 256 x 256 weight gradients of a backward as one grouped launch (gemm.WgradGroup / hold_wgrad_group_x6)
@@ -70,11 +74,17 @@ class Pool:
     def __init__(self, device):
         self.device = device
         self.bufs = {}
+        # rows a NEW buffer gets at least.  NodeField.forward sets it to the call's uncompacted sample count: the compacted row
+        # count changes from call to call, and a pool that grew with it re-allocated every [rows, 256] buffer of the tail and
+        # the backward whenever a call had more live samples than any before -- ~19 hipMallocs = 30 GB and up to a second
+        # inside a step, the outgrown blocks left behind in torch's cache (reserved memory crept to 285 GiB of the 288 GB;
+        # round 6, GPU call 23).  Sized by the uncompacted count once, like the uncompacted path, they never grow.
+        self.min_rows = 0
 
     def get(self, name, rows, cols, dtype=torch.float32):
         b = self.bufs.get(name)
         if b is None or b.shape[0] < rows or b.shape[1] != cols or b.dtype != dtype:
-            b = torch.zeros(rows, cols, dtype=dtype, device=self.device)
+            b = torch.zeros(max(rows, self.min_rows), cols, dtype=dtype, device=self.device)
             self.bufs[name] = b
         return b[:rows]
 
@@ -489,6 +499,7 @@ class NodeField:
         self.bpool = shared_pool(device)  # backward scratch (not needed across calls)
         self.device = device
         self.gen = 0  # bumped by every call that overwrites the saved activations (checked by the autograd glue)
+        self._compact_wait = self._compact_gap = 0  # back-off of the compaction attempts (forward)
 
     # ------------------------------------------------------------------ deformation
     def _deform(self, x, P, ppf, dfm, want_w):
@@ -597,59 +608,110 @@ class NodeField:
     def forward(self, pk, x, P, ppf, dfm, barf_w, pose_embed, time_code, training, beta=None):
         """-> dict(sdf [P,1], rgb [P,4], normal [P,3], xc, feat, grad).
         ``beta`` (the node's Laplace density beta, as the compositor will receive it): enables EXACT SAMPLE COMPACTION
-        (csrc/compact.hip) for single-frame calls -- after the trunk and the sdf row, the samples whose density and whose
+        (csrc/compact.hip; single- and multi-frame calls, _compaction) -- after the trunk and the sdf row, the samples whose density and whose
         density derivatives are exact fp32 zeros are dropped: the reverse sweep, the normal, the colour net and the whole
         backward run on the compacted rows, the dropped rows of rgb / normal are zeros (the compositor multiplies them by a
         weight of exactly 0).  Outputs are bit-identical to the uncompacted path; nothing changes when every sample is live."""
         sp, pool = self.spec, self.pool
         self.gen += 1
+        pool.min_rows = self.bpool.min_rows = P
         xc, w_def = self._deform(x, P, ppf, dfm, want_w=training)
         in0, h = self._trunk(pk, xc, P, barf_w, keep_all=True, need_in0=training)
         sdf = pool.get("sdf", P, 1)
         K.rowdot(h[7], pk["w8_sdf"], 256, pk["b8_sdf"], P, sdf)
-        cidx = K.alive_index(sdf, P, beta) if (COMPACT and beta is not None and ppf == P and P > 0) else None
-        if cidx is None:
-            self.last_live = None
+        self.last_live = None
+        plan = None
+        if COMPACT and beta is not None and P >= max(1, COMPACT_MIN_POINTS):
+            # every attempt costs a host read (the live count sizes the launches behind it).  While attempts keep finding nothing
+            # worth dropping -- the reference's initial beta = 0.1 has no dead sample anywhere in the scene -- they are spaced out:
+            # 1, 2, 4 .. COMPACT_BACKOFF calls apart; a successful attempt resets the spacing.  Skipping an attempt only skips an
+            # optimisation, results are the same either way.
+            if self._compact_wait > 0:
+                self._compact_wait -= 1
+                self.last_live = ("attempt skipped", self._compact_wait)
+            else:
+                plan = self._compaction(sdf, P, ppf, beta)
+                self._compact_gap = 0 if plan is not None else min(max(1, 2 * self._compact_gap), COMPACT_BACKOFF)
+                self._compact_wait = max(0, self._compact_gap - 1)
+        if plan is None:
             out = self._forward_tail(pk, xc, w_def, in0, h, P, ppf, dfm, barf_w, pose_embed, time_code, training)
             self.saved.update(sdf=sdf, cidx=None, P_full=P)
             out.update(sdf=sdf, xc=xc)
             return out
         # ---- compacted tail ----
-        Pa = int(cidx.numel())
-        Pc = (Pa + COMPACT_ALIGN - 1) // COMPACT_ALIGN * COMPACT_ALIGN  # rows the compacted stages run on
-        if Pc > COMPACT_MAX_LIVE * P:  # too few dead samples to pay for the gathers: every stage on every sample
-            self.last_live = (Pa, P, "not compacted")
-            out = self._forward_tail(pk, xc, w_def, in0, h, P, ppf, dfm, barf_w, pose_embed, time_code, training)
-            self.saved.update(sdf=sdf, cidx=None, P_full=P)
-            out.update(sdf=sdf, xc=xc)
-            return out
-        self.last_live = (Pa, P)
+        gidx, sidx, n_sc, Pc, ppf_c = plan
         rgb_f, nrm_f = pool.get("rgb_full", P, 4), pool.get("n_full", P, 4)
         rgb_f.zero_()
         nrm_f.zero_()
-        if Pa == 0:  # nothing along these rays: no colour, no normal, no gradient
-            self.saved = dict(P=0, P_full=P, cidx=cidx, pk=pk, sdf=sdf)
+        if Pc == 0:  # nothing along these rays: no colour, no normal, no gradient
+            self.saved = dict(P=0, P_full=P, cidx=gidx, pk=pk, sdf=sdf)
             return dict(sdf=sdf, rgb=rgb_f, normal=nrm_f[:, :3], xc=xc, feat=None, grad=None)
-        if Pc > Pa:
-            # the fast kernels want row counts that are multiples of 16 (whole-dW weight gradients) / 128 (point blocks): the list
-            # is padded with copies of ONE DEAD sample -- its cotangents are exact zeros, so the padding rows add exact zeros
-            # to every gradient sum; their forward values are not scattered back
-            live = torch.zeros(P, dtype=torch.int8, device=cidx.device)
-            live[cidx] = 1
-            dead = torch.argmin(live).reshape(1)  # index of the first dead sample (no host read)
-            gidx = torch.cat([cidx, dead.expand(Pc - Pa)])
-        else:
-            gidx = cidx
         gather = lambda src, name, cols: torch.index_select(src, 0, gidx, out=pool.get(name, Pc, cols))
         xc_c = gather(xc, "c_xc", 4)
         h_c = [gather(h[l], f"c_h{l}", 256) for l in range(8)]
         in0_c = gather(in0, "c_in0", sp.K0) if training else in0
         w_c = None if w_def is None else gather(w_def, "c_wdef", w_def.shape[1])
-        out = self._forward_tail(pk, xc_c, w_c, in0_c, h_c, Pc, Pc, dfm, barf_w, pose_embed, time_code, training)
-        rgb_f.index_copy_(0, cidx, out["rgb"][:Pa])
-        nrm_f[:, :3].index_copy_(0, cidx, out["normal"][:Pa])
+        out = self._forward_tail(pk, xc_c, w_c, in0_c, h_c, Pc, ppf_c, dfm, barf_w, pose_embed, time_code, training)
+        rgb_f.index_copy_(0, sidx, out["rgb"][:n_sc])
+        nrm_f[:, :3].index_copy_(0, sidx, out["normal"][:n_sc])
         self.saved.update(sdf=sdf, cidx=gidx, P_full=P)
         return dict(sdf=sdf, rgb=rgb_f, normal=nrm_f[:, :3], xc=xc, feat=out["feat"], grad=out["grad"])
+
+    def _compaction(self, sdf, P, ppf, beta):
+        """-> None (every stage on every sample) or (gidx [Pc] rows the compacted stages run on, sidx / n_sc: the first n_sc of
+        their results are scattered back to the rows sidx, Pc, points per frame of the compacted layout).  ONE host read either
+        way (the live count sizes the launches that follow).
+        Single frame (ppf == P): the ordered live list, padded to a multiple of COMPACT_ALIGN with copies of one dead sample.
+        Several frames (round 6; the reference's own training batch is 10 frames x 128 rays): the stages behind the trunk find
+        a row's frame as row // points-per-frame (pose embedding, bone transforms, the per-frame reductions of the backward), so
+        every frame keeps ONE common row count ppf_c = the largest live count of a frame, rounded up to COMPACT_ALIGN: frame
+        f's rows are its live samples in order, then as many of ITS OWN dead samples as fill the frame up -- real samples with
+        exactly zero cotangents, so they add exact zeros to every gradient sum, and what the forward computes for them is what
+        the uncompacted path computes there (scattered back with the rest; the compositor multiplies it by a weight of 0)."""
+        dev = sdf.device
+        if ppf == P:
+            cidx = K.alive_index(sdf, P, beta)
+            if cidx is None:
+                self.last_live = None
+                return None
+            Pa = int(cidx.numel())
+            Pc = (Pa + COMPACT_ALIGN - 1) // COMPACT_ALIGN * COMPACT_ALIGN
+            if Pc > COMPACT_MAX_LIVE * P:  # too few dead samples to pay for the gathers
+                self.last_live = (Pa, P, "not compacted")
+                return None
+            self.last_live = (Pa, P)
+            if Pc > Pa:
+                # the fast kernels want row counts that are multiples of 16 (whole-dW weight gradients) / 128 (point blocks): the
+                # list is padded with copies of ONE DEAD sample -- its cotangents are exact zeros; not scattered back
+                live = torch.zeros(P, dtype=torch.int8, device=dev)
+                live[cidx] = 1
+                dead = torch.argmin(live).reshape(1)  # index of the first dead sample (no host read)
+                gidx = torch.cat([cidx, dead.expand(Pc - Pa)])
+            else:
+                gidx = cidx
+            return gidx, cidx, Pa, Pc, Pc
+        B = P // ppf
+        live = K.alive_mask(sdf, P, beta).view(B, ppf)
+        csum = torch.cumsum(live, 1, dtype=torch.int32)  # rank + 1 of a live sample among its frame's live ones
+        cnt = csum[:, -1]
+        mx, Pa = (int(v) for v in torch.stack([cnt.max(), cnt.sum()]).cpu())  # the host read
+        if Pa == P:
+            self.last_live = None
+            return None
+        ppf_c = (mx + COMPACT_ALIGN - 1) // COMPACT_ALIGN * COMPACT_ALIGN
+        if B * ppf_c > COMPACT_MAX_LIVE * P or ppf_c > ppf:
+            self.last_live = (Pa, P, "not compacted")
+            return None
+        self.last_live = (Pa, P)
+        if mx == 0:
+            return torch.empty(0, dtype=torch.int64, device=dev), None, 0, 0, 0
+        # position of sample j in its frame's order "live samples ascending, then dead samples ascending": a permutation of the
+        # frame; its first ppf_c entries are the rows the compacted stages run on
+        j = torch.arange(ppf, dtype=torch.int32, device=dev).view(1, ppf)
+        pos = torch.where(live != 0, csum - 1, cnt.view(B, 1) + j - csum).long()  # (dead sample j: cnt + number of dead before it)
+        order = torch.empty(B, ppf, dtype=torch.int64, device=dev).scatter_(1, pos, j.long().expand(B, ppf))
+        gidx = (order[:, :ppf_c] + torch.arange(B, device=dev).view(B, 1) * ppf).reshape(-1)
+        return gidx, gidx, B * ppf_c, B * ppf_c, ppf_c
 
     def _forward_tail(self, pk, xc, w_def, in0, h, P, ppf, dfm, barf_w, pose_embed, time_code, training):
         """everything behind the trunk and the sdf row, on P rows (all samples, or the compacted live ones): lin8's feature

@@ -156,6 +156,13 @@ def alive_index(sdf, P, beta):
     return idx
 
 
+def alive_mask(sdf, P, beta):
+    """[P] uint8, 1 = live (the predicate of alive_index); no host read"""
+    mask = torch.empty(P, dtype=torch.uint8, device=sdf.device)
+    call("hold_alive_mask", ptr(sdf), sdf.stride(0) if sdf.dim() > 1 else 1, P, float(beta), ptr(mask))
+    return mask
+
+
 _H3_GUARD = {}
 
 

@@ -145,6 +145,10 @@ int64_t hold_alive_blocks(int64_t P);
 int hold_alive_count(const float* sdf, int32_t ld, int64_t P, float beta, int32_t* block_counts, hold_stream_t stream);
 int hold_alive_index(const float* sdf, int32_t ld, int64_t P, float beta, const int64_t* block_offsets, int64_t* idx,
                      hold_stream_t stream);
+/* mask[p] = 1 (live) / 0 (dead), the same predicate: what the compaction of a BATCH of frames ranks frame by frame (every frame keeps
+ * one common compacted row count, hold_amd/field.py:_compaction -- the reference's training batch is 10 frames x 128 rays,
+ * code/confs/general.yaml:82) */
+int hold_alive_mask(const float* sdf, int32_t ld, int64_t P, float beta, uint8_t* mask, hold_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Per-point kernels (hold_amd/csrc/points.hip)

@@ -52,16 +52,17 @@ def _rng(sc, N):
     return rng
 
 
-def _run(sc, sd_np, sd, compact, W=8, max_live=None):
+def _run(sc, sd_np, sd, compact, W=8, max_live=None, frames=(1,)):
     from hold_amd import field as F
-    prev = F.COMPACT, F.COMPACT_MAX_LIVE
+    prev = F.COMPACT, F.COMPACT_MAX_LIVE, F.COMPACT_MIN_POINTS
     F.COMPACT = compact
+    F.COMPACT_MIN_POINTS = 0  # (the product attempts compaction from 262 144 samples per call on: below, a step is host-bound)
     if max_live is not None:
         F.COMPACT_MAX_LIVE = max_live
     try:
         net = hip_net(sc, sd_np, train=True)
-        b, _ = oracle_input(sc, sd, [1], W, W)  # ONE frame: the configuration compaction applies to
-        out = net(hip_input(b, net, epoch=25, step=10), rng=_rng(sc, W * W))
+        b, _ = oracle_input(sc, sd, list(frames), W, W)  # one frame (the headline's calls) or a batch of frames (the reference's step)
+        out = net(hip_input(b, net, epoch=25, step=10), rng=_rng(sc, len(frames) * W * W))
         gt = torch.from_numpy(b["gt.rgb"]).view(-1, 3).cuda()
         loss = ((out["rgb"] - gt).abs().mean() + 0.1 * (out["semantics"] ** 2).mean() + 0.05 * out["normal"].sum(-1).mean()
                 + 0.02 * out["right.fg_rgb"].sum(-1).mean() + 0.03 * out["object.mask_prob"].mean() + 0.01 * out["depth"].mean())
@@ -71,7 +72,7 @@ def _run(sc, sd_np, sd, compact, W=8, max_live=None):
         keys = [k for k in out.keys() if torch.is_tensor(out[k]) and out[k].is_floating_point()]
         return {k: out[k].detach().clone() for k in keys}, grads, live, float(loss)
     finally:
-        F.COMPACT, F.COMPACT_MAX_LIVE = prev
+        F.COMPACT, F.COMPACT_MAX_LIVE, F.COMPACT_MIN_POINTS = prev
 
 
 def test_compacted_step_equals_the_uncompacted_step_on_a_sharp_beta_scene():
@@ -99,6 +100,70 @@ def test_compacted_step_equals_the_uncompacted_step_on_a_sharp_beta_scene():
         # a sum over a row of dW with cancellation -- amplifies the reordering of dW's fp32 partial sums; most tensors are bit-identical
         exact += torch.equal(g1[n], g0[n])
     print(f"compaction: live samples {live1}; {exact} of {len(g0)} gradient tensors bit-identical")
+
+
+def test_compacted_ten_frame_batch_equals_the_uncompacted_step():
+    """compaction for B > 1 -- the reference's own training batch is 10 frames x 128 rays
+    (code/confs/general.yaml:82).  Every frame keeps one common compacted row count (field._compaction), so the per-frame
+    stages (pose embedding, bone transforms, the per-frame reductions of the backward) see whole frames.  Same bar as the
+    single-frame test: every output bit for bit, parameter gradients (incl. the pose-table rows of all frames, some of them
+    twice in the batch) to 1e-4 of each tensor's norm."""
+    sc, sd_np, sd = _sharp_net(0.005)
+    frames = (0, 1, 2, 3, 1, 0, 3, 2, 2, 1)
+    o1, g1, live1, l1 = _run(sc, sd_np, sd, True, W=6, max_live=0.999, frames=frames)
+    o0, g0, live0, l0 = _run(sc, sd_np, sd, False, W=6, frames=frames)
+    assert all(v is None for v in live0.values())
+    assert any(v is not None and len(v) == 2 and v[0] < v[1] for v in live1.values()), live1  # compaction did drop samples
+    assert l1 == l0
+    for k in o0:
+        assert torch.equal(o1[k], o0[k]), k
+    assert set(g1) == set(g0) and len(g0) >= 100
+    exact = 0
+    for n in g0:
+        assert torch.isfinite(g1[n]).all() and torch.isfinite(g0[n]).all(), n
+        d = float((g1[n] - g0[n]).norm() / (g0[n].norm() + 1e-30))
+        assert d < 1e-4, (n, d)
+        exact += torch.equal(g1[n], g0[n])
+    pose_rows = [n for n in g0 if ".params." in n and float(g0[n].norm()) > 0]
+    assert len(pose_rows) >= 4, pose_rows  # the per-frame gradients are in the comparison
+    print(f"10-frame compaction: live samples {live1}; {exact} of {len(g0)} gradient tensors bit-identical")
+
+
+def test_alive_mask_equals_the_index_list_without_a_host_read():
+    from hold_amd import kernels as K
+    beta, P = 0.005, 3 * 1024 * 5 + 77
+    g = torch.Generator().manual_seed(3)
+    sdf = (beta * (400 * torch.rand(P, generator=g) - 100)).cuda().view(P, 1)
+    idx, m = K.alive_index(sdf, P, beta), K.alive_mask(sdf, P, beta)
+    assert m.dtype == torch.uint8 and m.shape == (P,) and int(m.sum()) == idx.numel() and torch.equal(torch.nonzero(m).view(-1), idx)
+    assert int(K.alive_mask(torch.zeros(P, 1, device="cuda"), P, beta).sum()) == P
+
+
+def test_failed_compaction_attempts_are_spaced_out_and_change_nothing():
+    """every attempt is a host read; on a scene without dead samples (the reference's initial beta) they back off to one in
+    COMPACT_BACKOFF calls -- the forward's outputs are the same with and without an attempt"""
+    from hold_amd import field as F
+    sc, sd_np, sd, _ = setup()
+    net = hip_net(sc, sd_np, train=False)
+    b, _ = oracle_input(sc, sd, [1], 6, 6)
+    seen, outs = [], []
+    prev, F.COMPACT_MIN_POINTS = F.COMPACT_MIN_POINTS, 0
+    try:
+        with torch.no_grad():
+            for _ in range(9):
+                out = net(hip_input(b, net, epoch=25, step=10))
+                seen.append(net.nodes["right"].field.last_live)
+                outs.append(out["rgb"].clone())
+            F.COMPACT_MIN_POINTS = prev  # the size gate: a call this small is not even looked at
+            net(hip_input(b, net, epoch=25, step=10))
+            assert net.nodes["right"].field.last_live is None and net.nodes["right"].field._compact_wait == seen[-1][1]
+    finally:
+        F.COMPACT_MIN_POINTS = prev
+    attempts = [i for i, v in enumerate(seen) if v is None]
+    assert attempts == [0, 1, 3, 7], seen  # gaps 1, 2, 4, 8
+    assert all(v[0] == "attempt skipped" for i, v in enumerate(seen) if i not in attempts)
+    assert all(torch.equal(o, outs[0]) for o in outs)
+    assert F.COMPACT_BACKOFF >= 8
 
 
 def test_default_scene_has_no_dead_samples_and_takes_the_uncompacted_path():
