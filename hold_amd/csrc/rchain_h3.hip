@@ -138,6 +138,20 @@ __device__ __forceinline__ void dma_piece(const char* src, uint32_t voff, uint32
       : "memory");
 }
 
+// ... of a SIDE tile: whole 128-byte lines that this launch reads exactly once, requested with the non-temporal hint -- they do not
+// displace the weight stream (read by every workgroup) from the L2.  Same-box A/B of the headline (round 6, GPU call 28): DBWD 10.6 ->
+// 10.2 ms, DSP + a2 7.8 -> 7.4, DSP 6.27 -> 6.20, the background's sweep 2.17 -> 2.03.  The hint is for once-touched whole lines only:
+// on hold_gemm_h3's quarter-line input fragments (each line touched by four requests) it costs 20 %, and on result stores it doubles
+// every kernel that stores 32-byte row fragments -- those rely on the L2 merging a line's four partial writes (GPU call 27)
+__device__ __forceinline__ void dma_side(const char* src, uint32_t voff, uint32_t dst) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1 nt"
+      :
+      : "v"(voff), "s"(src), "s"(dst)
+      : "memory");
+}
 #define RC_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
 template <int MODE, bool A2, int DIST_>
@@ -300,7 +314,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // piece i of side tile tn of matrix mat -> LDS tile at dst
     auto dma_tile_piece = [&](const float* mat, int tn, int i, uint32_t dst) {
-      dma_piece(reinterpret_cast<const char*>(mat + 32 * tn), dvoff[i], dst + i * PIECE);
+      dma_side(reinterpret_cast<const char*>(mat + 32 * tn), dvoff[i], dst + i * PIECE);
     };
 
     // One k step with an EXPLICIT schedule (rmlp_h3.hip:kstep): 4 groups ("pairs") x 6 MFMAs (hi hi, hi lo, lo hi for two

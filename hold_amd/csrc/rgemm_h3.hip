@@ -14,7 +14,7 @@
 // amax_in covers the features, amax_floor the rest).  Without amax_in the scale is the constant one of amax_floor (lin8's input, the
 // trunk's last softplus output: amax_floor = 64 is the 2^6 of rmlp_h3.hip).  OVERFLOW GUARD as in rmlp_h3.hip: exact running maximum
 // of the scaled values, guard word, conditional f32x6 launch (hold_gemm_r6_if) behind the kernel.
-// Structure, rings, queue accounting: csrc/rgemm.hip (4-slot weight ring = 64 KiB here, wave-private 4-slot side rings).
+// Structure, rings, queue accounting: csrc/rgemm.hip (4-slot weight ring = 64 KiB here, wave-private side rings: side_dist()).
 // Roofline: fp16 MFMA pipe at 3 limb products per product; HBM per point 4 (K + 256) B (+ 1 KiB mask operand) + 8 B of maxima.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,7 +32,15 @@ namespace {
 
 constexpr int NW = 4, BPTS = 32 * NW, PIECE = 1024, SLOT = 16 * PIECE;
 constexpr int R3 = 4;         // weight ring slots, DMA distance R3 - 1 k steps
-constexpr int SIDE_RING = 4;  // side ring slots: a fragment is requested four k steps before its k step
+// Side ring (per wave): a k step's input fragment is requested side_dist() k steps ahead into slot (k step % side_ring()).  With ONE
+// side matrix: five steps ahead, eight slots (LDS 129 KiB); with the mask operand as a second one: four / four (129 KiB again).
+// What the distance buys is set by the in-order vector-memory queue: the rendezvous of step j must have the weights issued in step
+// j - 2 (8 + 4 NSIDE younger operations), so at most that many operations stay in flight, and a side request is forced as soon as
+// the weight pieces issued right behind it are -- 1.75 k steps after its issue at distance 4 (it is consumed before the NEXT
+// rendezvous, which allows 7 + 2 NSIDE), 2.75 at distance 5 (the weights' own bound, 8 + 4 NSIDE = 12).  At ~8 KiB of side requests
+// per workgroup and step the bytes in flight are what bounds a launch (256 x 14 KiB / ~1 us = 3.6 TB/s measured before).
+constexpr int side_dist(int nside) { return nside == 1 ? 5 : 4; }
+constexpr int side_ring(int nside) { return nside == 1 ? 8 : 4; }
 
 enum { EPI_NONE = 0, EPI_RELU = 1, EPI_MASK = 2 };
 
@@ -104,13 +112,15 @@ template <int EPI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rgemm_h3_kernel(RGArgs a) {
   constexpr int NSIDE = EPI == EPI_MASK ? 2 : 1;  // side matrices: the input, and the mask operand
   constexpr int SIDE_SLOT = NSIDE * 2 * PIECE;
+  constexpr int SD = side_dist(NSIDE), SIDE_RING = side_ring(NSIDE);
   constexpr int OFF_SIDE = R3 * SLOT;
   constexpr int OFF_BIAS = OFF_SIDE + NW * SIDE_RING * SIDE_SLOT;
-  // VMEM operations that may stay in flight at a rendezvous (rgemm.hip's accounting with four weight pieces per wave and step):
-  // the previous rendezvous' four weight pieces and side requests, three stores.  The true number of operations younger than the
-  // weights a rendezvous needs is 8 + 4 NSIDE (rgemm.hip), so the two extra operations of a block -- the load of the next block's
-  // row maxima and the store of the finished block's -- stay inside the slack
-  constexpr int NWAIT = 4 + 2 * NSIDE + 3;
+  // VMEM operations that may stay in flight at a rendezvous.  Queue of a k step: W x 4, store, S x 2 NSIDE, store.  The rendezvous of
+  // step j needs (a) the weights issued in step j - 2: 8 + 4 NSIDE younger operations; (b) the side fragments consumed before the
+  // next rendezvous, i.e. the k step j + 2's, issued in step j + 2 - SD: 7 + 2 NSIDE younger operations at SD = 4, one whole step
+  // (6 + 2 NSIDE) more at SD = 5.  NWAIT = the smaller bound.  The two extra operations of a block (the load of the next block's
+  // row maxima, the store of the finished block's) only make a needed operation OLDER in the queue: never unsafe
+  constexpr int NWAIT = SD == 4 ? 7 + 2 * NSIDE : 8 + 4 * NSIDE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -189,14 +199,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const char* Xb = reinterpret_cast<const char*>(a.aux);
   const char* wbase = a.wpack;
 
-  // ---- once per workgroup: the first R3 - 1 weight steps, the input fragments of the k steps 0..3 ----
+  // ---- once per workgroup: the first R3 - 1 weight steps, the input fragments of the k steps 0..SD-1 ----
 #pragma unroll
   for (int s0 = 0; s0 < R3 - 1; ++s0)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       dma_piece(a.wpack + (long)s0 * SLOT + wave * (4 * PIECE) + i * PIECE, lane16, (uint32_t)(s0 * SLOT + wave * (4 * PIECE) + i * PIECE));
 #pragma unroll
-  for (int e = 0; e < 4; ++e)
+  for (int e = 0; e < SD; ++e)
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
       dma_piece(Ab + (16 * e + 8 * h2) * 4, in_off, side_dst0 + e * SIDE_SLOT + h2 * PIECE);
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // track: does the k step exist (its values count for the guard)?  0 = no (the slot holds the NEXT block's k step 0, split again at
   // its block start with ITS scale), 1 = yes, 2 = only with KS = 20
   auto mop = [&](int e, bool unit, int stage, int k, Limbs& out, EpiState& st, int track = 1) {
-    const int ss = e & 3;
+    const int ss = (e == 20 ? 0 : e) % SIDE_RING;  // (unit 20 = the next block's k step 0 when KS = 20; unit 16 when KS = 16: slot 0 too)
     if (stage == 0) {
       const int i = k;
       if ((i & 3) == 0) {
@@ -294,8 +304,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   // One k step j (rgemm.hip:kstep with 6 instead of 12 MFMAs per group): 4 groups x 6 MFMAs (hi hi, hi lo, lo hi for two n-tiles);
   // behind every MFMA one fragment read (gaps 0..3), in the group behind the rendezvous the four weight pieces of stream step
-  // gs + R3 - 1, in the last group -- BEHIND them in the queue -- the side fragments of k step j + 4 (of the next block once
-  // j + 4 >= KS), and cnt[group] / 6 micro-operations.
+  // gs + R3 - 1, in the last group -- BEHIND them in the queue -- the side fragments of k step j + SD (of the next block once
+  // j + SD >= KS), and cnt[group] / 6 micro-operations.
   auto kstep = [&](int j, const int (&cnt)[4], auto&& mp) {
     // KS % R3 == 0 and every block starts a new pass over the stream: ring slots are compile-time functions of j
     const int slot = j % R3, nslot = (j + 1) % R3, fslot = (j + R3 - 1) % R3;
@@ -303,10 +313,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     jw = jw >= KS ? jw - KS : jw;
     const char* wsrc = wbase + (long)jw * SLOT + wave * (4 * PIECE);
     const uint32_t wdst = (uint32_t)(fslot * SLOT + wave * (4 * PIECE));
-    const int e4 = j + 4;
+    const int e4 = j + SD;
     const bool wrap = e4 >= KS;
     const int ec = wrap ? e4 - KS : e4;  // k step (and epilogue unit) the side request is for
-    const uint32_t sd = side_dst0 + (j & 3) * SIDE_SLOT;
+    const uint32_t sd = side_dst0 + (uint32_t)(ec % SIDE_RING) * SIDE_SLOT;
     const char* s1 = Ab + 64 * (ec < a.K16 ? ec : 0);  // padded k steps (zero weights) re-read k step 0: never past a row
     const uint32_t o1 = wrap ? in_off_next : in_off;
     const char* s2 = Xb + 64 * (ec < 16 ? ec : 15);
@@ -436,7 +446,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 template <int EPI>
 int launch_h3(const RGArgs& a, hipStream_t s) {
   constexpr int NSIDE = EPI == EPI_MASK ? 2 : 1;
-  constexpr int lds = R3 * SLOT + NW * SIDE_RING * NSIDE * 2 * PIECE + 1024;
+  constexpr int lds = R3 * SLOT + NW * side_ring(NSIDE) * NSIDE * 2 * PIECE + 1024;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static int n_cu = 0;
   static bool attr_set = false;
