@@ -138,6 +138,7 @@ SIGNATURES = {
     "hold_gemm_r6": [_P, _I, _L, _P, _I, _P, _I, _P, _I, _P, _I, _P],
     "hold_gemm_r6_if": [_P, _I, _L, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P],
     "hold_gemm_h3": [_P, _I, _L, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _F, _P, _P, _P, _P],
+    "hold_gemm_h3_bits": [_P, _I, _L, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _F, _P, _P, _P, _P, _P, _P],
     "hold_weight_norm_fwd": [C.POINTER(WnDesc), _P],
     "hold_weight_norm_bwd": [C.POINTER(WnDesc), _P],
     "hold_rowdot": [_P, _I, _P, _I, _F, _P, _L, _P, _I, _P],

@@ -18,6 +18,7 @@
 // Roofline: fp16 MFMA pipe at 3 limb products per product; HBM per point 4 (K + 256) B (+ 1 KiB mask operand) + 8 B of maxima.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/hold_hip.h"
 
@@ -42,7 +43,8 @@ constexpr int R3 = 4;         // weight ring slots, DMA distance R3 - 1 k steps
 constexpr int side_dist(int nside) { return nside == 1 ? 5 : 4; }
 constexpr int side_ring(int nside) { return nside == 1 ? 8 : 4; }
 
-enum { EPI_NONE = 0, EPI_RELU = 1, EPI_MASK = 2 };
+// MASKB: the mask as one BIT per element (bits_in) instead of aux; RELUB: ReLU that also writes its mask as bits (bits_out)
+enum { EPI_NONE = 0, EPI_RELU = 1, EPI_MASK = 2, EPI_MASKB = 3, EPI_RELUB = 4 };
 
 struct RGArgs {
   const float* A; int lda; long P;
@@ -54,6 +56,10 @@ struct RGArgs {
   int KS, K16;         // k steps run (16 or 20), k steps that exist in A (K / 16)
   const float* bias;   // [256] or null (not with EPI_MASK)
   const float* aux; int ld_aux;  // EPI_MASK: C = y * (aux > 0)
+  // ReLU masks as bits (round 6): [P][8] dwords, bit n of a row = (column n of the ReLU launch's result > 0).  EPI_RELU writes them
+  // (bits_out, optional) from the values in its epilogue registers; EPI_MASKB reads them (bits_in) instead of streaming the [P][256]
+  // fp32 activation a second time -- 32 bytes per point instead of 1 KiB, and the masked launch has ONE side matrix
+  uint32_t* bits_out; const uint32_t* bits_in;
   float* C; int ldc;
 };
 
@@ -108,7 +114,11 @@ __device__ __forceinline__ void dma_piece(const char* src, uint32_t voff, uint32
 }
 #define RG_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
-template <int EPI>
+// ABL (developer build, results garbage, timing only): 1 = the input / mask pieces are requested in the SHAPE of whole lines (lane L -> row
+// 8 i + L / 8, 16-byte chunk L % 8 of a 32-column tile: the four pieces of two k steps cover a [32 rows][128 B] tile, as csrc/rchain_h3.hip's
+// side tiles do) instead of 32-byte row fragments; 2 = the result stores too.  Same bytes, same instruction counts, same queue: what the
+// access shape alone costs -- the upper bound of what whole-line tiles through LDS could gain this kernel
+template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rgemm_h3_kernel(RGArgs a) {
   constexpr int NSIDE = EPI == EPI_MASK ? 2 : 1;  // side matrices: the input, and the mask operand
   constexpr int SIDE_SLOT = NSIDE * 2 * PIECE;
@@ -131,7 +141,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const float* side_rd = reinterpret_cast<const float*>(smem + OFF_SIDE + wave * (SIDE_RING * SIDE_SLOT)) + lane * 4;
   const int KS = a.KS;
 
-  reinterpret_cast<float*>(smem + OFF_BIAS)[tid] = (EPI != EPI_MASK && a.bias) ? a.bias[tid] : 0.f;
+  constexpr bool MASKED = EPI == EPI_MASK || EPI == EPI_MASKB;
+  constexpr bool RELU = EPI == EPI_RELU || EPI == EPI_RELUB;
+  reinterpret_cast<float*>(smem + OFF_BIAS)[tid] = (!MASKED && a.bias) ? a.bias[tid] : 0.f;
   __syncthreads();
   const float c3 = *a.c3, s_w = 1.0f / c3;  // exact powers of two
   // per-point scale state: kB / sB = exponent / scale of the B operand of the block being accumulated (its row maximum, or the
@@ -151,7 +163,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   auto init_q = [&]() {  // bias of this lane's rows (features 32 nt + 8 g + 4 hh + k), in the accumulators' scale s_w 2^kB
     const float swB = s_w * sB;
-    if (EPI == EPI_MASK) {
+    if (MASKED) {
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
@@ -188,13 +200,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // latency exposed); the value is read a block later, when the in-order queue has retired it long ago (>= 128 younger
   // operations, every rendezvous leaves at most NWAIT of them in flight).  An earlier version moved the 32 values per wave by a
   // 4-byte LDS-DMA: results within tolerance but not bit-reproducible (the row scales depended on stale LDS) -- GPU call 11.
+  long row_P = -1;  // first row of this wave's share of the block held in P (none yet)
   float am_cur = AMb ? AMb[clamp_row(blk)] : 0.f;
   float am_next = 0.f;
+  // mask bits.  A lane owns, of every 16-column unit e, the columns 16 e + 8 h2 + 4 hh + k: in dword e / 2 of its row the bits
+  // 16 (e % 2) + 8 h2 + 4 hh + k.  Both directions work on the dword shifted by 4 hh, so that every position is an immediate:
+  // bo[d] collects the lane's own bits of the block held in P (EPI_RELU; shifted back, OR-ed with the other lane half and stored at the
+  // block's end), mb[d] holds the row's dword >> 4 hh (EPI_MASKB; requested a whole block ahead, like the row maxima)
+  uint32_t bo[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  uint32_t mb[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  u32x4 mbn0 = {0u, 0u, 0u, 0u}, mbn1 = {0u, 0u, 0u, 0u};
+  constexpr bool want_bits = EPI == EPI_RELUB;
+  auto request_bits = [&](long b) {  // the rows of block b (both lane halves of a point load the same 32 bytes)
+    const uint32_t* ptr = a.bits_in + clamp_row(b) * 8;
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=a"(mbn0), "=a"(mbn1) : "v"(ptr) : "memory");
+  };
+  auto store_bits = [&]() {  // of the block held in P (rows row_P ..): lane half 0 stores the point's 32 bytes
+    u32x4 w0, w1;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      uint32_t w = bo[d] << (4 * hh);
+      w |= (uint32_t)__shfl_xor((int)w, 32);
+      if (d < 4) w0[d] = w; else w1[d - 4] = w;
+      bo[d] = 0u;
+    }
+    if (hh == 0 && row_P + li < a.P) {
+      u32x4* dst = reinterpret_cast<u32x4*>(a.bits_out + (row_P + li) * 8);
+      dst[0] = w0;
+      dst[1] = w1;
+    }
+  };
   auto request_amax = [&](long b) {
     const float* ptr = AMb + clamp_row(b);
     asm volatile("global_load_dword %0, %1, off" : "=a"(am_next) : "v"(ptr) : "memory");
   };
-  long row_P = -1;  // first row of this wave's share of the block held in P (none yet)
   const char* Ab = reinterpret_cast<const char*>(a.A);
   const char* Xb = reinterpret_cast<const char*>(a.aux);
   const char* wbase = a.wpack;
@@ -254,10 +293,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if (!unit) return;
       if (k < 8) {
         float t = st.y[k];
-        if (EPI == EPI_RELU) t = relu1(t);
+        if (RELU) t = relu1(t);
         if (EPI == EPI_MASK) t = st.mk[k] > 0.f ? t : 0.f;
+        if (EPI == EPI_MASKB) {  // bit 16 (e % 2) + 8 (k / 4) + k % 4 of the shifted dword: all ones or zero
+          const int m = __builtin_amdgcn_sbfe((int)mb[e >> 1], 16 * (e & 1) + 8 * (k >> 2) + (k & 3), 1);
+          t = bitsf(fbits(t) & (uint32_t)m);
+        }
         RG_PIN(t);
         st.y[k] = t;
+        if (EPI == EPI_RELUB) {  // (t is +0 or positive after the ReLU: its bits are non-zero exactly when it is > 0)
+          const uint32_t one = fbits(t) < 1u ? fbits(t) : 1u;
+          bo[e >> 1] |= one << (16 * (e & 1) + 8 * (k >> 2) + (k & 3));
+        }
       } else {
         const int p = k - 8;
         asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(omx) : "v"(st.y[2 * p]), "v"(st.y[2 * p + 1]));
@@ -271,6 +318,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // launches with K = 304 a workgroup read a ring slot before its pieces had landed (round 6, GPU call 16: the same latent
         // race was in csrc/rgemm.hip since round 3).  Without a unit the store goes to a zero-length descriptor: dropped, counted.
         const f32x4 v = {st.y[4 * h2], st.y[4 * h2 + 1], st.y[4 * h2 + 2], st.y[4 * h2 + 3]};
+        if (ABL == 2 && unit) {  // timing ablation: the same 1 KiB per instruction as 8 whole lines of the unit pair's [32][128 B] tile
+          const long r = row_P + 8 * (2 * (e & 1) + h2) + (lane >> 3);
+          store4(v, crs, (uint32_t)((r * a.ldc + 32 * (e >> 1) + 4 * (lane & 7)) * 4));
+          return;
+        }
         store4(v, unit ? crs : nullrs, unit ? cvoff + (16 * e + 8 * h2) * 4 : 0u);
         return;
       }
@@ -306,6 +358,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // behind every MFMA one fragment read (gaps 0..3), in the group behind the rendezvous the four weight pieces of stream step
   // gs + R3 - 1, in the last group -- BEHIND them in the queue -- the side fragments of k step j + SD (of the next block once
   // j + SD >= KS), and cnt[group] / 6 micro-operations.
+  constexpr bool WL = ABL == 1 || ABL == 2 || ABL == 4;
+  uint32_t abl_o1[2] = {0u, 0u}, abl_o2[2] = {0u, 0u};
   auto kstep = [&](int j, const int (&cnt)[4], auto&& mp) {
     // KS % R3 == 0 and every block starts a new pass over the stream: ring slots are compile-time functions of j
     const int slot = j % R3, nslot = (j + 1) % R3, fslot = (j + R3 - 1) % R3;
@@ -318,9 +372,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int ec = wrap ? e4 - KS : e4;  // k step (and epilogue unit) the side request is for
     const uint32_t sd = side_dst0 + (uint32_t)(ec % SIDE_RING) * SIDE_SLOT;
     const char* s1 = Ab + 64 * (ec < a.K16 ? ec : 0);  // padded k steps (zero weights) re-read k step 0: never past a row
-    const uint32_t o1 = wrap ? in_off_next : in_off;
+    uint32_t o1 = wrap ? in_off_next : in_off;
     const char* s2 = Xb + 64 * (ec < 16 ? ec : 15);
-    const uint32_t o2 = wrap ? ax_off_cur : ax_off_prev;  // unit ec of the block in P, or (wrapped) of the running block
+    uint32_t o2 = wrap ? ax_off_cur : ax_off_prev;  // unit ec of the block in P, or (wrapped) of the running block
+    if (ABL == 3 || ABL == 4) {  // timing ablation: every workgroup walks the K columns from its own starting tile (2 (blockIdx % 8) k steps
+      // on): do all workgroups reading the same 128-byte column at the same time camp on a few channels?
+      const int er = ((ec < a.K16 ? ec : 0) + 2 * (int)(blockIdx.x & 7)) & 15;
+      s1 = Ab + 64 * er;
+      s2 = Xb + 64 * er;
+    }
+    if (ABL == 1 || ABL == 2 || ABL == 4) {  // timing ablation: the same bytes as whole lines (see the template's comment); rows of the block, clamped
+      const int ecl = ABL == 4 ? (((ec < a.K16 ? ec : 0) + 2 * (int)(blockIdx.x & 7)) & 15) : (ec < a.K16 ? ec : 0);
+      const long rb = (wrap ? blk + gridDim.x : blk) * BPTS + wave * 32;
+      auto lin = [&](int piece, long ld) {
+        long r = rb + 8 * (2 * (ecl & 1) + piece) + (lane >> 3);
+        r = r < a.P ? r : a.P - 1;
+        return (uint32_t)((r * ld + 32 * (ecl >> 1) + 4 * (lane & 7)) * 4);
+      };
+      s1 = Ab; s2 = Xb;
+      abl_o1[0] = lin(0, a.lda); abl_o1[1] = lin(1, a.lda);
+      abl_o2[0] = lin(0, a.ld_aux); abl_o2[1] = lin(1, a.ld_aux);
+    }
 #pragma unroll
     for (int pair = 0; pair < 4; ++pair) {
       if (pair == 2) {  // rendezvous: the weights of stream step gs + 1 have landed in every wave; slot gs - 1 is free
@@ -336,8 +408,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                                  __builtin_bit_cast(f16x8, Bc.l[al]), Q[2 * pair + tt], 0, 0, 0);
         if (m < 4) A[(pair + 1) & 1][m] = *reinterpret_cast<const u32x4*>(rd + m * PIECE);
         if (pair == 2 && m < 4) dma_piece(wsrc + m * PIECE, lane16, wdst + m * PIECE);
-        if (pair == 3 && (m == 0 || m == 2)) dma_piece(s1 + 32 * (m == 2), o1, sd + (m == 2) * PIECE);
-        if (pair == 3 && NSIDE == 2 && (m == 3 || m == 5)) dma_piece(s2 + 32 * (m == 5), o2, sd + 2 * PIECE + (m == 5) * PIECE);
+        if (pair == 3 && (m == 0 || m == 2)) dma_piece(WL ? s1 : s1 + 32 * (m == 2), WL ? abl_o1[m == 2] : o1, sd + (m == 2) * PIECE);
+        if (pair == 3 && NSIDE == 2 && (m == 3 || m == 5))
+          dma_piece(WL ? s2 : s2 + 32 * (m == 5), WL ? abl_o2[m == 5] : o2, sd + 2 * PIECE + (m == 5) * PIECE);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {  // constant trip count (the slice bounds fold once pair and m are unrolled)
           const int k = cnt[pair] * m / 6 + u;
@@ -367,6 +440,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         m = fmaxf(m, am_cur);
         request_amax(blk + gridDim.x);
       }
+      if (EPI == EPI_MASKB) request_bits(blk);  // this block's mask rows: needed from the next iteration on, when it is P
       kB = row_scale(m);
       sB = pow2f(kB);
     }
@@ -395,6 +469,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if (hh == 0 && row_P + li < a.P) a.amax_out[row_P + li] = o;
     }
     omx = 0.f;
+    if (want_bits && row_P >= 0) store_bits();
+    if (EPI == EPI_MASKB) {
+#pragma unroll
+      for (int d = 0; d < 8; ++d) mb[d] = (d < 4 ? mbn0[d & 3] : mbn1[d & 3]) >> (4 * hh);
+    }
     // ---- the block is finished: it becomes P; its stores run behind the next block ----
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) P[nt] = Q[nt];
@@ -425,8 +504,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float t = P[nt][4 * g + k] * yscP;
-          if (EPI == EPI_RELU) t = relu1(t);
+          if (RELU) t = relu1(t);
           if (EPI == EPI_MASK) t = bitsf(mv[k]) > 0.f ? t : 0.f;
+          if (EPI == EPI_MASKB) t = bitsf(fbits(t) & (uint32_t)__builtin_amdgcn_sbfe((int)mb[nt], 8 * g + k, 1));
+          if (EPI == EPI_RELUB) bo[nt] |= (fbits(t) < 1u ? fbits(t) : 1u) << (8 * g + k);
           v[k] = t;
           omx = fmaxf(omx, fabsf(t));
         }
@@ -436,6 +517,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const float o = fmaxf(omx, __shfl_xor(omx, 32));
       if (hh == 0 && row_P + li < a.P) a.amax_out[row_P + li] = o;
     }
+    if (want_bits && row_P >= 0) store_bits();
   }
   if (a.guard) {
     const float m2 = fmaxf(mx, __shfl_xor(mx, 32));
@@ -448,6 +530,35 @@ int launch_h3(const RGArgs& a, hipStream_t s) {
   constexpr int NSIDE = EPI == EPI_MASK ? 2 : 1;
   constexpr int lds = R3 * SLOT + NW * side_ring(NSIDE) * NSIDE * 2 * PIECE + 1024;
   static_assert(lds <= 160 * 1024, "LDS budget");
+#ifdef HOLD_DEV
+  if (const char* v = getenv("HOLD_RG_ABL")) {  // developer build: access-shape ablations (results garbage)
+    int dev_ = 0;
+    hipDeviceProp_t prop_;
+    if (hipGetDevice(&dev_) != hipSuccess || hipGetDeviceProperties(&prop_, dev_) != hipSuccess) return HOLD_E_LAUNCH;
+    const long blocks_ = (a.P + BPTS - 1) / BPTS;
+    const dim3 grid_((unsigned)(blocks_ < prop_.multiProcessorCount ? blocks_ : prop_.multiProcessorCount));
+    if (v[0] == '1') {
+      if (hipFuncSetAttribute((const void*)rgemm_h3_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return HOLD_E_LAUNCH;
+      hipLaunchKernelGGL((rgemm_h3_kernel<EPI, 1>), grid_, dim3(256), lds, s, a);
+      return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+    }
+    if (v[0] == '2') {
+      if (hipFuncSetAttribute((const void*)rgemm_h3_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return HOLD_E_LAUNCH;
+      hipLaunchKernelGGL((rgemm_h3_kernel<EPI, 2>), grid_, dim3(256), lds, s, a);
+      return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+    }
+    if (v[0] == '3') {
+      if (hipFuncSetAttribute((const void*)rgemm_h3_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return HOLD_E_LAUNCH;
+      hipLaunchKernelGGL((rgemm_h3_kernel<EPI, 3>), grid_, dim3(256), lds, s, a);
+      return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+    }
+    if (v[0] == '4') {
+      if (hipFuncSetAttribute((const void*)rgemm_h3_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return HOLD_E_LAUNCH;
+      hipLaunchKernelGGL((rgemm_h3_kernel<EPI, 4>), grid_, dim3(256), lds, s, a);
+      return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+    }
+  }
+#endif
   static int n_cu = 0;
   static bool attr_set = false;
   if (n_cu == 0) {
@@ -466,6 +577,36 @@ int launch_h3(const RGArgs& a, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
 }
 
+// bits[p][d] bit b = (C[p][32 d + b] > 0), rebuilt from C -- only when the overflow guard's fallback count (guard[2]) moved since the
+// last such launch (guard[3]): hold_gemm_r6_if has then rewritten C behind an EPI_RELU launch whose bits came from overflowed values.
+// The last workgroup to finish publishes guard[3] = guard[2] (guard[1]: the arrival counter of the conditional launches, 0 between them).
+__global__ __launch_bounds__(256) void relu_bits_if_kernel(const float* __restrict__ C, int ldc, long P, uint32_t* __restrict__ bits,
+                                                           uint32_t* guard) {
+  if (__hip_atomic_load(guard + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+      __hip_atomic_load(guard + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    return;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < P * 8; i += (long)gridDim.x * 256) {
+    const float* c = C + (i >> 3) * ldc + 32 * (i & 7);
+    uint32_t w = 0u;
+#pragma unroll
+    for (int b4 = 0; b4 < 8; ++b4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(c + 4 * b4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w |= ((int)fbits(v[k]) > 0 ? 1u : 0u) << (4 * b4 + k);
+    }
+    bits[i] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(guard + 1, 1u) == gridDim.x - 1) {
+      guard[1] = 0u;
+      __hip_atomic_store(guard + 3, __hip_atomic_load(guard + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int64_t hold_gemm_h3_pack_bytes(int32_t K) { return (int64_t)((K + 63) / 64 * 4) * SLOT; }
@@ -479,14 +620,21 @@ extern "C" int hold_gemm_r6_if(const float* A, int32_t lda, int64_t P, const voi
 // scalar).  amax_in [P] (or NULL): an upper bound of |A[p][:]| over the columns its producer wrote (exact when it is a producer's
 // amax_out); amax_floor >= the magnitude of the other columns (NULL amax_in: of every column); amax_out [P] (or NULL): receives
 // max |C[p][:]|.  guard / wpack_r6: overflow guard and conditional f32x6 fallback (hold_gemm_r6_if), as hold_fused_sdf_h3.
-extern "C" int hold_gemm_h3(const float* A, int32_t lda, int64_t P, const void* wpack_h3, const float* c3, int32_t K,
-                            const float* bias, int32_t epilogue, const float* aux, int32_t ld_aux, float* C, int32_t ldc,
-                            const float* amax_in, float amax_floor, float* amax_out, uint32_t* guard, const void* wpack_r6,
-                            hold_stream_t st) {
+// relu_bits_out (epilogue 1, optional): [P][8] dwords, bit n of row p = (C[p][n] > 0).  mask_bits_in (epilogue 2, optional): such a
+// matrix; the mask is then taken from it instead of aux (aux is still what the f32x6 fallback reads: required with wpack_r6).
+extern "C" int hold_gemm_h3_bits(const float* A, int32_t lda, int64_t P, const void* wpack_h3, const float* c3, int32_t K,
+                                 const float* bias, int32_t epilogue, const float* aux, int32_t ld_aux, float* C, int32_t ldc,
+                                 const float* amax_in, float amax_floor, float* amax_out, uint32_t* relu_bits_out,
+                                 const uint32_t* mask_bits_in, uint32_t* guard, const void* wpack_r6, hold_stream_t st) {
   if (!A || !wpack_h3 || !c3 || !C || P < 0 || K < 256 || K > 320 || (K & 15) || lda < K || (lda & 3) || ldc < 256 || (ldc & 3)) return HOLD_E_ARG;
   if (((uintptr_t)A & 15) || ((uintptr_t)C & 15) || ((uintptr_t)wpack_h3 & 15) || (bias && ((uintptr_t)bias & 15))) return HOLD_E_ARG;
   if (epilogue < 0 || epilogue > 2) return HOLD_E_ARG;
-  if (epilogue == 2 && (!aux || bias || ld_aux < 256 || (ld_aux & 3) || ((uintptr_t)aux & 15))) return HOLD_E_ARG;
+  const bool maskb = epilogue == 2 && mask_bits_in != nullptr;
+  if (epilogue == 2 && bias) return HOLD_E_ARG;
+  if (epilogue == 2 && (!maskb || wpack_r6) && !aux) return HOLD_E_ARG;  // aux: the mask itself, or what the f32x6 fallback reads
+  if (aux && (ld_aux < 256 || (ld_aux & 3) || ((uintptr_t)aux & 15))) return HOLD_E_ARG;
+  if ((relu_bits_out && epilogue != 1) || (mask_bits_in && epilogue != 2)) return HOLD_E_ARG;
+  if (((uintptr_t)relu_bits_out & 15) || ((uintptr_t)mask_bits_in & 15)) return HOLD_E_ARG;
   if (!(amax_floor >= 0.f) || (!amax_in && !(amax_floor > 0.f))) return HOLD_E_ARG;
   if (((uintptr_t)amax_in & 3) || ((uintptr_t)amax_out & 3) || ((uintptr_t)guard & 3) || (wpack_r6 && !guard)) return HOLD_E_ARG;
   if (P == 0) return HOLD_OK;
@@ -495,9 +643,28 @@ extern "C" int hold_gemm_h3(const float* A, int32_t lda, int64_t P, const void* 
   RGArgs a;
   a.A = A; a.lda = lda; a.P = (long)P; a.wpack = (const char*)wpack_h3; a.c3 = c3; a.amax_in = amax_in; a.amax_floor = amax_floor;
   a.amax_out = amax_out; a.guard = guard; a.KS = (K + 63) / 64 * 4; a.K16 = K / 16; a.bias = bias; a.aux = aux;
-  a.ld_aux = ld_aux; a.C = C; a.ldc = ldc;
+  a.ld_aux = ld_aux; a.C = C; a.ldc = ldc; a.bits_out = relu_bits_out; a.bits_in = mask_bits_in;
   hipStream_t s = (hipStream_t)st;
-  const int rc = epilogue == 0 ? launch_h3<EPI_NONE>(a, s) : epilogue == 1 ? launch_h3<EPI_RELU>(a, s) : launch_h3<EPI_MASK>(a, s);
+  const int rc = epilogue == 0 ? launch_h3<EPI_NONE>(a, s)
+               : epilogue == 1 ? (relu_bits_out ? launch_h3<EPI_RELUB>(a, s) : launch_h3<EPI_RELU>(a, s))
+               : maskb ? launch_h3<EPI_MASKB>(a, s) : launch_h3<EPI_MASK>(a, s);
   if (rc != HOLD_OK || !wpack_r6) return rc;
-  return hold_gemm_r6_if(A, lda, P, wpack_r6, K, bias, epilogue, aux, ld_aux, C, ldc, amax_out, guard, st);
+#ifdef HOLD_DEV
+  if (const char* v = getenv("HOLD_RG_ABL"))  // a timing ablation's garbage results would trip the guard: no conditional relaunch
+    if (v[0] != '0') return rc;
+#endif
+  const int rc2 = hold_gemm_r6_if(A, lda, P, wpack_r6, K, bias, epilogue, aux, ld_aux, C, ldc, amax_out, guard, st);
+  if (rc2 != HOLD_OK || !relu_bits_out) return rc2;
+  // the f32x6 kernel rewrites C, not the bits: a third conditional launch rebuilds them from C iff the fallback count moved
+  hipLaunchKernelGGL(relu_bits_if_kernel, dim3(256), dim3(256), 0, s, (const float*)C, (int)ldc, (long)P, relu_bits_out, guard);
+  return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+}
+
+extern "C" int hold_gemm_h3(const float* A, int32_t lda, int64_t P, const void* wpack_h3, const float* c3, int32_t K,
+                            const float* bias, int32_t epilogue, const float* aux, int32_t ld_aux, float* C, int32_t ldc,
+                            const float* amax_in, float amax_floor, float* amax_out, uint32_t* guard, const void* wpack_r6,
+                            hold_stream_t st) {
+  if (epilogue == 2 && !aux) return HOLD_E_ARG;
+  return hold_gemm_h3_bits(A, lda, P, wpack_h3, c3, K, bias, epilogue, aux, ld_aux, C, ldc, amax_in, amax_floor, amax_out, nullptr,
+                           nullptr, guard, wpack_r6, st);
 }

@@ -47,6 +47,7 @@ USE_H3_BWD = os.environ.get("HOLD_H3_BWD", "1") != "0"  # mode f16x3: the three 
 USE_WGRAD_GROUP = os.environ.get("HOLD_WGRAD_GROUP", "1") != "0"
 USE_R6_GEMM = os.environ.get("HOLD_R6_GEMM", "1") != "0"  # ... and for the rendering net's layers / lin8 (csrc/rgemm.hip)
 USE_H3_GEMM = os.environ.get("HOLD_H3_GEMM", "1") != "0"  # mode f16x3: those layers in two fp16 limbs (csrc/rgemm_h3.hip; A/B switch)
+USE_RELU_BITS = os.environ.get("HOLD_RELU_BITS", "1") != "0"  # A/B: the backward's ReLU masks from bits (hold_gemm_h3_bits) or from r_l
 H3_ROW_FLOOR = 64.0  # assumed bound of activation columns no producer reported a maximum for (= 2^6, the trunk's activation scale)
 RIN_FEAT, RIN_X, RIN_N, RIN_POSE, RIN_TIME = 0, 256, 259, 262, 270
 
@@ -751,13 +752,19 @@ class NodeField:
         # ---- rendering net ----
         R, rb = pk["R"], pk["rb"]
         r = [pool.get(f"r{l}", P, 256) for l in range(4)]
+        rbits = None
         if h3g:
+            # the ReLU masks of lin0..2 as one bit per element (32 bytes per point and layer): what the backward's masked input-
+            # gradient launches read instead of streaming r_0..r_2 a second time (hold_gemm_h3_bits)
+            if training and USE_RELU_BITS:
+                rbits = [pool.get(f"rbits{l}", P, 8, torch.int32) for l in range(3)]
             # lin0 reads [features | xc | normal | pose | (time)]: the features' maxima are exact, the floor bounds the rest
             G.gemm_h3(rin, pk["R_h3"][0], pk["c3_R"][0], r[0], K=sp.Kr, wpack_r6=pk["R_r6"][0], bias=rb[0], epi=G.R6_RELU,
-                      amax_in=amx[0], amax_floor=H3_ROW_FLOOR, amax_out=amx[1])
+                      amax_in=amx[0], amax_floor=H3_ROW_FLOOR, amax_out=amx[1], bits_out=rbits[0] if rbits else None)
             for l in (1, 2, 3):
                 G.gemm_h3(r[l - 1], pk["R_h3"][l], pk["c3_R"][l], r[l], K=256, wpack_r6=pk["R_r6"][l], bias=rb[l], epi=G.R6_RELU,
-                          amax_in=amx[l & 1], amax_out=amx[(l + 1) & 1] if l < 3 else None)
+                          amax_in=amx[l & 1], amax_out=amx[(l + 1) & 1] if l < 3 else None,
+                          bits_out=rbits[l] if (rbits and l < 3) else None)
         elif USE_R6_GEMM and "R_r6" in pk:
             G.gemm_r6(rin, pk["R_r6"][0], r[0], K=sp.Kr, bias=rb[0], epi=G.R6_RELU)
             for l in (1, 2, 3):
@@ -770,7 +777,7 @@ class NodeField:
         rgb = pool.get("rgb", P, 4)
         G.head3_fwd(r[3], R[4], rb[4], rgb)  # 3-output head: a streaming kernel, not a 3/256-full GEMM tile
         self.saved = dict(P=P, ppf=ppf, xc=xc, w_def=w_def, w_c=w_c, in0=in0, h=h, t=t, ge=ge, g=g, rin=rin, r=r,
-                          rgb=rgb, dfm=dfm, barf_w=barf_w, pk=pk)
+                          rgb=rgb, dfm=dfm, barf_w=barf_w, pk=pk, rbits=rbits)
         return dict(rgb=rgb, normal=rin[:, RIN_N:RIN_N + 3], feat=rin[:, RIN_FEAT:RIN_FEAT + FEAT], grad=g)
 
     # ------------------------------------------------------------------ shared backward sweeps
@@ -988,6 +995,7 @@ class NodeField:
             d_normal = None if d_normal is None else d_normal.index_select(0, cidx)
         P, ppf = sv["P"], sv["ppf"]
         h, t, rin, r, rgb, xc = sv["h"], sv["t"], sv["rin"], sv["r"], sv["rgb"], sv["xc"]
+        rbits = sv.get("rbits")
         # ---------- rendering net ----------
         dy = pool.get("dy4", P, 4)
         sg = rgb[:, :3]
@@ -1017,7 +1025,7 @@ class NodeField:
             nxt = rr[ci]
             if h3g:
                 G.gemm_h3(cur, pk["RT_h3"][l], pk["c3_RT"][l], nxt, K=256, wpack_r6=pk["RT_r6"][l], epi=G.R6_MASK, aux=r[l - 1],
-                          amax_in=bamx[bi], amax_out=bamx[bi ^ 1])
+                          amax_in=bamx[bi], amax_out=bamx[bi ^ 1], bits_in=rbits[l - 1] if rbits else None)
                 bi ^= 1
             elif USE_R6_GEMM and "RT_r6" in pk:
                 G.gemm_r6(cur, pk["RT_r6"][l], nxt, K=256, epi=G.R6_MASK, aux=r[l - 1])

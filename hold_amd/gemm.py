@@ -58,12 +58,15 @@ def gemm_r6(A, wpack, out, *, K, bias=None, epi=R6_NONE, aux=None):
     return out
 
 
-def gemm_h3(A, wpack_h3, c3, out, *, K, wpack_r6, bias=None, epi=R6_NONE, aux=None, amax_in=None, amax_floor=0.0, amax_out=None):
+def gemm_h3(A, wpack_h3, c3, out, *, K, wpack_r6, bias=None, epi=R6_NONE, aux=None, amax_in=None, amax_floor=0.0, amax_out=None,
+            bits_out=None, bits_in=None):
     """gemm_r6 in the two-limb fp16 arithmetic (hold_gemm_h3, csrc/rgemm_h3.hip): wpack_h3 / c3 from field.pack_gemm_h3 (c3 = a
     one-element device tensor, 1 / s_w).  Every row of A is scaled by its own power of two from max(amax_in[p], amax_floor)
     (amax_in [P]: the amax_out of the launch that produced A, or any upper bound; amax_floor: bound of the columns that launch did
     not write / of everything without amax_in); amax_out [P] receives the row maxima of out.  wpack_r6 = gemm_r6's stream of the
-    same matrix: the conditional f32x6 fallback behind the overflow guard (kernels.h3_guard)."""
+    same matrix: the conditional f32x6 fallback behind the overflow guard (kernels.h3_guard).
+    bits_out ([P, 8] int32, epi = R6_RELU): receives the ReLU mask of `out` as one bit per element; bits_in (epi = R6_MASK): the mask
+    is read from such a matrix instead of streaming `aux` (which stays the operand of the f32x6 fallback)."""
     from . import kernels as _k
     P = A.shape[0]
     L = _lib.lib()
@@ -72,18 +75,24 @@ def gemm_h3(A, wpack_h3, c3, out, *, K, wpack_r6, bias=None, epi=R6_NONE, aux=No
     assert c3.numel() == 1 and c3.dtype == torch.float32 and c3.is_cuda
     for t in (amax_in, amax_out):
         assert t is None or (t.numel() == P and t.dtype == torch.float32 and t.is_contiguous())
+    for t in (bits_out, bits_in):
+        assert t is None or (t.shape == (P, 8) and t.dtype == torch.int32 and t.is_contiguous())
     ldmax = max(_ld(A), _ld(out), _ld(aux) if aux is not None else 0)
     rows = max(128, ((1 << 32) // (4 * ldmax) - 256) // 128 * 128)  # 32-bit offsets inside the kernel: split by rows
     guard = _k.h3_guard(A.device)
     e0 = _prof_begin()
     for r0 in range(0, P, rows):
         n = min(P, r0 + rows) - r0
-        check(L.hold_gemm_h3(ptr(A[r0:]), _ld(A), n, ptr(wpack_h3), ptr(c3), K, ptr(bias), int(epi),
-                             ptr(None if aux is None else aux[r0:]), 0 if aux is None else _ld(aux), ptr(out[r0:]), _ld(out),
-                             ptr(None if amax_in is None else amax_in.reshape(-1)[r0:]), float(amax_floor),
-                             ptr(None if amax_out is None else amax_out.reshape(-1)[r0:]), ptr(guard), ptr(wpack_r6), stream_ptr()),
+        check(L.hold_gemm_h3_bits(ptr(A[r0:]), _ld(A), n, ptr(wpack_h3), ptr(c3), K, ptr(bias), int(epi),
+                                  ptr(None if aux is None else aux[r0:]), 0 if aux is None else _ld(aux), ptr(out[r0:]), _ld(out),
+                                  ptr(None if amax_in is None else amax_in.reshape(-1)[r0:]), float(amax_floor),
+                                  ptr(None if amax_out is None else amax_out.reshape(-1)[r0:]),
+                                  ptr(None if bits_out is None else bits_out[r0:]), ptr(None if bits_in is None else bits_in[r0:]),
+                                  ptr(guard), ptr(wpack_r6), stream_ptr()),
               "hold_gemm_h3")
-    _prof_end(e0, 2.0 * P * 256 * K, "rgemm_h3_kernel", 4.0 * P * (K + 256 + (256 if aux is not None else 0) + 2))
+    _prof_end(e0, 2.0 * P * 256 * K, "rgemm_h3_kernel",
+              4.0 * P * (K + 256 + (256 if (aux is not None and bits_in is None) else 0) + 2
+                         + (8 if (bits_in is not None or bits_out is not None) else 0)))
     return out
 
 

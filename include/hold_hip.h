@@ -539,6 +539,17 @@ int64_t hold_gemm_h3_pack_bytes(int32_t K);
 int hold_gemm_h3(const float* A, int32_t lda, int64_t P, const void* wpack_h3, const float* c3, int32_t K, const float* bias,
                  int32_t epilogue, const float* aux, int32_t ld_aux, float* C, int32_t ldc, const float* amax_in, float amax_floor,
                  float* amax_out, uint32_t* guard, const void* wpack_r6, hold_stream_t stream);
+/* ... with the ReLU masks of the rendering net as BITS (round 6).  texture_net.py:95-101 applies ReLU after lin0..lin3, and autograd's
+ * backward multiplies the cotangent by (activation > 0): the product used to stream the [P][256] fp32 activation a second time for that
+ * (epilogue 2's aux, 1 KiB per point and layer).  relu_bits_out (epilogue 1; [P][8] dwords, 16-byte aligned, or NULL): bit n of row p =
+ * (C[p][n] > 0), written from the values in the epilogue registers.  mask_bits_in (epilogue 2; such a matrix, or NULL): the mask is
+ * taken from it -- 32 bytes per point, and the launch has one side matrix instead of two; aux may then be NULL unless wpack_r6 is given
+ * (the f32x6 fallback still masks by aux).  When an epilogue-1 launch falls back, a third conditional launch rebuilds its bits from the
+ * recomputed C (it compares guard[2] with guard[3], the count it last saw).  Otherwise hold_gemm_h3. */
+int hold_gemm_h3_bits(const float* A, int32_t lda, int64_t P, const void* wpack_h3, const float* c3, int32_t K, const float* bias,
+                      int32_t epilogue, const float* aux, int32_t ld_aux, float* C, int32_t ldc, const float* amax_in,
+                      float amax_floor, float* amax_out, uint32_t* relu_bits_out, const uint32_t* mask_bits_in, uint32_t* guard,
+                      const void* wpack_r6, hold_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Weight normalisation of all layers of a net in one launch per direction (hold_amd/csrc/wnorm.hip): every Linear of

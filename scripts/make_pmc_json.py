@@ -24,7 +24,8 @@ groups = {"fused_sdf_kernel": ["rmlp_h3_kernel<true,false,0>", "rmlp_kernel<true
           "rchain_a2_h3_kernel": ["rsweep_h3_kernel<1,true,3,0,217>", "rsweep_h3_kernel<1,true,1,0,217>"],
           "rchain_dbwd_h3_kernel": ["rsweep_h3_kernel<2,true,1,0,217>", "rsweep_h3_kernel<2,true,3,0,217>"],
           "rchain_bg_h3_kernel": ["rsweep_h3_kernel<1,false,3,0,172>"],
-          "rgemm_h3_kernel": ["rgemm_h3_kernel<0>", "rgemm_h3_kernel<1>", "rgemm_h3_kernel<2>"],
+          "rgemm_h3_kernel": ["rgemm_h3_kernel<0,0>", "rgemm_h3_kernel<1,0>", "rgemm_h3_kernel<2,0>", "rgemm_h3_kernel<3,0>", "rgemm_h3_kernel<4,0>",  # <EPI, ABL>
+                              "rgemm_h3_kernel<0>", "rgemm_h3_kernel<1>", "rgemm_h3_kernel<2>"],
           "chain_kernel": ["chain_x6_kernel<1,true,16>", "chain_x6_kernel<2,true,3>", "chain_x6_kernel<1,false,16>",
                            "chain_x6_kernel<0,false,3>", "chain_kernel"],
           "sampler_beta_kernel": ["sampler_beta_kernel"], "sampler_sample_kernel": ["sampler_sample_kernel"],

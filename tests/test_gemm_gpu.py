@@ -614,6 +614,70 @@ def test_gemm_h3_overflow_falls_back_to_r6_with_its_row_maxima():
     assert Kk.h3_overflow_count(dev) == n0 + 1 and torch.equal(am, o3.abs().amax(1))
 
 
+def _pack_bits(x):
+    """[P, 256] bool -> [P, 8] int32, bit n of row p = x[p, n] (the layout of hold_gemm_h3_bits)"""
+    w = (x.view(x.shape[0], 8, 32).to(torch.int64) << torch.arange(32, device=x.device)).sum(-1)
+    return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
+
+
+@pytest.mark.parametrize("P", [128 * 5, 128 * 70 + 37, 31])
+def test_gemm_h3_relu_bits_and_the_masked_launch_that_reads_them(P):
+    """hold_gemm_h3_bits (round 6): a ReLU launch also writes its mask as one bit per element, and the backward's masked launch reads
+    those 32 bytes per point instead of streaming the fp32 activation again -- same result, bit for bit, as masking by the
+    activation itself (texture_net.py:95-101: ReLU after lin0..3; autograd multiplies the cotangent by (activation > 0))"""
+    from hold_amd import field as F, gemm
+    dev = _dev()
+    torch.manual_seed(P)
+    A = torch.randn(P, 256, device=dev)
+    W1, W2 = torch.randn(256, 256, device=dev) / 16, torch.randn(256, 256, device=dev) / 16
+    b = torch.randn(256, device=dev) * 0.3
+    pk1, c31 = F.pack_gemm_h3(W1)
+    pk2, c32 = F.pack_gemm_h3(W2)
+    r, bits, am = torch.empty(P, 256, device=dev), torch.full((P, 8), 0x5a5a5a5a, dtype=torch.int32, device=dev), torch.empty(P, device=dev)
+    gemm.gemm_h3(A, pk1, c31, r, K=256, wpack_r6=F.pack_gemm_r6(W1), bias=b, epi=gemm.R6_RELU, amax_in=A.abs().amax(1).contiguous(),
+                 amax_out=am, bits_out=bits)
+    assert 0.2 < float((r > 0).float().mean()) < 0.8
+    assert torch.equal(bits, _pack_bits(r > 0))
+    r_plain = torch.empty_like(r)
+    gemm.gemm_h3(A, pk1, c31, r_plain, K=256, wpack_r6=F.pack_gemm_r6(W1), bias=b, epi=gemm.R6_RELU, amax_in=A.abs().amax(1).contiguous())
+    assert torch.equal(r_plain, r)  # writing the bits changes nothing else
+    cot = torch.randn(P, 256, device=dev) * (10.0 ** (torch.rand(P, 1, device=dev) * 8 - 6))
+    am_c = cot.abs().amax(1).contiguous()
+    o_aux, o_bits = torch.empty(P, 256, device=dev), torch.empty(P, 256, device=dev)
+    ao_aux, ao_bits = torch.empty(P, device=dev), torch.empty(P, device=dev)
+    gemm.gemm_h3(cot, pk2, c32, o_aux, K=256, wpack_r6=F.pack_gemm_r6(W2), epi=gemm.R6_MASK, aux=r, amax_in=am_c, amax_out=ao_aux)
+    gemm.gemm_h3(cot, pk2, c32, o_bits, K=256, wpack_r6=F.pack_gemm_r6(W2), epi=gemm.R6_MASK, aux=r, amax_in=am_c, amax_out=ao_bits,
+                 bits_in=bits)
+    assert torch.equal(o_bits, o_aux) and torch.equal(ao_bits, ao_aux)
+    assert torch.equal(o_bits != 0, (o_bits != 0) & (r > 0))  # (masked entries are exact zeros)
+
+
+def test_gemm_h3_relu_bits_are_rebuilt_when_the_launch_falls_back():
+    """an overflowing ReLU launch is recomputed by hold_gemm_r6_if, which rewrites C but knows nothing of the bits: the third
+    conditional launch (relu_bits_if_kernel: fallback count moved since it last looked) rebuilds them from the recomputed C"""
+    from hold_amd import field as F, gemm, kernels as Kk
+    dev = _dev()
+    P, K = 40000, 256
+    torch.manual_seed(4)
+    A = torch.randn(P, K, device=dev)
+    A[2345:2349] *= 1e4
+    W = torch.randn(256, K, device=dev) / 16
+    b = torch.randn(256, device=dev)
+    pk, c3 = F.pack_gemm_h3(W)
+    o3, o6 = torch.empty(P, 256, device=dev), torch.empty(P, 256, device=dev)
+    bits = torch.zeros(P, 8, dtype=torch.int32, device=dev)
+    n0 = Kk.h3_overflow_count(dev)
+    gemm.gemm_h3(A, pk, c3, o3, K=K, wpack_r6=F.pack_gemm_r6(W), bias=b, epi=gemm.R6_RELU, amax_floor=64.0, bits_out=bits)
+    gemm.gemm_r6(A, F.pack_gemm_r6(W), o6, K=K, bias=b, epi=gemm.R6_RELU)
+    g = Kk.h3_guard(dev).tolist()
+    assert Kk.h3_overflow_count(dev) == n0 + 1 and g[:2] == [0, 0] and g[3] == g[2]
+    assert torch.equal(o3, o6) and torch.equal(bits, _pack_bits(o6 > 0))
+    A[2345:2349] *= 1e-4  # no overflow: the bits come from the kernel's own registers, the third launch exits at once
+    bits.fill_(-1)
+    gemm.gemm_h3(A, pk, c3, o3, K=K, wpack_r6=F.pack_gemm_r6(W), bias=b, epi=gemm.R6_RELU, amax_floor=64.0, bits_out=bits)
+    assert Kk.h3_overflow_count(dev) == n0 + 1 and torch.equal(bits, _pack_bits(o3 > 0))
+
+
 @pytest.mark.parametrize("rscale,xscale", [(1e-9, 1.0), (3e-7, 40.0), (1e4, 1e-5), (1.0, 1.0)])
 def test_wgrad_h3_scales_follow_the_operands(rscale, xscale):
     """the two-limb fp16 weight gradient picks power-of-two operand scales per workgroup from a sample of its rows: loss
