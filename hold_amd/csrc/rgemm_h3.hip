@@ -117,7 +117,9 @@ __device__ __forceinline__ void dma_piece(const char* src, uint32_t voff, uint32
 // ABL (developer build, results garbage, timing only): 1 = the input / mask pieces are requested in the SHAPE of whole lines (lane L -> row
 // 8 i + L / 8, 16-byte chunk L % 8 of a 32-column tile: the four pieces of two k steps cover a [32 rows][128 B] tile, as csrc/rchain_h3.hip's
 // side tiles do) instead of 32-byte row fragments; 2 = the result stores too.  Same bytes, same instruction counts, same queue: what the
-// access shape alone costs -- the upper bound of what whole-line tiles through LDS could gain this kernel
+// access shape alone costs -- the upper bound of what whole-line tiles through LDS could gain this kernel.  3 / 4: column rotation per
+// workgroup (without / with whole lines).  5: every k step re-reads the weights of stream step 0 (hot in L1 / L2); 6: every block re-reads
+// the input / mask rows of the workgroup's first block (hot in the L2); 7: no result stores -- which of its three streams the kernel waits for
 template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rgemm_h3_kernel(RGArgs a) {
   constexpr int NSIDE = EPI == EPI_MASK ? 2 : 1;  // side matrices: the input, and the mask operand
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int SD = side_dist(NSIDE), SIDE_RING = side_ring(NSIDE);
   constexpr int OFF_SIDE = R3 * SLOT;
   constexpr int OFF_BIAS = OFF_SIDE + NW * SIDE_RING * SIDE_SLOT;
+  constexpr int OFF_RT = OFF_BIAS + 1024;  // wave-private result tiles, [32 rows][128 B] each (see "result stores" below)
   // VMEM operations that may stay in flight at a rendezvous.  Queue of a k step: W x 4, store, S x 2 NSIDE, store.  The rendezvous of
   // step j needs (a) the weights issued in step j - 2: 8 + 4 NSIDE younger operations; (b) the side fragments consumed before the
   // next rendezvous, i.e. the k step j + 2's, issued in step j + 2 - SD: 7 + 2 NSIDE younger operations at SD = 4, one whole step
@@ -258,6 +261,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   rsrc_t crs = make_rsrc(nullptr, 0);  // stores of the block held in P (none before the first block is finished)
   const rsrc_t nullrs = make_rsrc(nullptr, 0);
   uint32_t cvoff = 0;
+  // ---- result stores as WHOLE LINES (csrc/rchain_h3.hip's result tiles).  A unit's two 16-byte fragments per lane -- 32 rows x 32
+  // bytes per store instruction, four partial writes per 128-byte line that only the L2 merges -- cost this kernel 20-30 % of its
+  // time (developer-build ablations, GPU calls 38 / 39: no stores 0.66-0.92 ms, whole-line stores 0.83-1.07, fragments 0.96-1.34).
+  // Now the epilogue writes them into a wave-private tile [32 rows][128 B] of two units (position p of row r holds chunk p ^ f(r):
+  // the sweeps' swizzle, conflict-free both ways); one k step after the tile's second unit it is read back lane-linear -- piece i =
+  // rows 8 i .. 8 i + 7, eight lanes per row -- and leaves as four stores of eight whole lines each, two per k step, so the queue
+  // keeps its shape: unit e >= 2 even: read back tile e / 2 - 1 (stage 0), store its pieces 0, 1; e >= 3 odd: pieces 2, 3.  The last
+  // tile of a block is read back with "unit" 16 (the block's last k step); with KS = 16 its pieces 2, 3 leave at the next block's
+  // unit 0 with the OLD block's row offsets and descriptor (sv_old, crs_prev), or behind the loop.
+  char* rt_lane_w = smem + OFF_RT + wave * 4096 + li * 128;  // + ((chunk ^ fl) << 4)
+  const int fl = ((li >> 1) & 7) ^ ((li & 1) << 2);
+  const char* rt_lane_r = smem + OFF_RT + wave * 4096 + lane * 16;  // + 1024 i
+  const int r8 = lane >> 3, p8 = lane & 7;
+  const int f0 = (r8 >> 1) ^ ((r8 & 1) << 2);  // f(8 i + r8) = f0 ^ ((i & 1) << 2)
+  f32x4 rb[4];
+  uint32_t sv[4] = {0u, 0u, 0u, 0u}, sv_old[2] = {0u, 0u};
+  rsrc_t crs_prev = make_rsrc(nullptr, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // Preparation of k step / epilogue unit e (side slot e & 3), four stages of micro-operations:
   //   stage 0: the 8 input values (and mask values) from the side ring, the 8 values of P's unit e (un-scaled)
@@ -289,6 +311,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         RG_PIN(t);
         st.y[i] = t;
       }
+      if (ABL == 0 && e >= 2 && (e & 1) == 0 && e <= 16 && (i & 1) == 1) {  // i = 1, 3, 5, 7: piece i / 2 of the finished tile
+        rb[i >> 1] = *reinterpret_cast<const f32x4*>(rt_lane_r + (i >> 1) * 1024);
+      }
     } else if (stage == 1) {
       if (!unit) return;
       if (k < 8) {
@@ -318,12 +343,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // launches with K = 304 a workgroup read a ring slot before its pieces had landed (round 6, GPU call 16: the same latent
         // race was in csrc/rgemm.hip since round 3).  Without a unit the store goes to a zero-length descriptor: dropped, counted.
         const f32x4 v = {st.y[4 * h2], st.y[4 * h2 + 1], st.y[4 * h2 + 2], st.y[4 * h2 + 3]};
-        if (ABL == 2 && unit) {  // timing ablation: the same 1 KiB per instruction as 8 whole lines of the unit pair's [32][128 B] tile
+        if (ABL == 7) {  // timing ablation: no result traffic (the store is issued to the zero-length descriptor: dropped, counted)
+          store4(v, nullrs, 0u);
+          return;
+        }
+        if ((ABL == 2 || ABL == 8) && unit) {  // (8: whole-line stores with the product's fragment loads)  // timing ablation: the same 1 KiB per instruction as 8 whole lines of the unit pair's [32][128 B] tile
           const long r = row_P + 8 * (2 * (e & 1) + h2) + (lane >> 3);
           store4(v, crs, (uint32_t)((r * a.ldc + 32 * (e >> 1) + 4 * (lane & 7)) * 4));
           return;
         }
-        store4(v, unit ? crs : nullrs, unit ? cvoff + (16 * e + 8 * h2) * 4 : 0u);
+        if (ABL != 0) {  // (the ablations keep the fragment stores they were written against)
+          store4(v, unit ? crs : nullrs, unit ? cvoff + (16 * e + 8 * h2) * 4 : 0u);
+          return;
+        }
+        // the store of this slot: a piece of the tile finished before (see "result stores" above), or none (zero-length descriptor)
+        if (e == 0) store4(rb[2 + h2], KS > 16 ? nullrs : crs_prev, sv_old[h2] + 128 * 7);
+        else if (e == 1 || e > 17) store4(rb[0], nullrs, 0u);
+        else if ((e & 1) == 0) store4(rb[h2], crs, sv[h2] + 128 * (e / 2 - 1));
+        else store4(rb[2 + h2], crs, sv[2 + h2] + 128 * ((e - 3) / 2));
+        if (unit)  // this unit's fragment into the tile: chunk 4 (e % 2) + 2 h2 + hh of row li
+          *reinterpret_cast<f32x4*>(rt_lane_w + (((4 * (e & 1) + 2 * h2 + hh) ^ fl) << 4)) = v;
         return;
       }
       const int d = k & 1, op = k >> 1;
@@ -360,12 +399,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // j + SD >= KS), and cnt[group] / 6 micro-operations.
   constexpr bool WL = ABL == 1 || ABL == 2 || ABL == 4;
   uint32_t abl_o1[2] = {0u, 0u}, abl_o2[2] = {0u, 0u};
+  const uint32_t abl_in0 = in_off, abl_ax0 = ax_off_prev;
   auto kstep = [&](int j, const int (&cnt)[4], auto&& mp) {
     // KS % R3 == 0 and every block starts a new pass over the stream: ring slots are compile-time functions of j
     const int slot = j % R3, nslot = (j + 1) % R3, fslot = (j + R3 - 1) % R3;
     int jw = j + R3 - 1;
     jw = jw >= KS ? jw - KS : jw;
-    const char* wsrc = wbase + (long)jw * SLOT + wave * (4 * PIECE);
+    const char* wsrc = wbase + (long)(ABL == 5 ? 0 : jw) * SLOT + wave * (4 * PIECE);  // (ABL 5: every step re-reads stream step 0 -- L1 / L2-hot weights)
     const uint32_t wdst = (uint32_t)(fslot * SLOT + wave * (4 * PIECE));
     const int e4 = j + SD;
     const bool wrap = e4 >= KS;
@@ -375,6 +415,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     uint32_t o1 = wrap ? in_off_next : in_off;
     const char* s2 = Xb + 64 * (ec < 16 ? ec : 15);
     uint32_t o2 = wrap ? ax_off_cur : ax_off_prev;  // unit ec of the block in P, or (wrapped) of the running block
+    if (ABL == 6) {  // timing ablation: every block reads the input / mask rows of the workgroup's FIRST block (they stay in the L2)
+      o1 = abl_in0;
+      o2 = abl_ax0;
+    }
     if (ABL == 3 || ABL == 4) {  // timing ablation: every workgroup walks the K columns from its own starting tile (2 (blockIdx % 8) k steps
       // on): do all workgroups reading the same 128-byte column at the same time camp on a few channels?
       const int er = ((ec < a.K16 ? ec : 0) + 2 * (int)(blockIdx.x & 7)) & 15;
@@ -481,8 +525,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     row_P = blk * BPTS + wave * 32;
     am_cur = am_next;
     const long row = blk * BPTS + wave * 32 + li;  // unclamped: the buffer range check drops rows >= P
+    crs_prev = crs;
+    sv_old[0] = sv[2];
+    sv_old[1] = sv[3];
     crs = make_rsrc(a.C, cbytes);
     cvoff = (uint32_t)((row * a.ldc + 4 * hh) * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)  // whole-line pieces of this block's rows: lane -> (row 8 i + r8, chunk p8 ^ f); range-checked stores
+      sv[i] = (uint32_t)(((row_P + 8 * i + r8) * a.ldc + 4 * (p8 ^ f0 ^ ((i & 1) << 2))) * 4);
     in_off = in_off_next;
     in_off_next = (uint32_t)((clamp_row(blk + 2 * (long)gridDim.x) * a.lda + 4 * hh) * 4);
     ax_off_prev = ax_off_cur;
@@ -490,6 +540,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   RG_WAIT_VM(0);  // no LDS-DMA in flight when the workgroup's LDS is released
   (void)no_mop; (void)CNT_NONE; (void)xbytes;
+  if (ABL == 0) {  // the last tile's pieces 2, 3 of the block stored during the last iteration (KS = 20 stored them with unit 17)
+    store4(rb[2], KS > 16 ? nullrs : crs_prev, sv_old[0] + 128 * 7);
+    store4(rb[3], KS > 16 ? nullrs : crs_prev, sv_old[1] + 128 * 7);
+  }
   // ---- epilogue of the last block (exposed): mask rows by ordinary buffer loads ----
   {
     const rsrc_t xrs = make_rsrc(EPI == EPI_MASK ? a.aux : nullptr, xbytes);
@@ -528,7 +582,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 template <int EPI>
 int launch_h3(const RGArgs& a, hipStream_t s) {
   constexpr int NSIDE = EPI == EPI_MASK ? 2 : 1;
-  constexpr int lds = R3 * SLOT + NW * side_ring(NSIDE) * NSIDE * 2 * PIECE + 1024;
+  constexpr int lds = R3 * SLOT + NW * side_ring(NSIDE) * NSIDE * 2 * PIECE + 1024 + NW * 4096;
   static_assert(lds <= 160 * 1024, "LDS budget");
 #ifdef HOLD_DEV
   if (const char* v = getenv("HOLD_RG_ABL")) {  // developer build: access-shape ablations (results garbage)
@@ -555,6 +609,26 @@ int launch_h3(const RGArgs& a, hipStream_t s) {
     if (v[0] == '4') {
       if (hipFuncSetAttribute((const void*)rgemm_h3_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return HOLD_E_LAUNCH;
       hipLaunchKernelGGL((rgemm_h3_kernel<EPI, 4>), grid_, dim3(256), lds, s, a);
+      return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+    }
+    if (v[0] == '5') {
+      if (hipFuncSetAttribute((const void*)rgemm_h3_kernel<EPI, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return HOLD_E_LAUNCH;
+      hipLaunchKernelGGL((rgemm_h3_kernel<EPI, 5>), grid_, dim3(256), lds, s, a);
+      return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+    }
+    if (v[0] == '6') {
+      if (hipFuncSetAttribute((const void*)rgemm_h3_kernel<EPI, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return HOLD_E_LAUNCH;
+      hipLaunchKernelGGL((rgemm_h3_kernel<EPI, 6>), grid_, dim3(256), lds, s, a);
+      return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+    }
+    if (v[0] == '7') {
+      if (hipFuncSetAttribute((const void*)rgemm_h3_kernel<EPI, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return HOLD_E_LAUNCH;
+      hipLaunchKernelGGL((rgemm_h3_kernel<EPI, 7>), grid_, dim3(256), lds, s, a);
+      return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
+    }
+    if (v[0] == '8') {
+      if (hipFuncSetAttribute((const void*)rgemm_h3_kernel<EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return HOLD_E_LAUNCH;
+      hipLaunchKernelGGL((rgemm_h3_kernel<EPI, 8>), grid_, dim3(256), lds, s, a);
       return hipGetLastError() == hipSuccess ? HOLD_OK : HOLD_E_LAUNCH;
     }
   }
