@@ -59,7 +59,8 @@ constexpr int OFF_BIAS = RING * SLOT;               // [8][256] fp32, pre-scaled
 constexpr int OFF_W8 = OFF_BIAS + 8 * 256 * 4;      // [256] fp32
 constexpr int OFF_EMB = OFF_W8 + 256 * 4;           // [4 waves][32 points][EMB_STR] fp32 (wave-private), scaled by SA
 constexpr int OFF_BARF = OFF_EMB + NW * 32 * EMB_STR * 4;  // [64] fp32: SA x BARF weights of the 39 embedding columns
-constexpr int LDS_BYTES = OFF_BARF + 64 * 4;
+constexpr int OFF_RT = (OFF_BARF + 64 * 4 + 1023) & ~1023;  // STORE: wave-private result tiles [32 rows][128 B] (whole-line h stores)
+constexpr int LDS_BYTES = OFF_RT + NW * 4096;
 static_assert(L0S % RING == 0 && LKS % RING == 0, "the ring slot of a k step must not depend on the layer");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
@@ -395,6 +396,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     rsrc_t hrs = make_rsrc(nullptr, 0);
     const uint32_t hbytes = (uint32_t)(a.P * a.ldh * 4);
     const uint32_t hvoff = (uint32_t)(((p0 + li) * a.ldh + 4 * hh) * 4);
+    // ---- STORE: the h rows leave as WHOLE LINES (csrc/rgemm_h3.hip "result stores", csrc/rchain_h3.hip's result tiles).  A unit's
+    // two 16-byte fragments per lane are kept in registers (dv) until the NEXT unit's first micro-operations write them into a
+    // wave-private tile [32 rows][128 B] of two units (position p of row r holds chunk p ^ f(r)); an even unit j then reads the
+    // finished tile back lane-linear (piece i = rows 8 i .. 8 i + 7, eight lanes per row); the two store slots of a unit -- unchanged
+    // in number and place, so the vector-memory queue keeps its shape -- send pieces 0, 1 (even unit) and 2, 3 (odd unit) of that
+    // tile as eight whole lines each.  Tile 7 of a layer is finished by the next layer's unit 0 and leaves with its units 0 and 1
+    // (descriptor of the previous layer: hrs_prev); behind layer 7's last k step it is flushed.
+    char* rt_lane_w = smem + OFF_RT + wave * 4096 + li * 128;      // + ((chunk ^ fl) << 4)
+    const int fl = ((li >> 1) & 7) ^ ((li & 1) << 2);
+    const char* rt_lane_r = smem + OFF_RT + wave * 4096 + lane * 16;  // + 1024 i
+    uint32_t sv[4];
+    {
+      const int r8 = lane >> 3, p8 = lane & 7, f0 = (r8 >> 1) ^ ((r8 & 1) << 2);  // f(8 i + r8) = f0 ^ ((i & 1) << 2)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sv[i] = (uint32_t)(((p0 + 8 * i + r8) * a.ldh + 4 * (p8 ^ f0 ^ ((i & 1) << 2))) * 4);
+    }
+    rsrc_t hrs_prev = make_rsrc(nullptr, 0);
+    f32x4 dv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 rb[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     // Epilogue of k step j = (nt, q) of the finished layer: its 8 values P[nt][8 q + i] (features 32 nt + 16 q + 8 (i / 4) +
     // 4 hh + i % 4) as a flat list of micro-operations, ROUND-MAJOR: a round works on the 8 values (one instruction each) or, where
     // a packed fp32 instruction exists, on the 4 value PAIRS (2 i, 2 i + 1) -- consecutive micro-operations are independent.
@@ -438,6 +458,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                   (k >= 48) + (k >= 56) + (k >= 60) + (k >= 68) + (k >= 76) + (k >= 80) + (k >= 88);
         const int i = k - (HEAD ? bH[rd] : bS[rd]);  // value 0..7 or pair 0..3 within the round
         const int p = i >> 1, c = i & 1;             // (per-value rounds) pair and component of value i
+        if (STORE && k < 2)  // the fragments of the unit before (chunk 4 q' + 2 h2 + hh of row li; unit 0: the previous layer's unit 15)
+          *reinterpret_cast<f32x4*>(rt_lane_w + (((4 * ((j + 1) & 1) + 2 * k + hh) ^ fl) << 4)) = dv[k];
+        if (STORE && (j & 1) == 0 && k >= 2 && k < 6)  // ... which completed a tile: read it back (pieces 0..3)
+          rb[k - 2] = *reinterpret_cast<const f32x4*>(rt_lane_r + (k - 2) * 1024);
         if (rd == 0) { st.y[p][c] = P[nt][8 * q + i]; H3_PIN(st.y[p]); }
         else if (rd == 1) { st.y[i] = pk_mul(st.y[i], c3); }
         else if (rd == 2) { st.e[p][c] = KE * fabsf(st.y[p][c]); H3_PIN(st.e[p]); }
@@ -476,7 +500,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       } else {  // STORE: the four consecutive features of half h2
         const int h2 = k - (NSP + 16);
         const f32x4 v = {st.o[2 * h2][0], st.o[2 * h2][1], st.o[2 * h2 + 1][0], st.o[2 * h2 + 1][1]};
-        store4(v, hrs, hvoff + (32 * nt + 16 * q + 8 * h2) * 4);
+        if (j == 0) store4(rb[h2], hrs_prev, sv[h2] + 128 * 7);            // the previous layer's last tile
+        else if (j == 1) store4(rb[2 + h2], hrs_prev, sv[2 + h2] + 128 * 7);
+        else if ((j & 1) == 0) store4(rb[h2], hrs, sv[h2] + 128 * (j / 2 - 1));
+        else store4(rb[2 + h2], hrs, sv[2 + h2] + 128 * ((j - 3) / 2));
+        dv[h2] = v;
       }
     };
     const char* lsrc = wsrc0 + (long)(L0S + AHEAD) * SLOT;  // this wave's pieces of the step AHEAD behind the layer's first
@@ -493,7 +521,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       f32x2 c3 = {c3s, c3s};
       H3_PIN(c3);
       EpiState st;
-      if (STORE) hrs = make_rsrc(a.h[layer - 1], hbytes);
+      if (STORE) {
+        hrs_prev = hrs;
+        hrs = make_rsrc(a.h[layer - 1], hbytes);
+      }
 #pragma unroll
       for (int k = 0; k < NOPS; ++k) epi_mop(layer, c3, 0, k, Bc, st);
 #pragma unroll
@@ -506,6 +537,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           kstep(j, src, SchedNone(), no_mop);
       }
       lsrc += (long)LKS * SLOT;
+    }
+    if (STORE) {  // layer 6's last tile: unit 15's fragments, read-back, four whole-line stores (exposed, once per block)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) *reinterpret_cast<f32x4*>(rt_lane_w + (((4 + 2 * h2 + hh) ^ fl) << 4)) = dv[h2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4*>(rt_lane_r + i * 1024);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) store4(rb[i], hrs, sv[i] + 128 * 7);
     }
     // ---- output of layer 7 ----
     {
