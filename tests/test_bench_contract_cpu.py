@@ -1,5 +1,5 @@
 """The bench line's contract, checked on the committed output of the default command (profiles/r06_bench_final.json is what
-`python bench.py` printed on an MI355X, scripts/lease_logs/r6_call35.sh) and on bench.py's command line -- no GPU needed."""
+`python bench.py` printed on an MI355X, scripts/lease_logs/r6_call43.sh) and on bench.py's command line -- no GPU needed."""
 import json
 import os
 import subprocess
